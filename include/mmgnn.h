@@ -1,0 +1,197 @@
+/*
+ * mmgnn.h -- C ABI of libmmgnn.so: MI355X (gfx950) kernels for the heterogeneous-GNN
+ * message-passing hot path of AdalineL/Multi-Modal-GNN.
+ *
+ * The reference is pure Python; its "FFI" for this path is the set of ATen / PyG operators
+ * that src/model.py dispatches.  Each entry point below names the reference expression it
+ * replaces (paths relative to the reference repo).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", returns 0 on success, <0 on error (MMG_E_*); the message is available from
+ *     mmg_last_error() (thread-local).
+ *   - The CALLER owns every buffer: device pointers to contiguous, 16-byte aligned memory.
+ *     No allocation, no synchronisation, no global mutable state inside; everything is
+ *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ *   - Indices are int32 inside (row/col counts are checked to be < 2^31); the edge_index
+ *     handed to mmg_csr_build is the reference's int64 [2,E] row-major tensor.
+ *   - All features are fp32.  D (feature width) must be 64, 128 or 256.
+ *   - Workspace: *_ws_bytes() twins return the scratch size a call needs.
+ */
+#ifndef MMGNN_H
+#define MMGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMG_OK 0
+#define MMG_E_ARG (-1)     /* bad argument (shape, null pointer, unsupported D) */
+#define MMG_E_LAUNCH (-2)  /* HIP launch / runtime error */
+#define MMG_E_WS (-3)      /* workspace too small */
+
+#define MMG_MAX_REL 4      /* relations fused in one aggregate launch */
+
+int mmg_version(void);
+const char* mmg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * CSR construction (consumes the tensors of
+ * src/graph_build.py:476-586).  Stable sort of edge ids by edge_index[sort_row]:
+ *   rowptr[n_rows+1], col[E] = edge_index[1-sort_row][perm], perm[E] = original edge id.
+ * Bit-exact with torch.sort(stable=True) + bincount + cumsum.
+ * ------------------------------------------------------------------------------------- */
+size_t mmg_csr_build_ws_bytes(int64_t n_edges, int64_t n_rows);
+int mmg_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_rows, int sort_row,
+                  int32_t* rowptr, int32_t* col, int32_t* perm,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* deg[i] = rowptr[i+1]-rowptr[i]; inv[i] = 1/max(deg,1)  (PyG mean aggregation's clamp;
+ * also torch.bincount of src/model.py:297-298 when called on the has_lab CSR) */
+int mmg_row_degree(const int32_t* rowptr, int64_t n_rows, int32_t* deg, float* inv_deg, void* stream);
+/* in-degree of the column side: cnt[j] = #edges with col == j; inv[j] = 1/max(cnt,1) */
+int mmg_col_degree(const int32_t* col, int64_t n_edges, int64_t n_cols, int32_t* cnt, float* inv_cnt,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sparse aggregates (replace PyG SAGEConv's gather + scatter-mean, call site
+ * src/model.py:125-131,256, and their backward).  All relations share the ROW axis
+ * (patients, CSR-by-patient), so up to MMG_MAX_REL relations are fused per launch.
+ *
+ * gather:   out[i,:] (+)= sum_r  rowscale_r[i] * sum_{k in row_r(i)} table_r[col_r[k], :]
+ *           (vocab -> patient forward; patient -> vocab backward)
+ * scatter:  out_r[j,:]  = colscale_r[j] * sum_{k: col_r[k]=j} rowscale_r[row(k)] * x[row(k), :]
+ *           (patient -> vocab forward; vocab -> patient backward)
+ * rowscale / colscale entries may be NULL (= 1).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const int32_t* rowptr;   /* [n_rows+1] */
+  const int32_t* col;      /* [E] */
+  const float* rowscale;   /* [n_rows] or NULL */
+  const float* colscale;   /* [n_cols] or NULL */
+  const float* table;      /* gather: [n_cols, D] source rows */
+  float* out;              /* scatter: [n_cols, D] destination rows */
+  int32_t n_cols;
+} mmg_rel_t;
+
+int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
+                    float* out, int accumulate, void* stream);
+
+size_t mmg_scatter_rows_ws_bytes(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D);
+int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
+                     const float* x, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense layers on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replace torch.nn.Linear /
+ * BatchNorm1d / ReLU / Dropout / F.normalize of src/model.py:93-105,229-232,258-269 and the
+ * lin_l / lin_r of SAGEConv.
+ *
+ * Prologue applied to X on load (all optional):
+ *   x' = dropout( relu( x * scale[k] + shift[k] ) )      scale/shift = folded BatchNorm
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* scale;      /* [K] or NULL: no affine */
+  const float* shift;      /* [K] */
+  int relu;                /* apply max(.,0) after the affine */
+  float drop_p;            /* 0 = no dropout */
+  uint64_t seed;           /* dropout RNG: keep(seed, site, global_row*K + k) */
+  uint32_t site;
+  int64_t row_offset;      /* global index of row 0 (patient sharding) */
+} mmg_prologue_t;
+
+/* Y[M,N] = prologue(X)[M,K] . W[N,K]^T (+ bias[N]) (+ Y if accumulate)            */
+int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
+                   float* Y, int64_t M, int N, int K, int accumulate, void* stream);
+
+/* dW[N,K] (+)= dY[M,N]^T . prologue(X)[M,K]   (reduction over the M rows)          */
+size_t mmg_linear_wgrad_ws_bytes(int64_t M, int N, int K);
+int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW,
+                     int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* column reductions over rows: out[0,:] = sum_m A[m,:], out[1,:] = sum_m A[m,:]*B[m,:] (fp64 out) */
+size_t mmg_col_reduce2_ws_bytes(int64_t M, int N);
+int mmg_col_reduce2(const float* A, const float* B, double* out, int64_t M, int N,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* BatchNorm statistics -> folded scale/shift (+ running-stat update, momentum 0.1, unbiased var)
+ *   sums[2,N] fp64 = (sum y, sum y^2) over `count` rows (already all-reduced when sharded).
+ *   training != 0: mean/var from sums; running_* updated `n_updates` times (F7 double update).
+ *   training == 0: scale/shift from running stats.
+ *   Outputs: scale[N] = gamma*rstd, shift[N] = beta - mean*scale, mean[N], rstd[N]. */
+int mmg_bn_finalize(const double* sums, int64_t count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int training, int n_updates,
+                    float momentum, float eps, float* scale, float* shift, float* mean, float* rstd,
+                    int N, void* stream);
+
+/* out = dropout(relu(y*scale + shift))  materialised                                */
+int mmg_affine_act_drop(const float* Y, const mmg_prologue_t* pro, float* out, int64_t M, int N,
+                        void* stream);
+
+/* Backward through dropout -> relu -> affine(BN):
+ *   g_out = g * keepmask/(1-p) * [y*scale+shift > 0]
+ * pass 1 (stats):  sums[0,:] = sum g_out ; sums[1,:] = sum g_out * xhat,  xhat = (y-mean)*rstd
+ * pass 2 (apply):  dy = scale * (g_out - c0[k] - xhat*c1[k]),  c0 = sums0/count, c1 = sums1/count
+ *                  (eval mode: c0 = c1 = 0) */
+int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
+                     const float* rstd, double* sums, int64_t M, int N, void* ws, size_t ws_bytes,
+                     void* stream);
+int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
+                     const float* rstd, const float* c0, const float* c1, float* dY, int64_t M, int N,
+                     void* stream);
+
+/* Row L2 normalisation, F.normalize(p=2, dim=1, eps): out = z / max(||z||, eps); rnorm = 1/max(..) */
+int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, float eps, void* stream);
+/* dz = rnorm * (g - out * <out, g>)   (rows whose norm hit eps: dz = g * rnorm)     */
+int mmg_l2norm_bwd(const float* G, const float* out, const float* rnorm, float* dZ, int64_t M, int N,
+                   float eps, void* stream);
+
+/* keep-mask of the dropout RNG, for injected-mask parity tests: mask[i] in {0,1}     */
+int mmg_dropout_mask(uint64_t seed, uint32_t site, int64_t first_elem, int64_t n_elems, float p,
+                     uint8_t* mask, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Degree-gated dual edge head (src/model.py:305-333, EdgeRegressionHead :342-396).
+ * The first Linear(2D,64) is split: A = x_P . W1[:, :D]^T (per patient), B = x_lab . W1[:, D:]^T + b1
+ * (per lab) -- computed by mmg_linear_fwd -- so that per pair
+ *   h1 = drop(relu(A[pi] + B[li])); h2 = drop(relu(W2 h1 + b2)); pred = W3 h2 + b3
+ * edge_predictor runs on the final embeddings, tabular_mlp on the initial ones; the head is
+ * chosen per pair by deg[pi] < degree_threshold (src/model.py:312-315).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* A;          /* [n_patients, 64] */
+  const float* B;          /* [n_labs, 64] (bias b1 folded in) */
+  const float* W2;         /* [32, 64] */
+  const float* b2;         /* [32] */
+  const float* W3;         /* [32] */
+  const float* b3;         /* [1] */
+} mmg_head_t;
+
+typedef struct {
+  float* dA;               /* [n_patients, 64]  accumulated (+=) */
+  float* dB;               /* [n_labs, 64]      accumulated (+=) */
+  float* dW2;              /* [32, 64] += */
+  float* db2;              /* [32] += */
+  float* dW3;              /* [32] += */
+  float* db3;              /* [1] += */
+} mmg_head_grad_t;
+
+/* One launch evaluates ONE head on the pairs whose gate matches `want_low`
+ * (want_low = 1: deg[pi] < degree_threshold -> tabular_mlp; 0: the GNN edge_predictor);
+ * other pairs are left untouched in pred / contribute nothing to the gradients.
+ * pair_id (nullable) = original position of each pair, used only to key the dropout RNG so that
+ * a permuted (patient-sorted) pair list draws the same masks. */
+int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li,
+                      const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs,
+                      float drop_p, uint64_t seed, const int64_t* pair_id,
+                      float* pred, void* stream);
+int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,
+                      const int32_t* pi, const int32_t* li, const int32_t* deg, int degree_threshold,
+                      int want_low, int64_t n_pairs, int n_labs, float drop_p, uint64_t seed,
+                      const int64_t* pair_id, const float* dpred, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMGNN_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libmmgnn.so (C ABI: include/mmgnn.h).
+
+The library is REQUIRED: there is no CPU or eager-PyTorch fallback anywhere in this
+package.  If it is missing, importing the ops raises with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmgnn.so")
+
+MMG_MAX_REL = 4
+
+
+class MmgError(RuntimeError):
+    pass
+
+
+class RelT(C.Structure):
+    _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("rowscale", C.c_void_p),
+                ("colscale", C.c_void_p), ("table", C.c_void_p), ("out", C.c_void_p),
+                ("n_cols", C.c_int32)]
+
+
+class PrologueT(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int), ("drop_p", C.c_float),
+                ("seed", C.c_uint64), ("site", C.c_uint32), ("row_offset", C.c_int64)]
+
+
+class HeadT(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+                ("W3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class HeadGradT(C.Structure):
+    _fields_ = [("dA", C.c_void_p), ("dB", C.c_void_p), ("dW2", C.c_void_p), ("db2", C.c_void_p),
+                ("dW3", C.c_void_p), ("db3", C.c_void_p)]
+
+
+_vp, _i64, _i32, _f32, _sz, _u64, _u32 = (C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t,
+                                          C.c_uint64, C.c_uint32)
+_P = C.POINTER
+
+# name -> (restype, argtypes): every symbol include/mmgnn.h declares
+SIGNATURES = {
+    "mmg_version": (C.c_int, []),
+    "mmg_last_error": (C.c_char_p, []),
+    "mmg_csr_build_ws_bytes": (_sz, [_i64, _i64]),
+    "mmg_csr_build": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmg_row_degree": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "mmg_col_degree": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "mmg_gather_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _i32, _vp]),
+    "mmg_scatter_rows_ws_bytes": (_sz, [_P(RelT), _i32, _i64, _i32]),
+    "mmg_scatter_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "mmg_linear_fwd": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "mmg_linear_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32]),
+    "mmg_linear_wgrad": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "mmg_col_reduce2_ws_bytes": (_sz, [_i64, _i32]),
+    "mmg_col_reduce2": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
+    "mmg_bn_finalize": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,
+                                  _i32, _vp]),
+    "mmg_affine_act_drop": (C.c_int, [_vp, _P(PrologueT), _vp, _i64, _i32, _vp]),
+    "mmg_bn_bwd_stats": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
+    "mmg_bn_bwd_apply": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mmg_l2norm_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "mmg_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "mmg_dropout_mask": (C.c_int, [_u64, _u32, _i64, _i64, _f32, _vp, _vp]),
+    "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _f32, _u64, _vp, _vp, _vp]),
+    "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64,
+                                    _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmmgnn.so (once).  Raises MmgError loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MmgError(
+            f"{LIB_PATH} not found: the HIP library is mandatory (no CPU fallback). Build it with "
+            f"`make -C {os.path.join(_HERE, 'csrc')}` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().mmg_last_error()
+        raise MmgError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

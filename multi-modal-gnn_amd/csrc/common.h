@@ -1,0 +1,91 @@
+// Shared device/host helpers for libmmgnn (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/mmgnn.h"
+
+#define WAVE 64
+
+void mmg_set_error(const char* fmt, ...);
+
+#define MMG_CHECK_ARG(cond, ...)                   \
+  do {                                             \
+    if (!(cond)) {                                 \
+      mmg_set_error(__VA_ARGS__);                  \
+      return MMG_E_ARG;                            \
+    }                                              \
+  } while (0)
+
+#define MMG_CHECK_LAUNCH(what)                                                    \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      mmg_set_error("%s: %s", what, hipGetErrorString(e__));                      \
+      return MMG_E_LAUNCH;                                                        \
+    }                                                                             \
+  } while (0)
+
+static inline int mmg_valid_D(int D) { return D == 64 || D == 128 || D == 256; }
+
+// ------------------------------------------------------------------------------------
+// Counter-based dropout RNG: keep(seed, site, element) -- stateless, so the backward pass
+// regenerates the forward mask instead of storing it.  Two rounds of a murmur3-style
+// finaliser over (seed, site, 64-bit element index).
+// ------------------------------------------------------------------------------------
+__host__ __device__ static inline uint32_t mmg_mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__host__ __device__ static inline uint32_t mmg_rng_u32(uint64_t seed, uint32_t site, uint64_t elem) {
+  uint32_t h = mmg_mix32((uint32_t)seed ^ 0x9e3779b9u);
+  h = mmg_mix32(h ^ (uint32_t)(seed >> 32) ^ (site * 0x632be5abu));
+  h = mmg_mix32(h ^ (uint32_t)elem);
+  h = mmg_mix32(h + (uint32_t)(elem >> 32) * 0x27d4eb2fu + 0x165667b1u);
+  return h;
+}
+// keep with probability 1-p: 24-bit uniform >= p
+__host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, uint64_t elem, float p) {
+  float u = (float)(mmg_rng_u32(seed, site, elem) >> 8) * (1.0f / 16777216.0f);
+  return u >= p;
+}
+
+// folded prologue: dropout(relu(x*scale+shift)); returns the transformed value
+struct ProDev {
+  const float* scale; const float* shift; int relu; float p; float inv_keep; uint64_t seed; uint32_t site;
+  int64_t row_offset;
+};
+static inline ProDev mmg_pro_dev(const mmg_prologue_t* pro) {
+  ProDev d;
+  if (pro) {
+    d.scale = pro->scale; d.shift = pro->shift; d.relu = pro->relu; d.p = pro->drop_p;
+    d.inv_keep = pro->drop_p > 0.f ? 1.0f / (1.0f - pro->drop_p) : 1.0f;
+    d.seed = pro->seed; d.site = pro->site; d.row_offset = pro->row_offset;
+  } else {
+    d.scale = nullptr; d.shift = nullptr; d.relu = 0; d.p = 0.f; d.inv_keep = 1.f; d.seed = 0; d.site = 0;
+    d.row_offset = 0;
+  }
+  return d;
+}
+__device__ static inline float mmg_pro_apply(const ProDev& pr, float x, float sc, float sh, int64_t row,
+                                             int k, int K) {
+  float v = pr.scale ? fmaf(x, sc, sh) : x;
+  if (pr.relu) v = fmaxf(v, 0.f);
+  if (pr.p > 0.f) {
+    uint64_t e = (uint64_t)(pr.row_offset + row) * (uint64_t)K + (uint64_t)k;
+    v = mmg_keep(pr.seed, pr.site, e, pr.p) ? v * pr.inv_keep : 0.f;
+  }
+  return v;
+}
+
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ static inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,345 @@
+// HBM-bound row/column passes around the dense layers: BatchNorm statistics and backward,
+// ReLU/Dropout, row L2 normalisation (src/model.py:93-105, 229-232, 258-269 of the reference).
+// All loads/stores are 16 B per lane; column reductions accumulate in fp64 and are summed in a
+// fixed order (deterministic).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int CR_MAX_BLOCKS = 1024;
+
+struct ColGeom { int cg, rl; int nblk; int64_t rows_per_blk; };
+inline bool col_geom(int64_t M, int N, ColGeom* g) {
+  if (N % 4 || N / 4 > 256 || 256 % (N / 4)) return false;
+  g->cg = N / 4; g->rl = 256 / g->cg;
+  int64_t nb = (M + 63) / 64;
+  if (nb > CR_MAX_BLOCKS) nb = CR_MAX_BLOCKS;
+  if (nb < 1) nb = 1;
+  g->nblk = (int)nb;
+  g->rows_per_blk = (M + nb - 1) / nb;
+  return true;
+}
+
+// MODE 0: a = A, b = B (or A if B null)       -> (sum a, sum a*b)
+// MODE 1: BN backward stats: a = g_out(G,Y), b = xhat(Y)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ A, const float* __restrict__ B,
+                                                    ProDev pr, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, double* __restrict__ partial,
+                                                    int64_t M, int N, int64_t rows_per_blk) {
+  __shared__ double red[2 * 1024];   // [rl][2][N] with rl*N == 1024
+  const int cg = N / 4, rl = 256 / cg;
+  const int c4 = threadIdx.x % cg, rr = threadIdx.x / cg;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f};
+  if (MODE == 1) {
+    if (pr.scale) {
+      sc = *reinterpret_cast<const f32x4*>(pr.scale + c4 * 4);
+      sh = *reinterpret_cast<const f32x4*>(pr.shift + c4 * 4);
+    }
+    mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+    rs = *reinterpret_cast<const f32x4*>(rstd + c4 * 4);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
+  for (int64_t r = r0 + rr; r < r1; r += rl) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)r * N + c4 * 4);
+    const f32x4 b = B ? *reinterpret_cast<const f32x4*>(B + (size_t)r * N + c4 * 4) : a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float av = a[j], bv = b[j];
+      if (MODE == 1) {
+        // a = upstream grad G, b = pre-BN activation Y
+        const float o = pr.scale ? fmaf(bv, sc[j], sh[j]) : bv;
+        float g = av;
+        if (pr.relu && !(o > 0.f)) g = 0.f;
+        if (pr.p > 0.f) {
+          const uint64_t e = (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)(c4 * 4 + j);
+          g = mmg_keep(pr.seed, pr.site, e, pr.p) ? g * pr.inv_keep : 0.f;
+        }
+        av = g;
+        bv = (bv - mu[j]) * rs[j];
+      }
+      s0[j] += (double)av;
+      s1[j] += (double)av * (double)bv;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[(rr * 2 + 0) * N + c4 * 4 + j] = s0[j];
+    red[(rr * 2 + 1) * N + c4 * 4 + j] = s1[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    double s = 0;
+    for (int q = 0; q < rl; ++q) s += red[q * 2 * N + i];
+    partial[(size_t)blockIdx.x * 2 * N + i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_partial_sum(const double* __restrict__ partial, double* __restrict__ out, int n,
+                                                     int nblk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s = 0;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n + i];
+  out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ sums, int64_t count,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* running_mean, float* running_var, int training,
+                                                     int n_updates, float momentum, float eps, float* scale,
+                                                     float* shift, float* mean_out, float* rstd_out, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float mean, var;
+  if (training) {
+    const double m = sums[i] / (double)count;
+    double v = sums[N + i] / (double)count - m * m;
+    if (v < 0) v = 0;
+    mean = (float)m; var = (float)v;
+    if (running_mean) {
+      const float unb = (float)(v * ((double)count / (double)(count > 1 ? count - 1 : 1)));
+      float rm = running_mean[i], rv = running_var[i];
+      for (int u = 0; u < n_updates; ++u) {
+        rm = (1.f - momentum) * rm + momentum * mean;
+        rv = (1.f - momentum) * rv + momentum * unb;
+      }
+      running_mean[i] = rm; running_var[i] = rv;
+    }
+  } else {
+    mean = running_mean[i]; var = running_var[i];
+  }
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float g = gamma ? gamma[i] : 1.f, b = beta ? beta[i] : 0.f;
+  const float sc = g * rstd;
+  scale[i] = sc;
+  shift[i] = b - mean * sc;
+  if (mean_out) mean_out[i] = mean;
+  if (rstd_out) rstd_out[i] = rstd;
+}
+
+__global__ __launch_bounds__(256) void k_affine_act_drop(const float* __restrict__ Y, ProDev pr, float* __restrict__ out,
+                                                         int64_t M, int N) {
+  const int64_t n4 = M * (int64_t)(N / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / (N / 4);
+    const int c = (int)(i - r * (N / 4)) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float s = pr.scale ? pr.scale[c + j] : 1.f, sh = pr.scale ? pr.shift[c + j] : 0.f;
+      v[j] = mmg_pro_apply(pr, v[j], s, sh, r, c + j, N);
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ Y, ProDev pr,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ c0, const float* __restrict__ c1,
+                                                      float* __restrict__ dY, int64_t M, int N) {
+  const int64_t n4 = M * (int64_t)(N / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / (N / 4);
+    const int c = (int)(i - r * (N / 4)) * 4;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(G + (size_t)i * 4);
+    const f32x4 y4 = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = c + j;
+      const float sc = pr.scale ? pr.scale[k] : 1.f, sh = pr.scale ? pr.shift[k] : 0.f;
+      const float act = pr.scale ? fmaf(y4[j], sc, sh) : y4[j];
+      float g = g4[j];
+      if (pr.relu && !(act > 0.f)) g = 0.f;
+      if (pr.p > 0.f) {
+        const uint64_t e = (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)k;
+        g = mmg_keep(pr.seed, pr.site, e, pr.p) ? g * pr.inv_keep : 0.f;
+      }
+      if (pr.scale) {
+        const float xh = (y4[j] - mean[k]) * rstd[k];
+        const float a0 = c0 ? c0[k] : 0.f, a1 = c1 ? c1[k] : 0.f;
+        g = sc * (g - a0 - xh * a1);
+      }
+      o[j] = g;
+    }
+    *reinterpret_cast<f32x4*>(dY + (size_t)i * 4) = o;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_l2norm_fwd(const float* __restrict__ Z, float* __restrict__ out,
+                                                    float* __restrict__ rnorm, int64_t M, float eps) {
+  constexpr int N = VEC * 64;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (row >= M) return;
+  float v[VEC], ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { v[j] = Z[(size_t)row * N + lane * VEC + j]; ss = fmaf(v[j], v[j], ss); }
+  ss = wave_sum(ss);
+  const float nrm = sqrtf(ss);
+  const float r = 1.0f / fmaxf(nrm, eps);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) out[(size_t)row * N + lane * VEC + j] = v[j] * r;
+  if (lane == 0 && rnorm) rnorm[row] = r;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_l2norm_bwd(const float* __restrict__ G, const float* __restrict__ out,
+                                                    const float* __restrict__ rnorm, float* __restrict__ dZ, int64_t M,
+                                                    float eps) {
+  constexpr int N = VEC * 64;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (row >= M) return;
+  float g[VEC], o[VEC], dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    g[j] = G[(size_t)row * N + lane * VEC + j];
+    o[j] = out[(size_t)row * N + lane * VEC + j];
+    dot = fmaf(g[j], o[j], dot);
+  }
+  dot = wave_sum(dot);
+  const float r = rnorm[row];
+  const bool clamped = !(r * eps < 1.0f);   // ||z|| <= eps: the denominator was the constant eps
+  if (clamped) dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) dZ[(size_t)row * N + lane * VEC + j] = r * (g[j] - o[j] * dot);
+}
+
+__global__ __launch_bounds__(256) void k_dropout_mask(uint64_t seed, uint32_t site, int64_t first, int64_t n, float p,
+                                                      uint8_t* mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) mask[i] = mmg_keep(seed, site, (uint64_t)(first + i), p) ? 1 : 0;
+}
+
+inline unsigned ew_grid(int64_t n4) {
+  int64_t b = (n4 + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+template <int MODE>
+int run_col_reduce(const float* A, const float* B, const ProDev& pr, const float* mean, const float* rstd,
+                   double* out, int64_t M, int N, void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
+  ColGeom g;
+  MMG_CHECK_ARG(col_geom(M, N, &g), "%s: N=%d unsupported", what, N);
+  const size_t need = (size_t)g.nblk * 2 * N * 8 + 256;
+  if (ws_bytes < need) { mmg_set_error("%s: workspace %zu < %zu", what, ws_bytes, need); return MMG_E_WS; }
+  double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_col_reduce<MODE>, dim3(g.nblk), dim3(256), 0, st, A, B, pr, mean, rstd, partial, M, N,
+                     g.rows_per_blk);
+  hipLaunchKernelGGL(k_partial_sum, dim3((2 * N + 255) / 256), dim3(256), 0, st, partial, out, 2 * N, g.nblk);
+  return MMG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mmg_col_reduce2_ws_bytes(int64_t M, int N) {
+  ColGeom g;
+  if (M < 0 || !col_geom(M, N, &g)) return 0;
+  return (size_t)g.nblk * 2 * N * 8 + 256;
+}
+
+extern "C" int mmg_col_reduce2(const float* A, const float* B, double* out, int64_t M, int N, void* ws, size_t ws_bytes,
+                               void* stream) {
+  MMG_CHECK_ARG(M >= 0 && out, "col_reduce2: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) { hipMemsetAsync(out, 0, (size_t)2 * N * 8, st); return MMG_OK; }
+  MMG_CHECK_ARG(A && ws, "col_reduce2: null buffer");
+  int rc = run_col_reduce<0>(A, B, mmg_pro_dev(nullptr), nullptr, nullptr, out, M, N, ws, ws_bytes, st, "col_reduce2");
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("col_reduce2");
+  return MMG_OK;
+}
+
+extern "C" int mmg_bn_finalize(const double* sums, int64_t count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int training, int n_updates, float momentum,
+                               float eps, float* scale, float* shift, float* mean, float* rstd, int N, void* stream) {
+  MMG_CHECK_ARG(N > 0 && scale && shift, "bn_finalize: bad args");
+  MMG_CHECK_ARG(training ? (sums != nullptr && count > 0) : (running_mean && running_var),
+                "bn_finalize: missing statistics for the requested mode");
+  hipLaunchKernelGGL(k_bn_finalize, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, gamma, beta,
+                     running_mean, running_var, training, n_updates, momentum, eps, scale, shift, mean, rstd, N);
+  MMG_CHECK_LAUNCH("bn_finalize");
+  return MMG_OK;
+}
+
+extern "C" int mmg_affine_act_drop(const float* Y, const mmg_prologue_t* pro, float* out, int64_t M, int N, void* stream) {
+  MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0, "affine_act_drop: N=%d must be a multiple of 4", N);
+  if (M == 0) return MMG_OK;
+  MMG_CHECK_ARG(Y && out, "affine_act_drop: null buffer");
+  hipLaunchKernelGGL(k_affine_act_drop, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, Y, mmg_pro_dev(pro),
+                     out, M, N);
+  MMG_CHECK_LAUNCH("affine_act_drop");
+  return MMG_OK;
+}
+
+extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
+                                const float* rstd, double* sums, int64_t M, int N, void* ws, size_t ws_bytes,
+                                void* stream) {
+  MMG_CHECK_ARG(M >= 0 && sums && mean && rstd, "bn_bwd_stats: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) { hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st); return MMG_OK; }
+  MMG_CHECK_ARG(G && Y && ws, "bn_bwd_stats: null buffer");
+  int rc = run_col_reduce<1>(G, Y, mmg_pro_dev(pro), mean, rstd, sums, M, N, ws, ws_bytes, st, "bn_bwd_stats");
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("bn_bwd_stats");
+  return MMG_OK;
+}
+
+extern "C" int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
+                                const float* rstd, const float* c0, const float* c1, float* dY, int64_t M, int N,
+                                void* stream) {
+  MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0, "bn_bwd_apply: N=%d must be a multiple of 4", N);
+  if (M == 0) return MMG_OK;
+  MMG_CHECK_ARG(G && Y && dY, "bn_bwd_apply: null buffer");
+  MMG_CHECK_ARG(!pro || !pro->scale || (mean && rstd), "bn_bwd_apply: affine prologue needs mean/rstd");
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, G, Y, mmg_pro_dev(pro),
+                     mean, rstd, c0, c1, dY, M, N);
+  MMG_CHECK_LAUNCH("bn_bwd_apply");
+  return MMG_OK;
+}
+
+extern "C" int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, float eps, void* stream) {
+  MMG_CHECK_ARG(mmg_valid_D(N), "l2norm_fwd: N=%d unsupported (64|128|256)", N);
+  MMG_CHECK_ARG(M >= 0, "l2norm_fwd: M < 0");
+  if (M == 0) return MMG_OK;
+  MMG_CHECK_ARG(Z && out, "l2norm_fwd: null buffer");
+  const unsigned nb = (unsigned)((M + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 64) hipLaunchKernelGGL(k_l2norm_fwd<1>, dim3(nb), dim3(256), 0, st, Z, out, rnorm, M, eps);
+  else if (N == 128) hipLaunchKernelGGL(k_l2norm_fwd<2>, dim3(nb), dim3(256), 0, st, Z, out, rnorm, M, eps);
+  else hipLaunchKernelGGL(k_l2norm_fwd<4>, dim3(nb), dim3(256), 0, st, Z, out, rnorm, M, eps);
+  MMG_CHECK_LAUNCH("l2norm_fwd");
+  return MMG_OK;
+}
+
+extern "C" int mmg_l2norm_bwd(const float* G, const float* out, const float* rnorm, float* dZ, int64_t M, int N, float eps,
+                              void* stream) {
+  MMG_CHECK_ARG(mmg_valid_D(N), "l2norm_bwd: N=%d unsupported (64|128|256)", N);
+  MMG_CHECK_ARG(M >= 0, "l2norm_bwd: M < 0");
+  if (M == 0) return MMG_OK;
+  MMG_CHECK_ARG(G && out && rnorm && dZ, "l2norm_bwd: null buffer");
+  const unsigned nb = (unsigned)((M + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 64) hipLaunchKernelGGL(k_l2norm_bwd<1>, dim3(nb), dim3(256), 0, st, G, out, rnorm, dZ, M, eps);
+  else if (N == 128) hipLaunchKernelGGL(k_l2norm_bwd<2>, dim3(nb), dim3(256), 0, st, G, out, rnorm, dZ, M, eps);
+  else hipLaunchKernelGGL(k_l2norm_bwd<4>, dim3(nb), dim3(256), 0, st, G, out, rnorm, dZ, M, eps);
+  MMG_CHECK_LAUNCH("l2norm_bwd");
+  return MMG_OK;
+}
+
+extern "C" int mmg_dropout_mask(uint64_t seed, uint32_t site, int64_t first_elem, int64_t n_elems, float p, uint8_t* mask,
+                                void* stream) {
+  MMG_CHECK_ARG(n_elems >= 0 && (mask || n_elems == 0), "dropout_mask: bad args");
+  if (n_elems == 0) return MMG_OK;
+  hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, site,
+                     first_elem, n_elems, p, mask);
+  MMG_CHECK_LAUNCH("dropout_mask");
+  return MMG_OK;
+}

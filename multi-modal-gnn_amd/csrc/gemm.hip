@@ -1,0 +1,303 @@
+// Dense layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32, 256 FLOP/clk/CU).
+// Replaces nn.Linear (+ the BatchNorm/ReLU/Dropout in front of it) of src/model.py:93-105 and the
+// lin_l / lin_r of PyG SAGEConv (call site src/model.py:125-131).
+//
+// linear_fwd : Y[M,N] = prologue(X)[M,K] . W[N,K]^T + b.  The W slice [BN,K] stays resident in LDS;
+//              a workgroup (4 waves as 2(M) x 2(N)) streams 64-row X tiles through LDS.  The k axis is
+//              split between the two lane halves (lane>>5 takes k in [h*K/2,(h+1)*K/2)), so every
+//              A/B fragment read is a contiguous ds_read_b128 (4 MFMA steps per read).
+// linear_wgrad: dW[N,K] = dY^T . prologue(X): each workgroup reduces a row chunk into a [TN,TK]
+//              register tile (operands are read column-wise: consecutive lanes, consecutive floats),
+//              writes one partial slab; a second kernel sums the slabs in fixed order.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64;
+
+template <int K, int BN>
+__global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X, ProDev pr,
+                                                    const float* __restrict__ W, const float* __restrict__ bias,
+                                                    float* __restrict__ Y, int64_t M, int N, int accumulate) {
+  constexpr int LDK = K + 4;            // row stride (floats): shifts rows by one 16-B slot
+  constexpr int NT = BN / 64;           // 32x32 accumulator tiles per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                     // [BN][LDK]
+  float* Xs = smem + BN * LDK;          // [BM][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int n0 = blockIdx.x * BN;
+
+  // ---- stage the W slice once
+  constexpr int K4 = K / 4;
+  for (int i = tid; i < BN * K4; i += 256) {
+    const int r = i / K4, c4 = i - r * K4;
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + c4 * 4);
+    *reinterpret_cast<f32x4*>(Ws + r * LDK + c4 * 4) = w;
+  }
+  // per-thread prologue constants: this thread always touches the same 4 k's
+  const int kc4 = tid % K4;               // float4 column
+  constexpr int ROWS_PER_PASS = 256 / K4; // rows covered by one pass of the workgroup
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (pr.scale) {
+    sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
+    sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
+  }
+
+  const int64_t n_tiles = (M + BM - 1) / BM;
+  for (int64_t t = blockIdx.y; t < n_tiles; t += gridDim.y) {
+    const int64_t row0 = t * BM;
+    __syncthreads();   // previous tile's MFMA reads are done (and W is staged on the first trip)
+#pragma unroll
+    for (int p = 0; p < BM / ROWS_PER_PASS; ++p) {
+      const int r = p * ROWS_PER_PASS + tid / K4;
+      const int64_t gr = row0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gr < M) {
+        v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + kc4 * 4);
+        if (pr.scale || pr.relu || pr.p > 0.f) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = mmg_pro_apply(pr, v[j], sc[j], sh[j], gr, kc4 * 4 + j, K);
+        }
+      }
+      *reinterpret_cast<f32x4*>(Xs + r * LDK + kc4 * 4) = v;
+    }
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+
+    const int h = lane >> 5, l31 = lane & 31;
+    const float* ap = Xs + (wm * 32 + l31) * LDK + h * (K / 2);
+    const float* bp = Ws + (wn * (BN / 2) + l31) * LDK + h * (K / 2);
+#pragma unroll 4
+    for (int q = 0; q < K / 8; ++q) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + q * 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + nt * 32 * LDK + q * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[nt], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: C/D map col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + wn * (BN / 2) + nt * 32 + l31;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t gr = row0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (gr < M) {
+          float* dst = Y + (size_t)gr * N + col;
+          float v = acc[nt][i] + bv;
+          if (accumulate) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- wgrad
+constexpr int WG_ROWS = 32;   // rows reduced per LDS stage
+
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
+                                                      ProDev pr, float* __restrict__ slab, int64_t M, int N, int K,
+                                                      int64_t rows_per_split) {
+  // grid: x = output tile (tn-major over N/TN x K/TK), y = row split
+  constexpr int MT = TN / 64, KT = TK / 64;   // 32x32 tiles per wave along n and k
+  __shared__ __attribute__((aligned(16))) float Ys[WG_ROWS][TN];
+  __shared__ __attribute__((aligned(16))) float Xs[WG_ROWS][TK];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 1, wk = wid & 1;
+  const int tiles_k = K / TK;
+  const int tn0 = (blockIdx.x / tiles_k) * TN, tk0 = (blockIdx.x % tiles_k) * TK;
+  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r_end = min(M, r_beg + rows_per_split);
+
+  f32x16 acc[MT][KT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  const int h = lane >> 5, l31 = lane & 31;
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += WG_ROWS) {
+    __syncthreads();
+    for (int i = tid; i < WG_ROWS * (TN / 4); i += 256) {
+      const int r = i / (TN / 4), c4 = i - r * (TN / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r0 + r < r_end) v = *reinterpret_cast<const f32x4*>(dY + (size_t)(r0 + r) * N + tn0 + c4 * 4);
+      *reinterpret_cast<f32x4*>(&Ys[r][c4 * 4]) = v;
+    }
+    for (int i = tid; i < WG_ROWS * (TK / 4); i += 256) {
+      const int r = i / (TK / 4), c4 = i - r * (TK / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int64_t gr = r0 + r;
+      if (gr < r_end) {
+        const int k = tk0 + c4 * 4;
+        v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + k);
+        if (pr.scale || pr.relu || pr.p > 0.f) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float s = pr.scale ? pr.scale[k + j] : 1.f, sh = pr.scale ? pr.shift[k + j] : 0.f;
+            v[j] = mmg_pro_apply(pr, v[j], s, sh, gr, k + j, K);
+          }
+        }
+      }
+      *reinterpret_cast<f32x4*>(&Xs[r][c4 * 4]) = v;
+    }
+    __syncthreads();
+    // A[i=n][k=m] = dY[m][n],  B[k=m][j=kk] = X[m][kk];  lane half h takes m = h*16 + s
+#pragma unroll 4
+    for (int s = 0; s < WG_ROWS / 2; ++s) {
+      const int m = h * (WG_ROWS / 2) + s;
+      float a[MT], b[KT];
+#pragma unroll
+      for (int x = 0; x < MT; ++x) a[x] = Ys[m][wn * (TN / 2) + x * 32 + l31];
+#pragma unroll
+      for (int x = 0; x < KT; ++x) b[x] = Xs[m][wk * (TK / 2) + x * 32 + l31];
+#pragma unroll
+      for (int x = 0; x < MT; ++x)
+#pragma unroll
+        for (int y = 0; y < KT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
+    }
+  }
+  // slab[split][N][K]
+  float* dst = slab + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < KT; ++y)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = tn0 + wn * (TN / 2) + x * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int k = tk0 + wk * (TK / 2) + y * 32 + l31;
+        dst[(size_t)n * K + k] = acc[x][y][i];
+      }
+}
+
+__global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
+                                                     int n_split, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < n_split; ++b) s += slab[(size_t)b * n + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+struct WgradPlan { int TN, TK, n_tiles, n_split; int64_t rows_per_split; };
+WgradPlan plan_wgrad(int64_t M, int N, int K) {
+  WgradPlan p;
+  p.TN = (N % 128 == 0) ? 128 : 64;
+  p.TK = (K % 128 == 0) ? 128 : 64;
+  p.n_tiles = (N / p.TN) * (K / p.TK);
+  int64_t max_split = (M + WG_ROWS - 1) / WG_ROWS;
+  if (max_split < 1) max_split = 1;
+  int64_t want = 512 / p.n_tiles;
+  if (want < 1) want = 1;
+  p.n_split = (int)(want < max_split ? want : max_split);
+  int64_t rps = (M + p.n_split - 1) / p.n_split;
+  rps = (rps + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+  if (rps < WG_ROWS) rps = WG_ROWS;
+  p.rows_per_split = rps;
+  p.n_split = (int)((M + rps - 1) / rps);
+  if (p.n_split < 1) p.n_split = 1;
+  return p;
+}
+
+template <int K, int BN>
+int launch_fwd(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+               int accumulate, hipStream_t st) {
+  constexpr size_t lds = (size_t)(BN + BM) * (K + 4) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)k_linear_fwd<K, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int n_slices = N / BN;
+  const int64_t n_tiles = (M + BM - 1) / BM;
+  int64_t gy = (2 * 256) / n_slices;
+  if (gy < 1) gy = 1;
+  if (gy > n_tiles) gy = n_tiles;
+  hipLaunchKernelGGL((k_linear_fwd<K, BN>), dim3((unsigned)n_slices, (unsigned)gy), dim3(256), lds, st, X, pr, W, bias,
+                     Y, M, N, accumulate);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias, float* Y,
+                              int64_t M, int N, int K, int accumulate, void* stream) {
+  MMG_CHECK_ARG(M >= 0, "linear_fwd: M < 0");
+  MMG_CHECK_ARG(K == 64 || K == 128 || K == 256, "linear_fwd: K=%d unsupported (64|128|256)", K);
+  MMG_CHECK_ARG(N > 0 && N % 64 == 0 && N <= 1024, "linear_fwd: N=%d must be a multiple of 64", N);
+  if (M == 0) return MMG_OK;
+  MMG_CHECK_ARG(X && W && Y, "linear_fwd: null buffer");
+  MMG_CHECK_ARG(!pro || !pro->scale || pro->shift, "linear_fwd: prologue scale without shift");
+  hipStream_t st = (hipStream_t)stream;
+  const ProDev pr = mmg_pro_dev(pro);
+  const bool wide = (N % 128 == 0);
+  if (K == 64) {
+    if (wide) launch_fwd<64, 128>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else launch_fwd<64, 64>(X, pr, W, bias, Y, M, N, accumulate, st);
+  } else if (K == 128) {
+    if (wide) launch_fwd<128, 128>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else launch_fwd<128, 64>(X, pr, W, bias, Y, M, N, accumulate, st);
+  } else {
+    launch_fwd<256, 64>(X, pr, W, bias, Y, M, N, accumulate, st);
+  }
+  MMG_CHECK_LAUNCH("linear_fwd");
+  return MMG_OK;
+}
+
+extern "C" size_t mmg_linear_wgrad_ws_bytes(int64_t M, int N, int K) {
+  if (M < 0 || N <= 0 || K <= 0 || N % 64 || K % 64) return 0;
+  WgradPlan p = plan_wgrad(M, N, K);
+  return (size_t)p.n_split * N * K * 4 + 256;
+}
+
+extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, int64_t M,
+                                int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  MMG_CHECK_ARG(M >= 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "linear_wgrad: N=%d K=%d must be multiples of 64", N, K);
+  MMG_CHECK_ARG(dW, "linear_wgrad: dW is null");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    if (!accumulate) hipMemsetAsync(dW, 0, (size_t)N * K * 4, st);
+    return MMG_OK;
+  }
+  MMG_CHECK_ARG(dY && X && ws, "linear_wgrad: null buffer");
+  const size_t need = mmg_linear_wgrad_ws_bytes(M, N, K);
+  if (ws_bytes < need) {
+    mmg_set_error("linear_wgrad: workspace %zu < %zu", ws_bytes, need);
+    return MMG_E_WS;
+  }
+  WgradPlan p = plan_wgrad(M, N, K);
+  float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  const ProDev pr = mmg_pro_dev(pro);
+  dim3 grid((unsigned)p.n_tiles, (unsigned)p.n_split);
+  if (p.TN == 128 && p.TK == 128)
+    hipLaunchKernelGGL((k_linear_wgrad<128, 128>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
+  else if (p.TN == 128)
+    hipLaunchKernelGGL((k_linear_wgrad<128, 64>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
+  else if (p.TK == 128)
+    hipLaunchKernelGGL((k_linear_wgrad<64, 128>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
+  else
+    hipLaunchKernelGGL((k_linear_wgrad<64, 64>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
+  const int64_t n = (int64_t)N * K;
+  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, dW, n, p.n_split, accumulate);
+  MMG_CHECK_LAUNCH("linear_wgrad");
+  return MMG_OK;
+}

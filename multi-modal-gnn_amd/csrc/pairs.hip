@@ -1,0 +1,280 @@
+// Degree-gated edge regression heads (src/model.py:305-333 and EdgeRegressionHead :342-396 of the
+// reference).  The first Linear(2D,64) is applied per NODE by mmg_linear_fwd (A = x_P.W1[:, :D]^T,
+// B = x_lab.W1[:, D:]^T + b1), so the per-pair work is a 64-wide gather-add + a 64x32 and a 32x1 layer.
+//
+// One launch serves ONE head; the gate (deg[pi] < threshold) is evaluated per pair and lanes whose
+// pair belongs to the other head are predicated off.  Thread-per-pair on the vector ALUs (fp32);
+// weights are broadcast from LDS.  Backward recomputes the forward (nothing per-pair is stored) and
+// reduces   dW2 through transposed LDS tiles,   dW3/db2/db3 through wave reductions,
+//           dA[pi] by run-length pre-reduction + one 256-B atomic per run (pairs sorted by patient
+//           collapse to ~1 atomic per patient),   dB[li] in LDS accumulators.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int PT = 256;          // pairs per workgroup tile == threads
+constexpr uint32_t SITE_H1 = 64, SITE_H2 = 65;
+
+struct HeadDev { const float *A, *B, *W2, *b2, *W3, *b3; };
+struct HeadGradDev { float *dA, *dB, *dW2, *db2, *dW3, *db3; };
+
+__device__ inline void load_row64(const float* __restrict__ p, float* dst) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + q * 4);
+    dst[q * 4 + 0] = v[0]; dst[q * 4 + 1] = v[1]; dst[q * 4 + 2] = v[2]; dst[q * 4 + 3] = v[3];
+  }
+}
+
+// h1 = dropout(relu(A[pi] + B[li]))  (post-dropout values, kept in registers)
+__device__ inline void head_layer1(const HeadDev& H, int p_i, int l_i, uint64_t pid, float drop_p, float inv_keep,
+                                   uint64_t seed, float* h1) {
+  float b[64];
+  load_row64(H.A + (size_t)p_i * 64, h1);
+  load_row64(H.B + (size_t)l_i * 64, b);
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    float v = fmaxf(h1[j] + b[j], 0.f);
+    if (drop_p > 0.f) v = mmg_keep(seed, SITE_H1, pid * 64ull + j, drop_p) ? v * inv_keep : 0.f;
+    h1[j] = v;
+  }
+}
+// pre-activation of unit i of layer 2 (weights broadcast from LDS)
+__device__ inline float head_unit2(const float* W2s, const float* b2s, const float* h1, int i) {
+  float s = b2s[i];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W2s + i * 64 + q * 4);
+    s = fmaf(w[0], h1[q * 4 + 0], s); s = fmaf(w[1], h1[q * 4 + 1], s);
+    s = fmaf(w[2], h1[q * 4 + 2], s); s = fmaf(w[3], h1[q * 4 + 3], s);
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(PT) void k_pair_fwd(HeadDev H, const int32_t* __restrict__ pi, const int32_t* __restrict__ li,
+                                                 const int32_t* __restrict__ deg, int thr, int want_low, int64_t n,
+                                                 float drop_p, uint64_t seed, const int64_t* __restrict__ pair_id,
+                                                 float* __restrict__ pred) {
+  __shared__ __attribute__((aligned(16))) float W2s[32 * 64];
+  __shared__ float b2s[32], W3s[32];
+  for (int i = threadIdx.x; i < 2048; i += PT) W2s[i] = H.W2[i];
+  if (threadIdx.x < 32) { b2s[threadIdx.x] = H.b2[threadIdx.x]; W3s[threadIdx.x] = H.W3[threadIdx.x]; }
+  __syncthreads();
+  const float b3 = H.b3[0];
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (int64_t k = (int64_t)blockIdx.x * PT + threadIdx.x; k < n; k += (int64_t)gridDim.x * PT) {
+    const int p_i = pi[k];
+    const bool low = deg[p_i] < thr;
+    if ((int)low != want_low) continue;
+    const uint64_t pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
+    float h1[64];
+    head_layer1(H, p_i, li[k], pid, drop_p, inv_keep, seed, h1);
+    float o = b3;
+    // rolled on purpose: a full unroll lets the scheduler hoist all 512 LDS weight reads (spills)
+#pragma unroll 2
+    for (int i = 0; i < 32; ++i) {
+      float v = fmaxf(head_unit2(W2s, b2s, h1, i), 0.f);
+      if (drop_p > 0.f) v = mmg_keep(seed, SITE_H2, pid * 32ull + i, drop_p) ? v * inv_keep : 0.f;
+      o = fmaf(W3s[i], v, o);
+    }
+    pred[k] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------- backward
+// LDS layout (floats).  T1t/T2t are TRANSPOSED tiles [unit][pair] with row stride LDT so that
+// thread-per-pair writes are conflict-free and the dW2 pass reads 4 pairs per ds_read_b128.
+constexpr int LDT = PT + 4;
+constexpr int LD4 = 65;                          // pair-major dh1 tile stride (aliases T1t)
+constexpr int OFF_W2 = 0;                        // [32][64]
+constexpr int OFF_B2 = OFF_W2 + 2048;            // [32]
+constexpr int OFF_W3 = OFF_B2 + 32;              // [32]
+constexpr int OFF_T1 = OFF_W3 + 32;              // T1t [64][LDT]  (>= PT*LD4 floats)
+constexpr int OFF_T2 = OFF_T1 + 64 * LDT;        // T2t [32][LDT]
+constexpr int OFF_PI = OFF_T2 + 32 * LDT;        // int [PT] patient id or -1
+constexpr int OFF_LI = OFF_PI + PT;              // int [PT]
+constexpr int OFF_RED = OFF_LI + PT;             // [4][68]: per-wave dW3[32] | db2[32] | db3
+constexpr int OFF_DB = OFF_RED + 4 * 68;         // dB accumulators [n_labs][64] (when they fit)
+static_assert(64 * LDT >= PT * LD4, "dh1 tile must fit in the T1t region");
+constexpr size_t BWD_LDS_FIXED = (size_t)OFF_DB * 4;
+constexpr size_t BWD_LDS_MAX = 160 * 1024;
+
+__global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
+                                                 const int32_t* __restrict__ li, const int32_t* __restrict__ deg, int thr,
+                                                 int want_low, int64_t n, int n_labs, int lds_db, float drop_p,
+                                                 uint64_t seed, const int64_t* __restrict__ pair_id,
+                                                 const float* __restrict__ dpred) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* W2s = sm + OFF_W2; float* b2s = sm + OFF_B2; float* W3s = sm + OFF_W3;
+  float* T1t = sm + OFF_T1; float* T2t = sm + OFF_T2;
+  int* PIs = reinterpret_cast<int*>(sm + OFF_PI); int* LIs = reinterpret_cast<int*>(sm + OFF_LI);
+  float* RED = sm + OFF_RED; float* DBs = sm + OFF_DB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < 2048; i += PT) W2s[i] = H.W2[i];
+  if (tid < 32) { b2s[tid] = H.b2[tid]; W3s[tid] = H.W3[tid]; }
+  for (int i = tid; i < 4 * 68; i += PT) RED[i] = 0.f;
+  if (lds_db) for (int i = tid; i < n_labs * 64; i += PT) DBs[i] = 0.f;
+  __syncthreads();
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+
+  const int i0 = tid >> 3, j0 = (tid & 7) * 8;     // this thread owns dW2[i0][j0..j0+7]
+  float w2acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  const int64_t n_tiles = (n + PT - 1) / PT;
+  for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int64_t k = t * PT + tid;
+    int p_i = -1, l_i = 0;
+    if (k < n) {
+      const int pp = pi[k];
+      if (((int)(deg[pp] < thr)) == want_low) { p_i = pp; l_i = li[k]; }
+    }
+    const bool active = p_i >= 0;
+    // inactive lanes run the same code on row 0 with dout = 0: every contribution is then zero
+    const uint64_t pid = active ? (pair_id ? (uint64_t)pair_id[k] : (uint64_t)k) : 0ull;
+    const float dout = active ? dpred[k] : 0.f;
+    float h1[64], dh1[64];
+    head_layer1(H, active ? p_i : 0, l_i, pid, drop_p, inv_keep, seed, h1);
+#pragma unroll
+    for (int j = 0; j < 64; ++j) { T1t[j * LDT + tid] = h1[j]; dh1[j] = 0.f; }
+    PIs[tid] = p_i; LIs[tid] = l_i;
+#pragma unroll 2
+    for (int i = 0; i < 32; ++i) {
+      const float pre = head_unit2(W2s, b2s, h1, i);
+      float m = (pre > 0.f) ? 1.f : 0.f;
+      float post = fmaxf(pre, 0.f);
+      if (drop_p > 0.f) {
+        const bool kp = mmg_keep(seed, SITE_H2, pid * 32ull + i, drop_p);
+        m = kp ? m * inv_keep : 0.f;
+        post = kp ? post * inv_keep : 0.f;
+      }
+      const float d2 = dout * W3s[i] * m;        // grad wrt the layer-2 pre-activation
+      T2t[i * LDT + tid] = d2;
+      const float c3 = wave_sum(dout * post);    // dW3[i]
+      const float c2 = wave_sum(d2);             // db2[i]
+      if (lane == 0) { RED[wid * 68 + i] += c3; RED[wid * 68 + 32 + i] += c2; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(W2s + i * 64 + q * 4);
+        dh1[q * 4 + 0] = fmaf(w[0], d2, dh1[q * 4 + 0]); dh1[q * 4 + 1] = fmaf(w[1], d2, dh1[q * 4 + 1]);
+        dh1[q * 4 + 2] = fmaf(w[2], d2, dh1[q * 4 + 2]); dh1[q * 4 + 3] = fmaf(w[3], d2, dh1[q * 4 + 3]);
+      }
+    }
+    {
+      const float c = wave_sum(dout);
+      if (lane == 0) RED[wid * 68 + 64] += c;
+    }
+    // through dropout+relu of layer 1: h1 > 0  <=>  unit kept and positive
+#pragma unroll
+    for (int j = 0; j < 64; ++j) dh1[j] = (h1[j] > 0.f) ? dh1[j] * inv_keep : 0.f;
+    __syncthreads();
+    // ---- dW2[i0][j0..j0+7] += sum_p d2[p][i0] * h1[p][j0..]
+#pragma unroll 2
+    for (int p = 0; p < PT; p += 4) {
+      const f32x4 d = *reinterpret_cast<const f32x4*>(T2t + i0 * LDT + p);
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(T1t + (j0 + jj) * LDT + p);
+        w2acc[jj] = fmaf(d[0], hv[0], w2acc[jj]); w2acc[jj] = fmaf(d[1], hv[1], w2acc[jj]);
+        w2acc[jj] = fmaf(d[2], hv[2], w2acc[jj]); w2acc[jj] = fmaf(d[3], hv[3], w2acc[jj]);
+      }
+    }
+    __syncthreads();
+    // ---- dh1 tile, pair-major (aliases T1t)
+    float* T4 = T1t;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) T4[tid * LD4 + j] = dh1[j];
+    __syncthreads();
+    // wave w flushes pairs [64w, 64w+64): lane j owns unit j; equal consecutive patients are pre-summed
+    {
+      float run = 0.f;
+      int cur = -1;
+      for (int q = 0; q < 64; ++q) {
+        const int p = wid * 64 + q;
+        const int pp = PIs[p];
+        if (pp < 0) continue;
+        const float v = T4[p * LD4 + lane];
+        if (pp != cur) {
+          if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
+          cur = pp; run = 0.f;
+        }
+        run += v;
+        const int ll = LIs[p];
+        if (lds_db) atomicAdd(DBs + ll * 64 + lane, v);
+        else atomicAdd(Gd.dB + (size_t)ll * 64 + lane, v);
+      }
+      if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
+    }
+    __syncthreads();
+  }
+  // ---- final flush of the workgroup accumulators
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) atomicAdd(Gd.dW2 + i0 * 64 + j0 + jj, w2acc[jj]);
+  __syncthreads();
+  if (tid < 65) {
+    const float s = RED[tid] + RED[68 + tid] + RED[2 * 68 + tid] + RED[3 * 68 + tid];
+    if (tid < 32) atomicAdd(Gd.dW3 + tid, s);
+    else if (tid < 64) atomicAdd(Gd.db2 + (tid - 32), s);
+    else atomicAdd(Gd.db3, s);
+  }
+  if (lds_db) for (int i = tid; i < n_labs * 64; i += PT) atomicAdd(Gd.dB + i, DBs[i]);
+}
+
+inline unsigned pair_grid(int64_t n) {
+  int64_t t = (n + PT - 1) / PT;
+  if (t > 1024) t = 1024;
+  if (t < 1) t = 1;
+  return (unsigned)t;
+}
+
+int check_head(const mmg_head_t* h, const char* what) {
+  MMG_CHECK_ARG(h && h->A && h->B && h->W2 && h->b2 && h->W3 && h->b3, "%s: head has a null pointer", what);
+  return MMG_OK;
+}
+
+}  // namespace
+
+extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
+                                 int degree_threshold, int want_low, int64_t n_pairs, float drop_p, uint64_t seed,
+                                 const int64_t* pair_id, float* pred, void* stream) {
+  MMG_CHECK_ARG(n_pairs >= 0, "pair_head_fwd: n_pairs < 0");
+  if (n_pairs == 0) return MMG_OK;
+  int rc = check_head(head, "pair_head_fwd");
+  if (rc) return rc;
+  MMG_CHECK_ARG(pi && li && deg && pred, "pair_head_fwd: null buffer");
+  MMG_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pair_head_fwd: drop_p out of range");
+  HeadDev H{head->A, head->B, head->W2, head->b2, head->W3, head->b3};
+  hipLaunchKernelGGL(k_pair_fwd, dim3(pair_grid(n_pairs)), dim3(PT), 0, (hipStream_t)stream, H, pi, li, deg,
+                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, pair_id, pred);
+  MMG_CHECK_LAUNCH("pair_head_fwd");
+  return MMG_OK;
+}
+
+extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi, const int32_t* li,
+                                 const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
+                                 float drop_p, uint64_t seed, const int64_t* pair_id, const float* dpred, void* stream) {
+  MMG_CHECK_ARG(n_pairs >= 0 && n_labs >= 0, "pair_head_bwd: negative size");
+  if (n_pairs == 0) return MMG_OK;
+  int rc = check_head(head, "pair_head_bwd");
+  if (rc) return rc;
+  MMG_CHECK_ARG(grad && grad->dA && grad->dB && grad->dW2 && grad->db2 && grad->dW3 && grad->db3,
+                "pair_head_bwd: grad has a null pointer");
+  MMG_CHECK_ARG(pi && li && deg && dpred, "pair_head_bwd: null buffer");
+  MMG_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pair_head_bwd: drop_p out of range");
+  HeadDev H{head->A, head->B, head->W2, head->b2, head->W3, head->b3};
+  HeadGradDev G{grad->dA, grad->dB, grad->dW2, grad->db2, grad->dW3, grad->db3};
+  size_t lds = BWD_LDS_FIXED;
+  int lds_db = 0;
+  if (lds + (size_t)n_labs * 64 * 4 <= BWD_LDS_MAX) { lds += (size_t)n_labs * 64 * 4; lds_db = 1; }
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipFuncSetAttribute((const void*)k_pair_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_MAX);
+    attr = BWD_LDS_MAX;
+  }
+  int64_t g = (n_pairs + PT - 1) / PT;
+  if (g > 512) g = 512;
+  hipLaunchKernelGGL(k_pair_bwd, dim3((unsigned)g), dim3(PT), lds, (hipStream_t)stream, H, G, pi, li, deg,
+                     degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, pair_id, dpred);
+  MMG_CHECK_LAUNCH("pair_head_bwd");
+  return MMG_OK;
+}

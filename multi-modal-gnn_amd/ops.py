@@ -1,0 +1,323 @@
+"""Typed Python entry points over the C ABI (include/mmgnn.h): one function per exported op.
+
+PyTorch is plumbing here -- it owns device memory and the stream; every computation below is a
+hand-written HIP kernel in libmmgnn.so.  All tensors must live on a HIP device, be contiguous and
+fp32 (indices int32 unless stated); violations raise instead of silently copying.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import HeadGradT, HeadT, PrologueT, RelT, check
+
+BN_MOMENTUM = 0.1
+BN_EPS = 1e-5
+L2_EPS = 1e-12
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor], dtype=torch.float32, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.MmgError(f"{name}: expected a HIP device tensor, got {t.device} (no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Growable per-device scratch (stream-ordered reuse: every op runs on the current stream)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+@dataclass
+class Pro:
+    """Prologue dropout(relu(x*scale+shift)) applied on load (mmg_prologue_t)."""
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    relu: bool = False
+    p: float = 0.0
+    seed: int = 0
+    site: int = 0
+    row_offset: int = 0
+
+    def c(self):
+        return PrologueT(_p(self.scale, name="pro.scale"), _p(self.shift, name="pro.shift"), int(self.relu),
+                         float(self.p), int(self.seed) & 0xFFFFFFFFFFFFFFFF, int(self.site), int(self.row_offset))
+
+
+def _pro(pro: Optional[Pro]):
+    return C.byref(pro.c()) if pro is not None else None
+
+
+# ------------------------------------------------------------------------------------------ CSR
+def csr_build(edge_index: torch.Tensor, n_rows: int, sort_row: int):
+    """-> (rowptr int32 [n_rows+1], col int32 [E], perm int32 [E]); see mmg_csr_build."""
+    lib = _lib.load()
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be [2,E], got {tuple(edge_index.shape)}")
+    E = int(edge_index.shape[1])
+    dev = edge_index.device
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(E, dtype=torch.int32, device=dev)
+    perm = torch.empty(E, dtype=torch.int32, device=dev)
+    nb = lib.mmg_csr_build_ws_bytes(E, n_rows)
+    ws = workspace(nb, dev)
+    check(lib.mmg_csr_build(_p(edge_index, torch.int64, "edge_index"), E, n_rows, sort_row, _p(rowptr, torch.int32),
+                            _p(col, torch.int32), _p(perm, torch.int32), _p(ws, torch.uint8), ws.numel(), _stream()),
+          "mmg_csr_build")
+    return rowptr, col, perm
+
+
+def row_degree(rowptr: torch.Tensor):
+    lib = _lib.load()
+    n = rowptr.numel() - 1
+    deg = torch.empty(n, dtype=torch.int32, device=rowptr.device)
+    inv = torch.empty(n, dtype=torch.float32, device=rowptr.device)
+    check(lib.mmg_row_degree(_p(rowptr, torch.int32), n, _p(deg, torch.int32), _p(inv), _stream()), "mmg_row_degree")
+    return deg, inv
+
+
+def col_degree(col: torch.Tensor, n_cols: int):
+    lib = _lib.load()
+    cnt = torch.empty(n_cols, dtype=torch.int32, device=col.device)
+    inv = torch.empty(n_cols, dtype=torch.float32, device=col.device)
+    check(lib.mmg_col_degree(_p(col, torch.int32), col.numel(), n_cols, _p(cnt, torch.int32), _p(inv), _stream()),
+          "mmg_col_degree")
+    return cnt, inv
+
+
+# ------------------------------------------------------------------------------------- aggregates
+@dataclass
+class Rel:
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    n_cols: int
+    rowscale: Optional[torch.Tensor] = None
+    colscale: Optional[torch.Tensor] = None
+    table: Optional[torch.Tensor] = None
+    out: Optional[torch.Tensor] = None
+
+
+def _rels(rels: Sequence[Rel], D: int, need_table=False, need_out=False):
+    if not 1 <= len(rels) <= _lib.MMG_MAX_REL:
+        raise ValueError(f"1..{_lib.MMG_MAX_REL} relations per launch")
+    arr = (RelT * len(rels))()
+    for i, r in enumerate(rels):
+        if need_table and (r.table is None or tuple(r.table.shape) != (r.n_cols, D)):
+            raise ValueError(f"relation {i}: table must be [{r.n_cols},{D}]")
+        if need_out and (r.out is None or tuple(r.out.shape) != (r.n_cols, D)):
+            raise ValueError(f"relation {i}: out must be [{r.n_cols},{D}]")
+        arr[i] = RelT(_p(r.rowptr, torch.int32), _p(r.col, torch.int32), _p(r.rowscale), _p(r.colscale),
+                      _p(r.table), _p(r.out), r.n_cols)
+    return arr
+
+
+def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, accumulate: bool):
+    lib = _lib.load()
+    if tuple(out.shape) != (n_rows, D):
+        raise ValueError("gather_rows: out shape")
+    for r in rels:
+        if r.rowptr.numel() != n_rows + 1:
+            raise ValueError("gather_rows: rowptr length")
+    arr = _rels(rels, D, need_table=True)
+    check(lib.mmg_gather_rows(arr, len(rels), n_rows, D, _p(out), int(accumulate), _stream()), "mmg_gather_rows")
+    return out
+
+
+def scatter_rows(rels: Sequence[Rel], n_rows: int, D: int, x: torch.Tensor):
+    """Writes every rel.out ([n_cols, D])."""
+    lib = _lib.load()
+    if tuple(x.shape) != (n_rows, D):
+        raise ValueError("scatter_rows: x shape")
+    for r in rels:
+        if r.rowptr.numel() != n_rows + 1:
+            raise ValueError("scatter_rows: rowptr length")
+    arr = _rels(rels, D, need_out=True)
+    nb = lib.mmg_scatter_rows_ws_bytes(arr, len(rels), n_rows, D)
+    ws = workspace(nb, x.device)
+    check(lib.mmg_scatter_rows(arr, len(rels), n_rows, D, _p(x), _p(ws, torch.uint8), ws.numel(), _stream()),
+          "mmg_scatter_rows")
+
+
+# ------------------------------------------------------------------------------------------ dense
+def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, pro: Optional[Pro] = None,
+               out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """out[M,N] (+)= pro(x)[M,K] @ W[N,K]^T + bias."""
+    lib = _lib.load()
+    M, K = x.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise ValueError(f"linear_fwd: W {tuple(W.shape)} vs x {tuple(x.shape)}")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs out")
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (M, N):
+        raise ValueError("linear_fwd: out shape")
+    check(lib.mmg_linear_fwd(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"), _p(out, name="out"),
+                             M, N, K, int(accumulate), _stream()), "mmg_linear_fwd")
+    return out
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, out: Optional[torch.Tensor] = None,
+                 accumulate: bool = False):
+    """out[N,K] (+)= dy[M,N]^T @ pro(x)[M,K]."""
+    lib = _lib.load()
+    M, N = dy.shape
+    K = x.shape[1]
+    if x.shape[0] != M:
+        raise ValueError("linear_wgrad: row mismatch")
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        accumulate = False
+    nb = lib.mmg_linear_wgrad_ws_bytes(M, N, K)
+    ws = workspace(nb, x.device)
+    check(lib.mmg_linear_wgrad(_p(dy), _p(x), _pro(pro), _p(out), M, N, K, int(accumulate), _p(ws, torch.uint8),
+                               ws.numel(), _stream()), "mmg_linear_wgrad")
+    return out
+
+
+def col_reduce2(a: torch.Tensor, b: Optional[torch.Tensor] = None):
+    """-> fp64 [2,N]: (sum_m a, sum_m a*b) with b = a when omitted."""
+    lib = _lib.load()
+    M, N = a.shape
+    out = torch.empty(2, N, dtype=torch.float64, device=a.device)
+    nb = lib.mmg_col_reduce2_ws_bytes(M, N)
+    ws = workspace(nb, a.device)
+    check(lib.mmg_col_reduce2(_p(a), _p(b), _p(out, torch.float64), M, N, _p(ws, torch.uint8), ws.numel(), _stream()),
+          "mmg_col_reduce2")
+    return out
+
+
+@dataclass
+class BNFold:
+    scale: torch.Tensor
+    shift: torch.Tensor
+    mean: torch.Tensor
+    rstd: torch.Tensor
+    count: int
+    training: bool
+
+
+def bn_finalize(sums: Optional[torch.Tensor], count: int, gamma, beta, running_mean, running_var, training: bool,
+                n_updates: int = 1) -> BNFold:
+    lib = _lib.load()
+    N = gamma.numel()
+    dev = gamma.device
+    st = torch.empty(4, N, dtype=torch.float32, device=dev)
+    check(lib.mmg_bn_finalize(_p(sums, torch.float64), count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                              int(training), n_updates, BN_MOMENTUM, BN_EPS, _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
+                              N, _stream()), "mmg_bn_finalize")
+    return BNFold(st[0], st[1], st[2], st[3], count, training)
+
+
+def affine_act_drop(y: torch.Tensor, pro: Pro, out: Optional[torch.Tensor] = None):
+    lib = _lib.load()
+    M, N = y.shape
+    out = torch.empty_like(y) if out is None else out
+    check(lib.mmg_affine_act_drop(_p(y), _pro(pro), _p(out), M, N, _stream()), "mmg_affine_act_drop")
+    return out
+
+
+def bn_bwd_stats(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold):
+    lib = _lib.load()
+    M, N = y.shape
+    out = torch.empty(2, N, dtype=torch.float64, device=y.device)
+    nb = lib.mmg_col_reduce2_ws_bytes(M, N)
+    ws = workspace(nb, y.device)
+    check(lib.mmg_bn_bwd_stats(_p(g), _p(y), _pro(pro), _p(fold.mean), _p(fold.rstd), _p(out, torch.float64), M, N,
+                               _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_bn_bwd_stats")
+    return out
+
+
+def bn_bwd_apply(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFold], c0, c1,
+                 out: Optional[torch.Tensor] = None):
+    lib = _lib.load()
+    M, N = y.shape
+    out = torch.empty_like(y) if out is None else out
+    check(lib.mmg_bn_bwd_apply(_p(g), _p(y), _pro(pro), _p(fold.mean) if fold else None,
+                               _p(fold.rstd) if fold else None, _p(c0), _p(c1), _p(out), M, N, _stream()),
+          "mmg_bn_bwd_apply")
+    return out
+
+
+def l2norm_fwd(z: torch.Tensor):
+    lib = _lib.load()
+    M, N = z.shape
+    out = torch.empty_like(z)
+    rn = torch.empty(M, dtype=torch.float32, device=z.device)
+    check(lib.mmg_l2norm_fwd(_p(z), _p(out), _p(rn), M, N, L2_EPS, _stream()), "mmg_l2norm_fwd")
+    return out, rn
+
+
+def l2norm_bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor):
+    lib = _lib.load()
+    M, N = out.shape
+    dz = torch.empty_like(out)
+    check(lib.mmg_l2norm_bwd(_p(g), _p(out), _p(rn), _p(dz), M, N, L2_EPS, _stream()), "mmg_l2norm_bwd")
+    return dz
+
+
+def dropout_mask(seed: int, site: int, n_rows: int, width: int, p: float, device, row_offset: int = 0):
+    """The keep-mask ([n_rows, width] uint8) the kernels draw for (seed, site) -- used to inject the
+    same masks into the CPU oracle in parity tests."""
+    lib = _lib.load()
+    m = torch.empty(n_rows, width, dtype=torch.uint8, device=device)
+    check(lib.mmg_dropout_mask(seed & 0xFFFFFFFFFFFFFFFF, site, row_offset * width, n_rows * width, float(p),
+                               _p(m, torch.uint8), _stream()), "mmg_dropout_mask")
+    return m
+
+
+# ------------------------------------------------------------------------------------------ heads
+@dataclass
+class Head:
+    A: torch.Tensor     # [P,64]
+    B: torch.Tensor     # [L,64]
+    W2: torch.Tensor    # [32,64]
+    b2: torch.Tensor    # [32]
+    W3: torch.Tensor    # [32] (mlp.6.weight flattened)
+    b3: torch.Tensor    # [1]
+
+    def c(self):
+        return HeadT(_p(self.A), _p(self.B), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3))
+
+
+def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred):
+    lib = _lib.load()
+    n = pi.numel()
+    h = head.c()
+    check(lib.mmg_pair_head_fwd(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
+                                int(want_low), n, float(p), seed & 0xFFFFFFFFFFFFFFFF, _p(pair_id, torch.int64),
+                                _p(pred), _stream()), "mmg_pair_head_fwd")
+
+
+def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool, n_labs: int, p: float, seed: int,
+                  pair_id, dpred):
+    """`grads` mirrors `head` (dA,dB,dW2,db2,dW3,db3), accumulated in place."""
+    lib = _lib.load()
+    n = pi.numel()
+    h = head.c()
+    g = HeadGradT(_p(grads.A), _p(grads.B), _p(grads.W2), _p(grads.b2), _p(grads.W3), _p(grads.b3))
+    check(lib.mmg_pair_head_bwd(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32),
+                                thr, int(want_low), n, n_labs, float(p), seed & 0xFFFFFFFFFFFFFFFF,
+                                _p(pair_id, torch.int64), _p(dpred), _stream()), "mmg_pair_head_bwd")

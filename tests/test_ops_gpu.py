@@ -1,0 +1,309 @@
+"""Per-kernel parity: every C-ABI entry point vs a CPU restatement on the same seeded inputs.
+
+Bars: integer/index work bit-exact; fp32 within 1e-5 relative of an fp64 CPU computation unless a
+test states otherwise (the step-level bar of BASELINE.json is 1e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import graph as og
+from oracle.pyg_min import scatter_mean
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mmgnn  # noqa: F401
+    from mmgnn import ops as o
+    return o
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rand_edges(gen, n_rows, n_cols, E):
+    r = torch.randint(0, n_rows, (E,), generator=gen)
+    c = torch.randint(0, n_cols, (E,), generator=gen)
+    return torch.stack([r, c]).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ CSR
+@pytest.mark.parametrize("n_rows,n_cols,E,sort_row", [
+    (1, 1, 0, 0), (7, 5, 1, 0), (300, 12, 5000, 0), (300, 12, 5000, 1), (1834, 50, 61484, 0),
+    (70000, 50, 300000, 0), (50, 70000, 300000, 1), (3, 3, 4097, 0),
+])
+def test_csr_build_bit_exact(ops, dev, n_rows, n_cols, E, sort_row):
+    gen = torch.Generator().manual_seed(E + n_rows)
+    ei = rand_edges(gen, n_rows, n_cols, E)
+    if sort_row == 1:
+        ei = ei.flip(0).contiguous()
+        n_sort = n_rows
+    else:
+        n_sort = n_rows
+    rp, col, perm = ops.csr_build(ei.to(dev), n_sort, sort_row)
+    rrp, rcol, rperm = og.csr_reference(ei, n_sort, sort_row)
+    assert torch.equal(rp.cpu(), rrp)
+    assert torch.equal(perm.cpu(), rperm)
+    assert torch.equal(col.cpu(), rcol)
+    deg, inv = ops.row_degree(rp)
+    d = (rrp[1:] - rrp[:-1])
+    assert torch.equal(deg.cpu(), d)
+    assert torch.equal(inv.cpu(), 1.0 / d.clamp(min=1).float())
+    if E:
+        nc = int(rcol.max()) + 1
+        cnt, cinv = ops.col_degree(col, nc)
+        assert torch.equal(cnt.cpu().long(), torch.bincount(rcol.long(), minlength=nc))
+
+
+def test_csr_build_large_keys_three_passes(ops, dev):
+    # > 2^16 rows forces three 8-bit radix passes (odd pass count lands in perm directly)
+    gen = torch.Generator().manual_seed(1)
+    ei = rand_edges(gen, 200000, 50, 1 << 20)
+    rp, col, perm = ops.csr_build(ei.to(dev), 200000, 0)
+    rrp, rcol, rperm = og.csr_reference(ei, 200000, 0)
+    assert torch.equal(rp.cpu(), rrp) and torch.equal(perm.cpu(), rperm) and torch.equal(col.cpu(), rcol)
+
+
+# ------------------------------------------------------------------------------------- aggregates
+def _csr(ops, dev, ei, n_rows):
+    rp, col, perm = ops.csr_build(ei.to(dev), n_rows, 0)
+    return rp, col
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("n_rows", [1, 257, 1834])
+def test_gather_rows_is_scatter_mean(ops, dev, D, n_rows):
+    gen = torch.Generator().manual_seed(D + n_rows)
+    sizes = [50, 114, 100]
+    rels, ref = [], torch.zeros(n_rows, D, dtype=torch.float64)
+    for k, nc in enumerate(sizes):
+        E = n_rows * (3 + 10 * k)
+        ei = rand_edges(gen, n_rows, nc, E)
+        ei[0, : E // 10] = 0 if n_rows == 1 else ei[0, : E // 10] % max(n_rows // 2, 1)   # leave empty rows
+        tab = torch.randn(nc, D, generator=gen)
+        rp, col = _csr(ops, dev, ei, n_rows)
+        _, inv = ops.row_degree(rp)
+        rels.append(ops.Rel(rp, col, nc, rowscale=inv, table=tab.to(dev)))
+        ref += scatter_mean(tab.double(), ei.flip(0), n_rows)   # src = vocab (row 1), dst = patient (row 0)
+    out = torch.full((n_rows, D), 7.0, device=dev)
+    ops.gather_rows(rels, n_rows, D, out, accumulate=False)
+    assert rel(out, ref) <= 1e-5
+    base = torch.randn(n_rows, D, generator=gen)
+    out2 = base.to(dev).clone()
+    ops.gather_rows(rels, n_rows, D, out2, accumulate=True)
+    assert rel(out2, ref + base.double()) <= 1e-5
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("n_rows", [1, 300, 5000])
+def test_scatter_rows_is_scatter_mean(ops, dev, D, n_rows):
+    gen = torch.Generator().manual_seed(3 * D + n_rows)
+    sizes = [50, 114, 100]
+    x = torch.randn(n_rows, D, generator=gen)
+    rels, refs = [], []
+    for k, nc in enumerate(sizes):
+        E = n_rows * (5 + 12 * k)
+        ei = rand_edges(gen, n_rows, nc, E)
+        ei[1] = ei[1] % max(nc - 3, 1)          # some vocab rows get no edge -> 0
+        rp, col = _csr(ops, dev, ei, n_rows)
+        cnt, cinv = ops.col_degree(col, nc)
+        out = torch.full((nc, D), -3.0, device=dev)
+        rels.append(ops.Rel(rp, col, nc, colscale=cinv, out=out))
+        refs.append(scatter_mean(x.double(), ei, nc))
+    ops.scatter_rows(rels, n_rows, D, x.to(dev))
+    for r, ref in zip(rels, refs):
+        assert rel(r.out, ref) <= 1e-5
+
+
+def test_scatter_rows_rowscale_and_global_atomic_fallback(ops, dev):
+    # n_cols too large for the LDS accumulators -> global-atomic path
+    gen = torch.Generator().manual_seed(5)
+    n_rows, nc, D = 2000, 3000, 128
+    ei = rand_edges(gen, n_rows, nc, 20000)
+    x = torch.randn(n_rows, D, generator=gen)
+    rs = torch.rand(n_rows, generator=gen) + 0.5
+    rp, col = _csr(ops, dev, ei, n_rows)
+    out = torch.empty(nc, D, device=dev)
+    ops.scatter_rows([ops.Rel(rp, col, nc, rowscale=rs.to(dev), out=out)], n_rows, D, x.to(dev))
+    ref = torch.zeros(nc, D, dtype=torch.float64).index_add_(0, ei[1], (x * rs[:, None]).double()[ei[0]])
+    assert rel(out, ref) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------ dense
+@pytest.mark.parametrize("M,N,K", [(1, 64, 64), (50, 128, 128), (1834, 128, 128), (1834, 64, 128), (1000, 128, 64),
+                                   (777, 256, 256), (333, 64, 256), (114, 128, 128), (5000, 256, 128)])
+def test_linear_fwd(ops, dev, M, N, K):
+    gen = torch.Generator().manual_seed(M + N + K)
+    x, W, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5, torch.randn(N, generator=gen)
+    y = ops.linear_fwd(x.to(dev), W.to(dev), b.to(dev))
+    ref = x.double() @ W.double().t() + b.double()
+    assert rel(y, ref) <= 1e-5
+    y2 = ops.linear_fwd(x.to(dev), W.to(dev), None, out=y.clone(), accumulate=True)
+    assert rel(y2, 2 * ref - b.double()) <= 1e-5
+
+
+def _host_pro(ops, dev, x, scale, shift, relu, p, seed, site, row_offset=0):
+    v = x.double() * scale.double() + shift.double()
+    if relu:
+        v = v.clamp(min=0)
+    if p > 0:
+        m = ops.dropout_mask(seed, site, x.shape[0], x.shape[1], p, dev, row_offset).cpu().double()
+        v = v * m / (1 - p)
+    return v
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_linear_fwd_prologue_and_wgrad(ops, dev, p):
+    gen = torch.Generator().manual_seed(11)
+    M, N, K = 1500, 128, 128
+    x, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5
+    sc, sh = torch.rand(K, generator=gen) + 0.5, torch.randn(K, generator=gen) * 0.3
+    pro = ops.Pro(sc.to(dev), sh.to(dev), True, p, seed=99, site=3, row_offset=40)
+    xp = _host_pro(ops, dev, x, sc, sh, True, p, 99, 3, 40)
+    if p > 0:
+        keep = float((xp != 0).double().mean() / (x.double() * sc.double() + sh.double() > 0).double().mean())
+        assert abs(keep - (1 - p)) < 0.02
+    y = ops.linear_fwd(x.to(dev), W.to(dev), None, pro=pro)
+    assert rel(y, xp @ W.double().t()) <= 1e-5
+    mat = ops.affine_act_drop(x.to(dev), pro)
+    assert rel(mat, xp) <= 1e-6
+    dy = torch.randn(M, N, generator=gen)
+    dW = ops.linear_wgrad(dy.to(dev), x.to(dev), pro)
+    assert rel(dW, dy.double().t() @ xp) <= 1e-5
+    dW2 = ops.linear_wgrad(dy.to(dev), x.to(dev), pro, out=dW.clone(), accumulate=True)
+    assert rel(dW2, 2 * (dy.double().t() @ xp)) <= 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(50, 64, 128), (1834, 128, 128), (9000, 256, 256), (3, 128, 64), (264, 128, 128)])
+def test_linear_wgrad_shapes(ops, dev, M, N, K):
+    gen = torch.Generator().manual_seed(M)
+    dy, x = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+    dW = ops.linear_wgrad(dy.to(dev), x.to(dev))
+    assert rel(dW, dy.double().t() @ x.double()) <= 1e-5
+
+
+@pytest.mark.parametrize("M,N", [(1, 128), (50, 128), (1834, 64), (100000, 128), (777, 256)])
+def test_col_reduce_and_bn_finalize(ops, dev, M, N):
+    gen = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, N, generator=gen) * 2 + 0.7
+    b = torch.randn(M, N, generator=gen)
+    s = ops.col_reduce2(a.to(dev), b.to(dev)).cpu()
+    assert rel(s[0], a.double().sum(0)) <= 1e-12 and rel(s[1], (a.double() * b.double()).sum(0)) <= 1e-12
+    s2 = ops.col_reduce2(a.to(dev)).cpu()
+    assert rel(s2[1], (a.double() ** 2).sum(0)) <= 1e-12
+    if M > 1:
+        bn = torch.nn.BatchNorm1d(N)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5, generator=gen); bn.bias.uniform_(-0.3, 0.3, generator=gen)
+            bn.running_mean.uniform_(-0.2, 0.2, generator=gen); bn.running_var.uniform_(0.5, 1.5, generator=gen)
+        rm, rv = bn.running_mean.clone().to(dev), bn.running_var.clone().to(dev)
+        fold = ops.bn_finalize(ops.col_reduce2(a.to(dev)), M, bn.weight.detach().to(dev), bn.bias.detach().to(dev),
+                               rm, rv, True, 2)
+        y = ops.affine_act_drop(a.to(dev), ops.Pro(fold.scale, fold.shift, False))
+        bn.train()
+        ref = bn(a); bn(a)           # two updates (F7)
+        assert rel(y, ref.detach()) <= 2e-5
+        assert rel(rm, bn.running_mean) <= 1e-5 and rel(rv, bn.running_var) <= 1e-5
+        bn.eval()
+        fold_e = ops.bn_finalize(None, M, bn.weight.detach().to(dev), bn.bias.detach().to(dev), rm, rv, False)
+        ye = ops.affine_act_drop(a.to(dev), ops.Pro(fold_e.scale, fold_e.shift, False))
+        assert rel(ye, bn(a).detach()) <= 2e-5
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_bn_relu_dropout_backward(ops, dev, p):
+    gen = torch.Generator().manual_seed(21)
+    M, N = 3000, 128
+    y = (torch.randn(M, N, generator=gen) * 1.5 + 0.2)
+    g = torch.randn(M, N, generator=gen)
+    gamma, beta = torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen) * 0.2
+    fold = ops.bn_finalize(ops.col_reduce2(y.to(dev)), M, gamma.to(dev), beta.to(dev), None, None, True)
+    pro = ops.Pro(fold.scale, fold.shift, True, p, seed=5, site=17)
+    # reference in fp64 autograd with the device's own dropout mask injected
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    xh = (yd - yd.mean(0)) / torch.sqrt(yd.var(0, unbiased=False) + 1e-5)
+    out = torch.relu(xh * gd + bd)
+    if p > 0:
+        out = out * ops.dropout_mask(5, 17, M, N, p, dev).cpu().double() / (1 - p)
+    out.backward(g.double())
+    sums = ops.bn_bwd_stats(g.to(dev), y.to(dev), pro, fold)
+    assert rel(sums[0], bd.grad) <= 1e-6 and rel(sums[1], gd.grad) <= 1e-5
+    c = (sums / M).float()
+    dy = ops.bn_bwd_apply(g.to(dev), y.to(dev), pro, fold, c[0].contiguous(), c[1].contiguous())
+    assert rel(dy, yd.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("N", [64, 128, 256])
+def test_l2norm(ops, dev, N):
+    gen = torch.Generator().manual_seed(N)
+    z = torch.randn(500, N, generator=gen)
+    z[3] = 0.0                      # clamp branch: ||z|| <= eps
+    z[4] = 1e-20
+    out, rn = ops.l2norm_fwd(z.to(dev))
+    zd = z.double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(zd, p=2, dim=1, eps=1e-12)
+    assert rel(out, ref.detach()) <= 1e-6
+    g = torch.randn(500, N, generator=gen)
+    ref.backward(g.double())
+    dz = ops.l2norm_bwd(g.to(dev), out, rn)
+    good = torch.ones(500, dtype=torch.bool); good[3] = False
+    assert rel(dz[good.to(dev)], zd.grad[good]) <= 1e-5
+    assert torch.isfinite(dz).all()
+
+
+# ------------------------------------------------------------------------------------------ heads
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("sorted_pairs", [False, True])
+def test_pair_head_fwd_bwd(ops, dev, p, sorted_pairs):
+    gen = torch.Generator().manual_seed(31)
+    P, L, n = 400, 50, 5000
+    A, B = torch.randn(P, 64, generator=gen), torch.randn(L, 64, generator=gen)
+    W2, b2 = torch.randn(32, 64, generator=gen) / 8, torch.randn(32, generator=gen) * 0.1
+    W3, b3 = torch.randn(32, generator=gen) / 5, torch.randn(1, generator=gen)
+    pi = torch.randint(0, P, (n,), generator=gen)
+    if sorted_pairs:
+        pi = pi.sort().values
+    li = torch.randint(0, L, (n,), generator=gen)
+    deg = torch.randint(0, 12, (P,), generator=gen)
+    pid = torch.randperm(n, generator=gen)
+    dpred = torch.randn(n, generator=gen)
+    head = ops.Head(*[t.to(dev) for t in (A, B, W2, b2, W3, b3)])
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    for want_low in (False, True):
+        pred = torch.full((n,), 123.0, device=dev)
+        ops.pair_head_fwd(head, i32(pi), i32(li), i32(deg), 6, want_low, p, 77, pid.to(dev), pred)
+        sel = (deg[pi] < 6) == want_low
+        leaf = [t.double().requires_grad_(True) for t in (A, B, W2, b2, W3, b3)]
+        h1 = torch.relu(leaf[0][pi] + leaf[1][li])
+        if p > 0:
+            m1 = ops.dropout_mask(77, 64, n, 64, p, dev).cpu().double()[pid]
+            h1 = h1 * m1 / (1 - p)
+        h2 = torch.relu(h1 @ leaf[2].t() + leaf[3])
+        if p > 0:
+            m2 = ops.dropout_mask(77, 65, n, 32, p, dev).cpu().double()[pid]
+            h2 = h2 * m2 / (1 - p)
+        ref = h2 @ leaf[4] + leaf[5]
+        assert rel(pred[sel.to(dev)], ref.detach()[sel]) <= 1e-5
+        assert bool((pred[(~sel).to(dev)] == 123.0).all())
+        (ref * dpred.double() * sel.double()).sum().backward()
+        g = ops.Head(*[torch.zeros_like(t, device=dev) for t in (A, B, W2, b2, W3, b3)])
+        ops.pair_head_bwd(head, g, i32(pi), i32(li), i32(deg), 6, want_low, L, p, 77, pid.to(dev), dpred.to(dev))
+        for name, got, want in zip("A B W2 b2 W3 b3".split(), (g.A, g.B, g.W2, g.b2, g.W3, g.b3), leaf):
+            assert rel(got, want.grad) <= 2e-5, (name, want_low)
+
+
+def test_ops_reject_cpu_tensors(ops):
+    with pytest.raises(Exception):
+        ops.linear_fwd(torch.zeros(4, 64), torch.zeros(64, 64))
