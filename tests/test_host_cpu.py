@@ -1,0 +1,114 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/mmgnn.h
+declares; the host mirror refuses to run without the HIP path; container + state_dict plumbing."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import fixtures as fx
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = {"model": {"architecture": "RGCN", "hidden_dim": 64, "num_layers": 2, "dropout": 0.0,
+                 "use_batch_norm": True, "activation": "relu"}}
+
+
+def header_symbols():
+    txt = open(os.path.join(REPO, "include", "mmgnn.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import mmgnn  # noqa: F401
+    from mmgnn import _lib
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/mmgnn.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype in _lib.SIGNATURES"
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.mmg_version() >= 100
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    import mmgnn  # noqa: F401
+    from mmgnn import _lib
+    lib = _lib.load()
+    # bad D is rejected on the host side before any launch
+    rc = lib.mmg_l2norm_fwd(None, None, None, 4, 100, 1e-12, None)
+    assert rc == -1 and b"unsupported" in lib.mmg_last_error()
+    rc = lib.mmg_csr_build(None, 10, 4, 2, None, None, None, None, 0, None)
+    assert rc == -1
+    assert lib.mmg_csr_build_ws_bytes(1000, 100) > 3 * 4000
+
+
+def test_cpu_model_fails_loudly():
+    import mmgnn  # noqa: F401
+    from mmgnn.model import build_model
+    g = fx.graph_from_frames(fx.det_frames(60, 9, 11, 8))
+    model = build_model(CFG, (g.node_types, g.edge_types), None)
+    model._init_embeddings(g)
+    with pytest.raises(Exception, match="HIP device|no CPU fallback"):
+        model(g)
+    from mmgnn import ops
+    with pytest.raises(Exception, match="HIP device"):
+        ops.linear_fwd(torch.zeros(4, 64), torch.zeros(64, 64))
+
+
+def test_param_count_and_state_dict_layout():
+    import mmgnn  # noqa: F401
+    from mmgnn.model import build_model
+    cfg = {"model": dict(CFG["model"], hidden_dim=128)}
+    m = build_model(cfg, (fx.NODE_TYPES, fx.EDGE_TYPES), None)
+    assert sum(p.numel() for p in m.parameters()) == 483970          # README.md:197 of the reference
+    assert len(m.embeddings) == 0                                    # lazy (model.py:86-89)
+    g = fx.graph_from_frames(fx.det_frames(1834, 50, 114, 100))
+    m._init_embeddings(g)
+    assert sum(p.numel() for p in m.parameters()) == 752514
+    sd = fx.det_state({t: g[t].num_nodes for t in g.node_types}, 128)
+    assert sorted(m.state_dict().keys()) == sorted(sd.keys())
+    m.load_state_dict(sd)
+    # PyG 2.3 key mangling 'src__rel__dst' is accepted too
+    old = {}
+    for k, v in sd.items():
+        mt = re.match(r"(convs\.\d+\.convs\.)<(.+)>(\..+)", k)
+        old[(mt.group(1) + mt.group(2).replace("___", "__") + mt.group(3)) if mt else k] = v
+    assert any("patient__has_lab__lab" in k for k in old)
+    m.load_state_dict(old)
+
+
+def test_unknown_config_values_raise_like_the_reference():
+    import mmgnn  # noqa: F401
+    from mmgnn.model import build_model, compute_regression_loss
+    with pytest.raises(ValueError, match="Unknown activation"):
+        build_model({"model": dict(CFG["model"], activation="gelu")}, (fx.NODE_TYPES, fx.EDGE_TYPES), None)
+    with pytest.raises(ValueError, match="Unknown architecture"):
+        build_model({"model": dict(CFG["model"], architecture="GAT")}, (fx.NODE_TYPES, fx.EDGE_TYPES), None)
+    with pytest.raises(ValueError, match="Unknown loss type"):
+        compute_regression_loss(torch.zeros(3), torch.zeros(3), "l3")
+    a, b = torch.tensor([1.0, 2.0, 4.0]), torch.tensor([0.0, 2.0, 2.0])
+    assert float(compute_regression_loss(a, b, "mae")) == pytest.approx(1.0)
+    assert float(compute_regression_loss(a, b, "mse")) == pytest.approx(5.0 / 3)
+
+
+def test_hetero_graph_container_protocol():
+    import mmgnn  # noqa: F401
+    from mmgnn.data import HeteroGraph
+    g = HeteroGraph()
+    g["patient"].num_nodes = 3
+    g["lab"].num_nodes = 2
+    ei = torch.tensor([[0, 1, 2], [1, 0, 1]])
+    g["patient", "has_lab", "lab"].edge_index = ei
+    g["patient", "has_lab", "lab"].edge_attr = torch.ones(3, 1)
+    g["lab", "has_lab_rev", "patient"].edge_index = ei.flip(0)
+    g.indexers = {"x": 1}
+    assert g.node_types == ["patient", "lab"]
+    assert g.edge_types == [("patient", "has_lab", "lab"), ("lab", "has_lab_rev", "patient")]
+    assert g.metadata() == (g.node_types, g.edge_types)
+    assert set(g.edge_index_dict) == set(g.edge_types)
+    assert g[("patient", "has_lab", "lab")].edge_attr.shape == (3, 1) and g.indexers == {"x": 1}
+    assert g.to("cpu") is g

@@ -1,0 +1,207 @@
+"""End-to-end parity of the HIP path (through the C ABI) against
+  (a) the golden vectors produced by the REFERENCE's own host code (tests/golden/model_*.npz) and
+  (b) the CPU oracle on the same inputs (eval, train with p=0, train with the device's dropout
+      masks injected into the oracle).
+Bar (BASELINE.json): predictions within 1e-4 relative fp32; gradients within 2e-4 of max|grad|.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_io import checksum, load, rel_err, t, unpack_mask
+from oracle import fixtures as fx
+from oracle import model as om
+from oracle import train as ot
+
+TOL = 1e-4
+CFG = {"model": {"architecture": "RGCN", "hidden_dim": 128, "num_layers": 2, "dropout": 0.0,
+                 "use_batch_norm": True, "activation": "relu"}}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def make(dev, n, hidden, dropout=0.0):
+    import mmgnn  # noqa: F401
+    from mmgnn.model import build_model
+    g = fx.graph_from_frames(fx.det_frames(*n))
+    gv = om.GraphView(g)
+    sd = fx.det_state(gv.num_nodes, hidden)
+    cfg = {"model": dict(CFG["model"], hidden_dim=hidden, dropout=dropout)}
+    model = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
+    gd = g.clone().to(dev)
+    model._init_embeddings(gd)
+    model.load_state_dict(sd, strict=True)
+    ei, ea = g["patient", "has_lab", "lab"].edge_index, g["patient", "has_lab", "lab"].edge_attr
+    return model, g, gd, gv, sd, ei, ea
+
+
+CASES = [("small", (300, 12, 15, 10), 64), ("eicu", (1834, 50, 114, 100), 128)]
+
+
+@pytest.mark.parametrize("tag,n,hidden", CASES)
+def test_state_dict_layout_matches_reference(dev, tag, n, hidden):
+    gold, meta = load(f"model_{tag}.npz")
+    model, *_ = make(dev, n, hidden)
+    assert list(model.state_dict().keys()) == meta["state_keys"]
+    assert sum(p.numel() for p in model.parameters()) == meta["params_after"]
+
+
+@pytest.mark.parametrize("tag,n,hidden", CASES)
+def test_eval_matches_reference_golden(dev, tag, n, hidden):
+    gold, meta = load(f"model_{tag}.npz")
+    model, g, gd, gv, sd, ei, ea = make(dev, n, hidden)
+    tr, va, te = ot.edge_splits(ei.shape[1], 0.7, 0.15, 0.15, 42)
+    model.eval()
+    with torch.no_grad():
+        enc = model.encode_nodes(gd)
+        fwd = model(gd)
+        pred = model.predict_lab_values(gd, ei[0][te].to(dev), ei[1][te].to(dev))
+    assert rel_err(pred.cpu(), t(gold["eval/pred_test"])) <= TOL
+    for nt in gv.node_types:
+        if f"eval/enc/{nt}" in gold:
+            assert rel_err(enc[nt].cpu(), t(gold[f"eval/enc/{nt}"])) <= TOL
+            assert rel_err(fwd[nt].cpu(), t(gold[f"eval/fwd/{nt}"])) <= TOL
+        else:
+            st = max(1, enc[nt].shape[0] // 16)
+            assert rel_err(enc[nt].cpu()[::st][:16], t(gold[f"eval/enc_rows/{nt}"])) <= TOL
+            assert rel_err(fwd[nt].cpu()[::st][:16], t(gold[f"eval/fwd_rows/{nt}"])) <= TOL
+        assert rel_err(checksum(fwd[nt].cpu()), t(gold[f"eval/fwd_sum/{nt}"])) <= TOL
+    # eval must not touch the BN buffers
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd[k]), k
+
+
+@pytest.mark.parametrize("tag,n,hidden", CASES)
+def test_train_step_matches_reference_golden(dev, tag, n, hidden):
+    gold, meta = load(f"model_{tag}.npz")
+    model, g, gd, gv, sd, ei, ea = make(dev, n, hidden)
+    tr, va, te = ot.edge_splits(ei.shape[1], 0.7, 0.15, 0.15, 42)
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    w = t(gold["lab_weights"])
+    sup = unpack_mask(gold["train/sup_mask"], int(tr.sum()))
+    model.train()
+    pred = model.predict_lab_values(gd, pi.to(dev), li.to(dev))
+    assert rel_err(checksum(pred.detach().cpu()), t(gold["train/pred_train_sum"])) <= TOL
+    loss = ((pred[sup.to(dev)] - y[sup].to(dev)).abs() * w[li[sup]].to(dev)).mean()       # train.py:366-386
+    assert abs(float(loss) - meta["train_loss"]) <= TOL * abs(meta["train_loss"])
+    loss.backward()
+    gmax = max(float(t(gold[k]).abs().max()) for k in gold if k.startswith("train/grad/"))
+    for k, p in model.named_parameters():
+        gr = p.grad.cpu() if p.grad is not None else torch.zeros_like(p).cpu()
+        if f"train/grad/{k}" in gold:
+            ref = t(gold[f"train/grad/{k}"])
+            assert float((gr - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6 * gmax, k
+        cs, cr = checksum(gr), t(gold[f"train/grad_sum/{k}"])
+        assert abs(float(cs[1] - cr[1])) <= 2e-4 * float(cr[1]) + 1e-6 * gmax * gr.numel(), k
+    for k, b in model.named_buffers():
+        ref = t(gold[f"train/buf/{k}"])
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == int(ref), k
+        else:
+            assert rel_err(b.cpu(), ref) <= TOL, k
+
+
+def _oracle_masks(ops, dev, seed, p, gv, n_pairs, D):
+    P = gv.num_nodes["patient"]
+    m = {}
+    for c in (0, 1):
+        m[f"enc{c}.drop0"] = ops.dropout_mask(seed, 2 * c, P, D, p, dev).cpu().float()
+        m[f"enc{c}.drop1"] = ops.dropout_mask(seed, 2 * c + 1, P, D, p, dev).cpu().float()
+    for ti, nt in enumerate(gv.node_types):
+        m[f"conv0.{nt}"] = ops.dropout_mask(seed, 16 + ti, gv.num_nodes[nt], D, p, dev).cpu().float()
+    m["head.drop0"] = ops.dropout_mask(seed, 64, n_pairs, 64, p, dev).cpu().float()
+    m["head.drop1"] = ops.dropout_mask(seed, 65, n_pairs, 32, p, dev).cpu().float()
+    return m
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_train_step_matches_oracle_with_injected_dropout(dev, p):
+    from mmgnn import ops
+    n, hidden = (500, 20, 25, 18), 128
+    model, g, gd, gv, sd, ei, ea = make(dev, n, hidden, dropout=p)
+    tr, va, te = ot.edge_splits(ei.shape[1], 0.7, 0.15, 0.15, 42)
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    w = ot.lab_weights(li, y, gv.num_nodes["lab"])
+    sup = ot.supervision_mask(int(tr.sum()), 0.2, torch.Generator().manual_seed(7))
+    seed = 424242
+    model._dropout_seed = seed
+    model.train()
+    pred = model.predict_lab_values(gd, pi.to(dev), li.to(dev))
+    loss = ((pred[sup.to(dev)] - y[sup].to(dev)).abs() * w[li[sup]].to(dev)).mean()
+    loss.backward()
+    masks = _oracle_masks(ops, dev, seed, p, gv, pi.numel(), hidden) if p > 0 else None
+    oloss, opred, ograds, obufs = ot.train_step_grads(sd, gv, pi, li, y, w, sup, p=p, masks=masks)
+    assert rel_err(pred.detach().cpu(), opred) <= TOL
+    assert abs(float(loss) - float(oloss)) <= TOL * abs(float(oloss))
+    gmax = max(float(v.abs().max()) for v in ograds.values())
+    for k, pm in model.named_parameters():
+        gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
+        ref = ograds[k]
+        assert float((gr - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6 * gmax, k
+    for k, b in model.named_buffers():
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == int(obufs[k]), k
+        else:
+            assert rel_err(b.cpu(), obufs[k]) <= TOL, k
+
+
+def test_forward_and_encode_are_differentiable(dev):
+    model, g, gd, gv, sd, ei, ea = make(dev, (300, 12, 15, 10), 64)
+    model.train()
+    out = model(gd)
+    (out["patient"].sum() + 2 * out["lab"].sum()).backward()
+    leaf = {k: v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v
+            for k, v in sd.items()}
+    o = om.forward(leaf, gv, training=True, p=0.0)
+    (o["patient"].sum() + 2 * o["lab"].sum()).backward()
+    gmax = max(float(v.grad.abs().max()) for v in leaf.values() if torch.is_tensor(v) and v.requires_grad and v.grad is not None)
+    for k, pm in model.named_parameters():
+        ref = leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k])
+        gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(ref)
+        assert float((gr - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6 * gmax, k
+    model.zero_grad()
+    enc = model.encode_nodes(gd)
+    enc["patient"].pow(2).sum().backward()
+    assert model.embeddings["patient"].weight.grad.abs().sum() > 0
+
+
+def test_isolated_and_low_degree_patients_use_the_tabular_head(dev):
+    model, g, gd, gv, sd, ei, ea = make(dev, (300, 12, 15, 10), 64)
+    model.eval()
+    deg = torch.bincount(ei[0], minlength=300)
+    low_p = torch.nonzero((deg > 0) & (deg < 6)).flatten()
+    assert len(low_p) > 0
+    pi = low_p.repeat_interleave(2)
+    li = torch.arange(len(pi)) % gv.num_nodes["lab"]
+    with torch.no_grad():
+        pred = model.predict_lab_values(gd, pi.to(dev), li.to(dev))
+        ref, _ = om.predict_lab_values(sd, gv, pi, li)
+    assert rel_err(pred.cpu(), ref) <= TOL
+
+
+def test_empty_pair_list_and_missing_embeddings(dev):
+    model, g, gd, gv, sd, ei, ea = make(dev, (120, 8, 9, 7), 64)
+    model.eval()
+    with torch.no_grad():
+        out = model.predict_lab_values(gd, torch.empty(0, dtype=torch.long, device=dev),
+                                       torch.empty(0, dtype=torch.long, device=dev))
+    assert out.shape == (0,)
+    import mmgnn  # noqa: F401
+    from mmgnn.model import build_model
+    fresh = build_model({"model": dict(CFG["model"], hidden_dim=64)}, (g.node_types, g.edge_types), None).to(dev)
+    assert len(fresh.embeddings) == 0
+    fresh.eval()
+    with torch.no_grad():
+        fresh(gd)                       # lazy creation on first forward (model.py:247-248)
+    assert len(fresh.embeddings) == 4
+    with pytest.raises(ValueError):
+        build_model({"model": dict(CFG["model"], activation="gelu")}, (g.node_types, g.edge_types), None)
+    with pytest.raises(ValueError):
+        build_model({"model": dict(CFG["model"], architecture="GAT")}, (g.node_types, g.edge_types), None)
