@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: has_lab edges/s for one full training step
+(fwd + weighted-MAE loss + bwd + Adam) of ``predict_lab_values`` on a synthetic eICU-shape hetero-graph.
+
+    python bench.py --gpus N --steps K --warmup W [--scale S] [--dim D] [--strong]
+
+One process per GPU (N>1: launched by torch.distributed.run, RCCL).  Workload at N GPUs:
+  default (weak): every GPU holds an  x<scale>  eICU-shape shard (1,834*scale patients, 61,484*scale
+                  has_lab edges, 128-d) of ONE global graph of N shards; vocab nodes shared.
+                  N=1, scale=100 is BASELINE.json configs[2].
+  --strong      : ONE global x<scale> graph, patient-sharded over the N GPUs.
+Prints ONE JSON line (rank 0) with the whole-job rate, the roofline of the dominant kernel (HIP events
+on the launch stream) and a CPU baseline (the oracle restatement, timed on this host's cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+import mmgnn  # noqa: E402,F401
+from mmgnn import dist as mdist  # noqa: E402
+from mmgnn import ops  # noqa: E402
+from mmgnn.data import build_plan  # noqa: E402
+from mmgnn.model import build_model  # noqa: E402
+from mmgnn.synth import make_graph  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA
+LAB = ("patient", "has_lab", "lab")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=int, default=100, help="eICU-shape multiples per GPU (weak) or in total (--strong)")
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--strong", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scale", type=int, default=10)
+    ap.add_argument("--profile-ops", action="store_true", help="print the per-op time table to stderr")
+    return ap.parse_args()
+
+
+def setup_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return world, rank, torch.device("cuda", local)
+
+
+def build_workload(args, world, rank, dev):
+    cfg = {"model": {"architecture": "RGCN", "hidden_dim": args.dim, "num_layers": 2, "dropout": args.dropout,
+                     "use_batch_norm": True, "activation": "relu"}}
+    comm = mdist.ShardComm() if world > 1 else None
+    if args.strong and world > 1:
+        g_all = make_graph(args.scale, seed=0, device=dev)
+        w = mdist.patient_weights(g_all)
+        b = mdist.partition_rows(w, world)
+        lo, hi = b[rank], b[rank + 1]
+        g = mdist.shard_graph(g_all, lo, hi)
+        n_global = int(g_all["patient"].num_nodes)
+        del g_all
+    else:
+        g = make_graph(args.scale, seed=1000 * rank, device=dev)     # this rank's shard of the global graph
+        P = int(g["patient"].num_nodes)
+        lo, hi, n_global = rank * P, (rank + 1) * P, world * P
+    torch.manual_seed(42)
+    model = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
+    model._init_embeddings(g)
+    plan = build_plan(g, dev)
+    if comm is not None:
+        mdist.shard_plan(plan, comm, lo, n_global)
+        mdist.shard_model(model, comm)
+        for name, p in model.named_parameters():   # replicated weights: identical on every rank
+            if name != "embeddings.patient.weight":  # (the patient table is sharded, not replicated)
+                torch.distributed.broadcast(p.data, 0)
+    # EdgeMasker rule (train.py:98-129) on this shard's has_lab edges, device RNG for speed at scale
+    ei = g[LAB].edge_index
+    E = ei.shape[1]
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    perm = torch.randperm(E, generator=gen, device=dev)
+    tr = perm[: int(0.7 * E)].sort().values
+    pi, li = ei[0][tr].contiguous(), ei[1][tr].contiguous()
+    y = g[LAB].edge_attr[tr].squeeze(-1).contiguous()
+    sup = torch.rand(tr.numel(), generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev) < 0.2
+    wlab = torch.ones(int(g["lab"].num_nodes), device=dev)
+    opt = torch.optim.Adam([p for n, p in model.named_parameters() if not n.startswith("embeddings.")],
+                           lr=1e-3, weight_decay=1e-5)         # F5: embeddings are not in the optimizer
+    n_sup_global = torch.tensor([float(sup.sum())], device=dev)
+    if comm is not None:
+        torch.distributed.all_reduce(n_sup_global)
+    return dict(model=model, plan=plan, g=g, pi=pi, li=li, y=y, sup=sup, wlab=wlab, opt=opt, E=E,
+                n_sup=float(n_sup_global), comm=comm)
+
+
+def train_step(w):
+    model, opt = w["model"], w["opt"]
+    model.train()
+    opt.zero_grad(set_to_none=True)
+    pred = model.predict_lab_values(w["plan"], w["pi"], w["li"])
+    sup = w["sup"]
+    per = (pred[sup] - w["y"][sup]).abs() * w["wlab"][w["li"][sup]]
+    loss = per.sum() / w["n_sup"]            # global mean over all shards' supervised pairs
+    loss.backward()
+    opt.step()
+    return loss
+
+
+def host_cores():
+    """CPU share of this process: affinity mask, cgroup quota, and the one-GPU box share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference) on a bounded sample of the same workload."""
+    from oracle import model as om, train as ot
+    s = max(1, min(args.cpu_scale, args.scale))
+    g = make_graph(s, seed=0, device="cpu")
+    gv = om.GraphView(g)
+    sd = om.init_state(gv.num_nodes, gv.edge_types, args.dim, 2, seed=42)
+    ei, ea = g[LAB].edge_index, g[LAB].edge_attr
+    E = ei.shape[1]
+    tr = torch.randperm(E, generator=torch.Generator().manual_seed(42))[: int(0.7 * E)].sort().values
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    sup = torch.rand(tr.numel(), generator=torch.Generator().manual_seed(1234)) < 0.2
+    wl = torch.ones(gv.num_nodes["lab"])
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    times = []
+    n_steps = 4 if s <= 1 else 3
+    for i in range(n_steps):
+        t0 = time.perf_counter()
+        ot.train_step_grads(sd, gv, pi, li, y, wl, sup, p=args.dropout)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": E / t, "unit": "has_lab edges/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (pure PyTorch CPU restatement) fwd+loss+bwd on the x{s} eICU-shape graph "
+                      f"({E} has_lab edges, {args.dim}-d, dropout {args.dropout}), median of {len(times) - 1} steps "
+                      f"after 1 warm-up, {cores} threads"}
+
+
+def main():
+    args = parse()
+    world, rank, dev = setup_dist(args)
+    w = build_workload(args, world, rank, dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up; the last warm-up step is profiled per op to find the dominant kernel
+    for i in range(max(args.warmup, 1)):
+        if i == max(args.warmup, 1) - 1:
+            prof = ops.OpProfiler()
+            ops.set_profiler(prof)
+        train_step(w)
+    table = prof.summary()
+    ops.set_profiler(None)
+    dominant = max(table.items(), key=lambda kv: kv[1]["ms"])[0]
+    if args.profile_ops and rank == 0:
+        tot = sum(v["ms"] for v in table.values())
+        for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
+            print(f"  {k:18s} calls {v['calls']:3d}  {v['ms']:9.3f} ms ({100 * v['ms'] / tot:5.1f}%)  "
+                  f"{gbs:8.1f} GB/s alg  {tf:6.2f} TFLOP/s", file=sys.stderr)
+
+    # ---- timed region: exactly K steps; only the dominant op carries HIP events
+    prof = ops.OpProfiler(only=[dominant])
+    ops.set_profiler(prof)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(w)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_profiler(None)
+    dom = prof.summary()[dominant]
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    edges = torch.tensor([float(w["E"])], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(edges)
+    dt = float(tmax)
+    total_edges = float(edges)
+
+    if rank == 0:
+        value = total_edges * args.steps / dt
+        launches = dom["calls"]
+        avg_ms = dom["ms"] / launches
+        bytes_per_launch = dom["bytes"] / launches
+        flops_per_launch = dom["flops"] / launches
+        hbm_frac = (bytes_per_launch / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS
+        mfma_frac = (flops_per_launch / (avg_ms * 1e-3) / 1e12) / MFMA_F32_PEAK_TF
+        if mfma_frac > hbm_frac:
+            roof = {"bound": "mfma", "achieved": flops_per_launch / (avg_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": mfma_frac, "traffic": None}
+        else:
+            roof = {"bound": "hbm", "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": hbm_frac, "traffic": None}
+        roof.update({"kernel": dominant, "avg_launch_ms": avg_ms, "launches_timed": launches,
+                     "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch})
+        P_loc = int(w["plan"].n_rows)
+        out = {
+            "metric": "has_lab edges/s, one full training step (fwd + weighted-MAE loss + bwd + Adam) of "
+                      "predict_lab_values on the full hetero-graph",
+            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"eICU-shape synthetic hetero-graph x{args.scale}"
+                                    + (" total, patient-sharded" if args.strong else " per GPU")
+                                    + f", {args.dim}-d, 2 SAGE layers x 6 relations, dropout {args.dropout}"),
+                       "patients_per_gpu": P_loc, "has_lab_edges_total": int(total_edges),
+                       "train_pairs_rank0": int(w["pi"].numel()), "hidden_dim": args.dim,
+                       "parallelism": f"patient-shard x{world}" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "loss": float(loss.detach()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

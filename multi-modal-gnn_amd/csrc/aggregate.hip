@@ -3,10 +3,10 @@
 //
 //  gather : one wave per patient row, lane owns D/64 contiguous floats (a 64-lane row read is one
 //           coalesced 256..1024-B segment); the source tables are the tiny vocab tables (L2-resident).
-//  scatter: patient-major streaming; every workgroup owns a contiguous row chunk, accumulates into
-//           LDS-resident vocab accumulators [n_cols, DC] with ds_add_f32, then writes ONE partial
-//           slab; a second kernel sums the slabs in fixed order (deterministic across launches for a
-//           fixed grid except for the intra-workgroup LDS add order).
+//  scatter: patient-major streaming; every workgroup owns a contiguous row chunk and multiplies the
+//           32-row indicator tile (built in LDS from the CSR) with the feature tile on the fp32 matrix
+//           cores, keeping the [V, D] accumulators in registers; ONE partial slab per workgroup, summed
+//           by a second kernel in fixed order (bitwise reproducible).
 #include "common.h"
 
 namespace {
@@ -76,102 +76,174 @@ __global__ __launch_bounds__(256) void k_gather(RelPack rp, int64_t n_rows, floa
 }
 
 // ------------------------------------------------------------------------------ scatter
-constexpr int SC_THREADS = 512;
-constexpr size_t SC_LDS_BUDGET = 144 * 1024;
+// out[v, :] = sum_rows Ind[row, v] * x[row, :]  is a tall-skinny product  Ind^T [V x P] . x [P x D].
+// LDS float atomics (ds_add_f32) were measured at ~0.3 adds/clk/CU on gfx950 -- 40x off the HBM
+// time of this pass -- so the per-row indicator tile (rowscale at the edge positions, else 0) is
+// materialised in LDS for 32 patient rows at a time and multiplied on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: 1.0*x and rs*x products are exact, accumulation is fp32).  has_lab is 67 %
+// dense, so this is the dense formulation of a dense block, not a reshaped sparse op; the sparse
+// relations ride along in the same pass so that x is read from HBM once.
+// Each workgroup owns a contiguous row chunk and ALL vocab tiles (accumulators stay in registers for
+// the whole chunk), writes one partial slab; k_scatter_reduce sums the slabs in fixed order.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+constexpr int SC_ROWS = 32;     // patient rows per LDS stage (= MFMA K extent per stage)
+constexpr int SC_MAX_NT = 16;   // 32-row vocab tiles per launch (512 padded vocab rows)
 
 struct ScatterPlan {
-  int dc;            // accumulator column-chunk width (64 | 128 | 256)
-  int n_dchunks;     // D / dc
-  int total_cols;    // sum of n_cols
-  int n_rowchunks;   // workgroups along the row axis
-  int64_t rows_per_chunk;
-  size_t lds_bytes;
-  bool lds_ok;
+  int nt;              // padded vocab tiles (template instance)
+  int total_pad;       // nt * 32
+  int dc;              // feature columns per workgroup (64 | 128)
+  int n_dchunks;
+  int n_split;
+  int64_t rows_per_split;
+  bool ok;
 };
+
+int pad32(int n) { return (n + 31) & ~31; }
 
 ScatterPlan plan_scatter(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
   ScatterPlan p{};
-  p.total_cols = 0;
-  for (int r = 0; r < n_rel; ++r) p.total_cols += rels[r].n_cols;
-  p.dc = D;
-  while ((size_t)p.total_cols * p.dc * 4 > SC_LDS_BUDGET && p.dc > 64) p.dc >>= 1;
-  p.lds_ok = (size_t)p.total_cols * p.dc * 4 <= SC_LDS_BUDGET;
+  int tiles = 0;
+  for (int r = 0; r < n_rel; ++r) tiles += pad32(rels[r].n_cols) / 32;
+  const int inst[] = {2, 4, 6, 8, 10, 12, 16};
+  p.ok = false;
+  for (int i = 0; i < 7; ++i)
+    if (tiles <= inst[i]) { p.nt = inst[i]; p.ok = true; break; }
+  p.total_pad = p.nt * 32;
+  p.dc = D >= 128 ? 128 : 64;
   p.n_dchunks = D / p.dc;
-  p.lds_bytes = (size_t)p.total_cols * p.dc * 4;
-  // one workgroup per CU and column chunk; at least 32 rows per workgroup
-  int64_t want = 256 / p.n_dchunks;
+  int64_t max_split = (n_rows + SC_ROWS - 1) / SC_ROWS;
+  if (max_split < 1) max_split = 1;
+  int64_t want = 512 / p.n_dchunks;      // two workgroups per CU: one stages while the other multiplies
   if (want < 1) want = 1;
-  int64_t maxc = (n_rows + 31) / 32;
-  if (maxc < 1) maxc = 1;
-  p.n_rowchunks = (int)(want < maxc ? want : maxc);
-  p.rows_per_chunk = (n_rows + p.n_rowchunks - 1) / p.n_rowchunks;
+  p.n_split = (int)(want < max_split ? want : max_split);
+  int64_t rps = (n_rows + p.n_split - 1) / p.n_split;
+  rps = (rps + SC_ROWS - 1) / SC_ROWS * SC_ROWS;
+  p.rows_per_split = rps;
+  p.n_split = (int)((n_rows + rps - 1) / rps);
+  if (p.n_split < 1) p.n_split = 1;
   return p;
 }
 
-// slab layout: [n_rowchunks][total_cols][D]
-template <int VECC>   // floats per lane inside the column chunk: dc = 64*VECC
-__global__ __launch_bounds__(SC_THREADS) void k_scatter_lds(RelPack rp, int64_t n_rows, int64_t rows_per_chunk, int D,
-                                                            int total_cols, const float* __restrict__ x,
-                                                            float* __restrict__ slab) {
-  extern __shared__ __attribute__((aligned(16))) float acc[];
-  constexpr int DC = VECC * 64;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = SC_THREADS / 64;
+// slab layout: [n_split][NT*32][D]
+// The indicator tile holds integer edge COUNTS (ds_add_u32: multi-edges add up, exactly like
+// scatter_add); the rowscale of the tile's relation is applied when the A fragment is read.
+template <int NT, int KT, bool HAS_RS>   // KT = 32-column tiles per workgroup (dc = 32*KT)
+__global__ __launch_bounds__(256, 2) void k_scatter_mfma(RelPack rp, int64_t n_rows, int64_t rows_per_split, int D,
+                                                         const float* __restrict__ x, float* __restrict__ slab) {
+  constexpr int NTOT = NT * 32, DC = KT * 32;
+  constexpr int NSPLIT = 4 / KT, NTW = NT / NSPLIT;
+  __shared__ __attribute__((aligned(16))) int Cs[SC_ROWS][NTOT];
+  __shared__ __attribute__((aligned(16))) float Xs[SC_ROWS][DC];
+  __shared__ float RSt[NT][SC_ROWS];   // rowscale of the relation that owns each vocab tile, per stage row
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int kt = wid % KT, nt0 = (wid / KT) * NTW;
+  const int h = lane >> 5, l31 = lane & 31;
   const int d0 = blockIdx.y * DC;
-  const int n_acc = total_cols * DC;
-  for (int i = threadIdx.x; i < n_acc; i += SC_THREADS) acc[i] = 0.f;
-  __syncthreads();
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_split;
+  const int64_t r_end = min(n_rows, r_beg + rows_per_split);
 
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
-  const int64_t r1 = min(n_rows, r0 + rows_per_chunk);
-  for (int64_t row = r0 + wid; row < r1; row += nw) {
-    float xv[VECC];
-    const float* src = x + (size_t)row * D + d0 + lane * VECC;
+  f32x16 acc[NTW];
 #pragma unroll
-    for (int v = 0; v < VECC; ++v) xv[v] = src[v];
-    for (int r = 0; r < rp.n; ++r) {
-      const RelDev& R = rp.r[r];
-      const int beg = R.rowptr[row], end = R.rowptr[row + 1];
-      if (beg == end) continue;
-      const float rs = R.rowscale ? R.rowscale[row] : 1.f;
-      float sv[VECC];
+  for (int t = 0; t < NTW; ++t)
 #pragma unroll
-      for (int v = 0; v < VECC; ++v) sv[v] = xv[v] * rs;
-      for (int base = beg; base < end; base += 64) {
-        const int cnt = min(64, end - base);
-        const int cidx = (lane < cnt) ? R.col[base + lane] : 0;
-        for (int j = 0; j < cnt; ++j) {
-          const int c = __builtin_amdgcn_readlane(cidx, j);
-          float* a = acc + (size_t)(R.acc_off + c) * DC + lane * VECC;
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += SC_ROWS) {
+    __syncthreads();                       // previous stage's MFMA reads are done
+    const f32x4s z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < SC_ROWS * NTOT / 4; i += 256) reinterpret_cast<f32x4s*>(&Cs[0][0])[i] = z;
+    for (int i = tid; i < SC_ROWS * DC / 4; i += 256) {
+      const int r = i / (DC / 4), c4 = i - r * (DC / 4);
+      f32x4s v = z;
+      if (r0 + r < r_end) v = *reinterpret_cast<const f32x4s*>(x + (size_t)(r0 + r) * D + d0 + c4 * 4);
+      *reinterpret_cast<f32x4s*>(&Xs[r][c4 * 4]) = v;
+    }
+    if (HAS_RS) {
+      for (int i = tid; i < NT * SC_ROWS; i += 256) {
+        const int t = i / SC_ROWS, m = i - t * SC_ROWS;
+        int rel = 0;                       // tiles never straddle relations (acc_off is a multiple of 32)
+        for (int r = 1; r < rp.n; ++r)
+          if (t * 32 >= rp.r[r].acc_off) rel = r;
+        float v = 1.f;
+        if (rp.r[rel].rowscale && r0 + m < r_end) v = rp.r[rel].rowscale[r0 + m];
+        RSt[t][m] = v;
+      }
+    }
+    __syncthreads();                       // zero-fill complete before the counts land
+    {   // 8 lanes per row: every thread issues its (independent) rowptr and col loads at once
+      const int m = tid >> 3, q = tid & 7;
+      const int64_t row = r0 + m;
+      if (row < r_end) {
+        int beg[MMG_MAX_REL], end[MMG_MAX_REL];
 #pragma unroll
-          for (int v = 0; v < VECC; ++v) atomicAdd(a + v, sv[v]);   // ds_add_f32
+        for (int r = 0; r < MMG_MAX_REL; ++r) {
+          beg[r] = 0; end[r] = 0;
+          if (r < rp.n) { beg[r] = rp.r[r].rowptr[row]; end[r] = rp.r[r].rowptr[row + 1]; }
+        }
+#pragma unroll
+        for (int r = 0; r < MMG_MAX_REL; ++r) {
+          if (r < rp.n)
+            for (int k = beg[r] + q; k < end[r]; k += 8) atomicAdd(&Cs[m][rp.r[r].acc_off + rp.r[r].col[k]], 1);
         }
       }
     }
+    __syncthreads();
+    // A[i=v][k=m] = cnt[m][v] * rs[m],  B[k=m][j=d] = Xs[m][d];  lane half h takes m = 16h + s
+#pragma unroll 4
+    for (int s = 0; s < SC_ROWS / 2; ++s) {
+      const int m = h * (SC_ROWS / 2) + s;
+      const float b = Xs[m][kt * 32 + l31];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        float a = (float)Cs[m][(nt0 + t) * 32 + l31];
+        if (HAS_RS) a *= RSt[nt0 + t][m];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
   }
-  __syncthreads();
-  // flush: acc[c][0..DC) -> slab[blockIdx.x][c][d0..d0+DC)
-  float* dst = slab + (size_t)blockIdx.x * total_cols * D;
-  for (int i = threadIdx.x; i < n_acc; i += SC_THREADS) {
-    const int c = i / DC, d = i - c * DC;
-    dst[(size_t)c * D + d0 + d] = acc[i];
-  }
+  float* dst = slab + (size_t)blockIdx.x * NTOT * D;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int v = (nt0 + t) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      dst[(size_t)v * D + d0 + kt * 32 + l31] = acc[t][i];
+    }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_reduce(RelPack rp, int D, int total_cols, int n_chunks,
+__global__ __launch_bounds__(256) void k_scatter_reduce(RelPack rp, int D, int total_pad, int n_split,
                                                         const float* __restrict__ slab) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t n = (int64_t)total_cols * D;
+  const int64_t n = (int64_t)total_pad * D;
   if (i >= n) return;
   const int c = (int)(i / D), d = (int)(i - (int64_t)c * D);
-  float s = 0.f;
-  for (int b = 0; b < n_chunks; ++b) s += slab[(size_t)b * n + i];
   for (int r = 0; r < rp.n; ++r) {
     const RelDev& R = rp.r[r];
     if (c >= R.acc_off && c < R.acc_off + R.n_cols) {
+      float s = 0.f;
+      for (int b = 0; b < n_split; ++b) s += slab[(size_t)b * n + i];
       const int j = c - R.acc_off;
       const float cs = R.colscale ? R.colscale[j] : 1.f;
       R.out[(size_t)j * D + d] = s * cs;
+      return;
     }
+  }
+}
+
+template <int NT>
+void launch_scatter_mfma(const ScatterPlan& p, const RelPack& rp, int64_t n_rows, int D, const float* x, float* slab,
+                         hipStream_t st) {
+  dim3 grid((unsigned)p.n_split, (unsigned)p.n_dchunks);
+  bool has_rs = false;
+  for (int r = 0; r < rp.n; ++r) has_rs |= rp.r[r].rowscale != nullptr;
+  if (p.dc == 128) {
+    if (has_rs) hipLaunchKernelGGL((k_scatter_mfma<NT, 4, true>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
+    else hipLaunchKernelGGL((k_scatter_mfma<NT, 4, false>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
+  } else {
+    if (has_rs) hipLaunchKernelGGL((k_scatter_mfma<NT, 2, true>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
+    else hipLaunchKernelGGL((k_scatter_mfma<NT, 2, false>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
   }
 }
 
@@ -198,7 +270,7 @@ __global__ __launch_bounds__(256) void k_scatter_atomic(RelPack rp, int64_t n_ro
   }
 }
 
-int pack(const mmg_rel_t* rels, int n_rel, RelPack* rp, bool need_table, bool need_out) {
+int pack(const mmg_rel_t* rels, int n_rel, RelPack* rp, bool need_table, bool need_out, bool pad_cols = false) {
   MMG_CHECK_ARG(rels && n_rel >= 1 && n_rel <= MMG_MAX_REL, "aggregate: n_rel must be 1..%d", MMG_MAX_REL);
   rp->n = n_rel;
   int off = 0;
@@ -208,7 +280,7 @@ int pack(const mmg_rel_t* rels, int n_rel, RelPack* rp, bool need_table, bool ne
     MMG_CHECK_ARG(!need_out || rels[r].out, "aggregate: relation %d has null out", r);
     rp->r[r] = RelDev{rels[r].rowptr, rels[r].col, rels[r].rowscale, rels[r].colscale, rels[r].table,
                       rels[r].out, rels[r].n_cols, off};
-    off += rels[r].n_cols;
+    off += pad_cols ? ((rels[r].n_cols + 31) & ~31) : rels[r].n_cols;
   }
   return MMG_OK;
 }
@@ -236,8 +308,8 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
 extern "C" size_t mmg_scatter_rows_ws_bytes(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
   if (!rels || n_rel < 1 || n_rel > MMG_MAX_REL || !mmg_valid_D(D) || n_rows < 0) return 0;
   ScatterPlan p = plan_scatter(rels, n_rel, n_rows, D);
-  if (!p.lds_ok) return 256;
-  return (size_t)p.n_rowchunks * p.total_cols * D * 4 + 256;
+  if (!p.ok) return 256;
+  return (size_t)p.n_split * p.total_pad * D * 4 + 256;
 }
 
 extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, const float* x, void* ws,
@@ -245,14 +317,19 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
   MMG_CHECK_ARG(mmg_valid_D(D), "scatter_rows: D=%d unsupported (64|128|256)", D);
   MMG_CHECK_ARG(n_rows >= 0 && n_rows < 2147483647LL / 64, "scatter_rows: n_rows out of range");
   RelPack rp;
-  int rc = pack(rels, n_rel, &rp, false, true);
+  int rc = pack(rels, n_rel, &rp, false, true, true);
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   ScatterPlan p = plan_scatter(rels, n_rel, n_rows, D);
-  if (p.total_cols == 0) return MMG_OK;
-  if (n_rows == 0 || !p.lds_ok) {
+  int total_cols = 0;
+  for (int r = 0; r < n_rel; ++r) total_cols += rels[r].n_cols;
+  if (total_cols == 0) return MMG_OK;
+  if (n_rows == 0 || !p.ok) {
+    // empty input, or more than 512 padded vocab rows: zero + global float atomics
+    rc = pack(rels, n_rel, &rp, false, true, false);
+    if (rc) return rc;
     for (int r = 0; r < n_rel; ++r)
-      if (rels[r].n_cols > 0) hipMemsetAsync(rels[r].out, 0, (size_t)rels[r].n_cols * D * 4, st);
+      if (rels[r].n_cols > 0) (void)hipMemsetAsync(rels[r].out, 0, (size_t)rels[r].n_cols * D * 4, st);
     if (n_rows == 0) return MMG_OK;
     MMG_CHECK_ARG(x, "scatter_rows: x is null");
     const unsigned nb = (unsigned)((n_rows + 3) / 4);
@@ -269,23 +346,18 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     return MMG_E_WS;
   }
   float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  dim3 grid((unsigned)p.n_rowchunks, (unsigned)p.n_dchunks);
-  if (p.dc == 64) {
-    hipFuncSetAttribute((const void*)k_scatter_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    hipLaunchKernelGGL(k_scatter_lds<1>, grid, dim3(SC_THREADS), p.lds_bytes, st, rp, n_rows, p.rows_per_chunk, D,
-                       p.total_cols, x, slab);
-  } else if (p.dc == 128) {
-    hipFuncSetAttribute((const void*)k_scatter_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    hipLaunchKernelGGL(k_scatter_lds<2>, grid, dim3(SC_THREADS), p.lds_bytes, st, rp, n_rows, p.rows_per_chunk, D,
-                       p.total_cols, x, slab);
-  } else {
-    hipFuncSetAttribute((const void*)k_scatter_lds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-    hipLaunchKernelGGL(k_scatter_lds<4>, grid, dim3(SC_THREADS), p.lds_bytes, st, rp, n_rows, p.rows_per_chunk, D,
-                       p.total_cols, x, slab);
+  switch (p.nt) {
+    case 2: launch_scatter_mfma<2>(p, rp, n_rows, D, x, slab, st); break;
+    case 4: launch_scatter_mfma<4>(p, rp, n_rows, D, x, slab, st); break;
+    case 6: launch_scatter_mfma<6>(p, rp, n_rows, D, x, slab, st); break;
+    case 8: launch_scatter_mfma<8>(p, rp, n_rows, D, x, slab, st); break;
+    case 10: launch_scatter_mfma<10>(p, rp, n_rows, D, x, slab, st); break;
+    case 12: launch_scatter_mfma<12>(p, rp, n_rows, D, x, slab, st); break;
+    default: launch_scatter_mfma<16>(p, rp, n_rows, D, x, slab, st); break;
   }
-  const int64_t n = (int64_t)p.total_cols * D;
-  hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rp, D, p.total_cols,
-                     p.n_rowchunks, slab);
+  const int64_t n = (int64_t)p.total_pad * D;
+  hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rp, D, p.total_pad,
+                     p.n_split, slab);
   MMG_CHECK_LAUNCH("scatter_rows");
   return MMG_OK;
 }

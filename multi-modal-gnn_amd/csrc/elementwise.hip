@@ -7,7 +7,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int CR_MAX_BLOCKS = 1024;
+constexpr int CR_MAX_BLOCKS = 2048;
 
 struct ColGeom { int cg, rl; int nblk; int64_t rows_per_blk; };
 inline bool col_geom(int64_t M, int N, ColGeom* g) {
@@ -42,9 +42,7 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ A,
     rs = *reinterpret_cast<const f32x4*>(rstd + c4 * 4);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
-  for (int64_t r = r0 + rr; r < r1; r += rl) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)r * N + c4 * 4);
-    const f32x4 b = B ? *reinterpret_cast<const f32x4*>(B + (size_t)r * N + c4 * 4) : a;
+  auto body = [&](int64_t r, const f32x4& a, const f32x4& b) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float av = a[j], bv = b[j];
@@ -63,6 +61,21 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ A,
       s0[j] += (double)av;
       s1[j] += (double)av * (double)bv;
     }
+  };
+  int64_t r = r0 + rr;
+  for (; r + 3 * rl < r1; r += 4 * rl) {       // 4 independent 16-B loads per operand in flight
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4*>(A + (size_t)(r + u * rl) * N + c4 * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = B ? *reinterpret_cast<const f32x4*>(B + (size_t)(r + u * rl) * N + c4 * 4) : a[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(r + u * rl, a[u], b[u]);
+  }
+  for (; r < r1; r += rl) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)r * N + c4 * 4);
+    const f32x4 b = B ? *reinterpret_cast<const f32x4*>(B + (size_t)r * N + c4 * 4) : a;
+    body(r, a, b);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -77,13 +90,16 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ A,
   }
 }
 
+// one wave per output element: lanes stride over the block partials, then a fixed-order wave reduction
 __global__ __launch_bounds__(256) void k_partial_sum(const double* __restrict__ partial, double* __restrict__ out, int n,
                                                      int nblk) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (i >= n) return;
   double s = 0;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n + i];
-  out[i] = s;
+  for (int b = lane; b < nblk; b += 64) s += partial[(size_t)b * n + i];
+  s = wave_sum_d(s);
+  if (lane == 0) out[i] = s;
 }
 
 __global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ sums, int64_t count,
@@ -233,7 +249,7 @@ int run_col_reduce(const float* A, const float* B, const ProDev& pr, const float
   double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   hipLaunchKernelGGL(k_col_reduce<MODE>, dim3(g.nblk), dim3(256), 0, st, A, B, pr, mean, rstd, partial, M, N,
                      g.rows_per_blk);
-  hipLaunchKernelGGL(k_partial_sum, dim3((2 * N + 255) / 256), dim3(256), 0, st, partial, out, 2 * N, g.nblk);
+  hipLaunchKernelGGL(k_partial_sum, dim3((2 * N + 3) / 4), dim3(256), 0, st, partial, out, 2 * N, g.nblk);
   return MMG_OK;
 }
 

@@ -220,6 +220,221 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
   if (lds_db) for (int i = tid; i < n_labs * 64; i += PT) atomicAdd(Gd.dB + i, DBs[i]);
 }
 
+// ---------------------------------------------------------------------------- backward on MFMA
+// One WAVE owns a tile of 32 pairs; every contraction of the head backward runs on the fp32 matrix
+// cores (v_mfma_f32_32x32x2_f32), the vector ALUs only do the gather-add, masks and epilogues:
+//   (1) H2pre[pair,u]   = H1[pair,:] . W2[u,:]            32 MFMA   (A = h1 rows in registers)
+//   (2) dW2[u,k]       += D2[pair,u] * H1[pair,k]          32 MFMA   (A = the C-layout of (1): no lane movement)
+//   (3) dH1[pair,k]     = D2[pair,:] . W2[:,k]             32 MFMA   (A = D2 transposed through a 4 KB LDS tile)
+//   (4) dB[lab,k]      += [li[pair]==lab] * dH1[pair,k]    16*LT*2 MFMA (one-hot A built on the fly)
+// dA[pi] is flushed with run-length pre-reduction (pairs arrive sorted by patient).  No workgroup
+// barrier anywhere: waves are independent.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TP = 32;                 // pairs per wave tile
+constexpr int LDH = 68;                // H1 / dH1 tile row stride (floats)
+constexpr int LDD = 36;                // D2 tile row stride
+constexpr int WAVE_LDS = TP * LDH + TP * LDD + 4 * TP + 2 * TP;   // floats per wave
+
+__device__ inline int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+template <int LT>
+__global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
+                                                       const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
+                                                       int thr, int want_low, int64_t n, int n_labs, float drop_p,
+                                                       uint64_t seed, const int64_t* __restrict__ pair_id,
+                                                       const float* __restrict__ dpred) {
+  __shared__ __attribute__((aligned(16))) float sm[4 * WAVE_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  float* H1s = sm + wid * WAVE_LDS;                 // [32][LDH]  (later: dH1 tile)
+  float* D2s = H1s + TP * LDH;                      // [32][LDD]
+  int* PIs = reinterpret_cast<int*>(D2s + TP * LDD);   // [32] patient or -1
+  int* LIs = PIs + TP;                              // [32]
+  float* DOs = reinterpret_cast<float*>(LIs + TP);  // [32] dout (0 for inactive)
+  unsigned* PLo = reinterpret_cast<unsigned*>(DOs + TP);   // [32] pair id low / high words
+  unsigned* PHi = PLo + TP;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+
+  // ---- loop-invariant weight fragments
+  float w2b[32];            // B of (1): W2[u=l31][k=32h+s]
+#pragma unroll
+  for (int s = 0; s < 32; ++s) w2b[s] = H.W2[l31 * 64 + 32 * h + s];
+  float w2c[16][2];         // B of (3): W2[u=16h+s][k=ct*32+l31]
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    w2c[s][0] = H.W2[(16 * h + s) * 64 + l31];
+    w2c[s][1] = H.W2[(16 * h + s) * 64 + 32 + l31];
+  }
+  const float b2v = H.b2[l31], w3v = H.W3[l31];
+
+  f32x16 accW2[2], accB[LT][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    accW2[0][i] = 0.f; accW2[1][i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < LT; ++t) { accB[t][0][i] = 0.f; accB[t][1][i] = 0.f; }
+  }
+  float w3acc = 0.f, b2acc = 0.f, b3acc = 0.f;
+
+  const int64_t n_tiles = (n + TP - 1) / TP;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid, n_waves = (int64_t)gridDim.x * 4;
+  for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
+    // ---- (a) pair metadata: lane l31 of half 0 owns pair row l31
+    const int64_t k = t * TP + l31;
+    int p_i = -1, l_i = 0;
+    float dout = 0.f;
+    uint64_t pid = 0;
+    if (k < n) {
+      const int pp = pi[k];
+      if (((int)(deg[pp] < thr)) == want_low) {
+        p_i = pp; l_i = li[k];
+        dout = dpred[k];
+        pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
+      }
+    }
+    if (__ballot(p_i >= 0) == 0ull) continue;      // no pair of this tile belongs to this head (wave-uniform)
+    if (h == 0) {
+      PIs[l31] = p_i; LIs[l31] = l_i; DOs[l31] = dout;
+      PLo[l31] = (unsigned)pid; PHi[l31] = (unsigned)(pid >> 32);
+      b3acc += dout;
+    }
+    // ---- (b) h1[pair=l31][k=32h+s]: gather-add, relu, dropout; kept in registers AND written to LDS
+    float h1a[32];
+    {
+      const float* ap = H.A + (size_t)(p_i >= 0 ? p_i : 0) * 64 + 32 * h;
+      const float* bp = H.B + (size_t)l_i * 64 + 32 * h;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + q * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + q * 4);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float x = fmaxf(a[j] + b[j], 0.f);
+          if (drop_p > 0.f) x = mmg_keep(seed, SITE_H1, pid * 64ull + (32 * h + q * 4 + j), drop_p) ? x * inv_keep : 0.f;
+          v[j] = x;
+          h1a[q * 4 + j] = x;
+        }
+        *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
+      }
+    }
+    // ---- (1) H2pre = H1 . W2^T
+    f32x16 acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[s], w2b[s], acc1, 0, 0, 0);
+    // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
+    float d2c[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = crow(r, h);
+      const float pre = acc1[r] + b2v;
+      float m = pre > 0.f ? 1.f : 0.f;
+      float post = fmaxf(pre, 0.f);
+      if (drop_p > 0.f) {
+        const uint64_t pd = ((uint64_t)PHi[row] << 32) | PLo[row];
+        const bool kp = mmg_keep(seed, SITE_H2, pd * 32ull + l31, drop_p);
+        m = kp ? m * inv_keep : 0.f;
+        post = kp ? post * inv_keep : 0.f;
+      }
+      const float dr = DOs[row];
+      const float d2 = dr * w3v * m;
+      d2c[r] = d2;
+      w3acc = fmaf(dr, post, w3acc);
+      b2acc += d2;
+      D2s[row * LDD + l31] = d2;
+    }
+    // ---- H1 in the column layout: h1c[s][ct] = H1[pair crow(s,h)][ct*32 + l31]
+    float h1c[16][2];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      h1c[s][0] = H1s[crow(s, h) * LDH + l31];
+      h1c[s][1] = H1s[crow(s, h) * LDH + 32 + l31];
+    }
+    // ---- (2) dW2[u,k] += D2[pair,u] * H1[pair,k]   (A = d2c: already lane=u, step s = pair crow(s,h))
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      accW2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2c[s], h1c[s][0], accW2[0], 0, 0, 0);
+      accW2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2c[s], h1c[s][1], accW2[1], 0, 0, 0);
+    }
+    // ---- (3) dH1[pair,k] = D2[pair,:] . W2[:,k]     (A = D2[pair=l31][u=16h+s] from the LDS tile)
+    float d2a[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(D2s + l31 * LDD + 16 * h + q * 4);
+      d2a[q * 4 + 0] = v[0]; d2a[q * 4 + 1] = v[1]; d2a[q * 4 + 2] = v[2]; d2a[q * 4 + 3] = v[3];
+    }
+    f32x16 accH[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { accH[0][i] = 0.f; accH[1][i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      accH[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s], w2c[s][0], accH[0], 0, 0, 0);
+      accH[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s], w2c[s][1], accH[1], 0, 0, 0);
+    }
+    // through dropout+relu of layer 1 (h1 > 0 <=> kept and positive); C layout: lane = column, reg = pair row
+    float dh[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dh[r][0] = h1c[r][0] > 0.f ? accH[0][r] * inv_keep : 0.f;
+      dh[r][1] = h1c[r][1] > 0.f ? accH[1][r] * inv_keep : 0.f;
+    }
+    // ---- (4) dB[lab,k] += onehot(li[pair])[lab] * dH1[pair,k]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int lab = LIs[crow(s, h)];
+#pragma unroll
+      for (int lt = 0; lt < LT; ++lt) {
+        const float a = (lab == lt * 32 + l31) ? 1.f : 0.f;
+        accB[lt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dh[s][0], accB[lt][0], 0, 0, 0);
+        accB[lt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dh[s][1], accB[lt][1], 0, 0, 0);
+      }
+    }
+    // ---- dA[pi] += dH1: tile to LDS (aliases H1s: all H1 reads are done), then run-length flush
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      H1s[crow(r, h) * LDH + l31] = dh[r][0];
+      H1s[crow(r, h) * LDH + 32 + l31] = dh[r][1];
+    }
+    {
+      float run = 0.f;
+      int cur = -1;
+      for (int q = 0; q < TP; ++q) {
+        const int pp = PIs[q];
+        if (pp < 0) continue;
+        const float v = H1s[q * LDH + lane];
+        if (pp != cur) {
+          if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
+          cur = pp; run = 0.f;
+        }
+        run += v;
+      }
+      if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
+    }
+  }
+  // ---- final flush of the per-wave accumulators
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int u = crow(r, h);
+    atomicAdd(Gd.dW2 + u * 64 + l31, accW2[0][r]);
+    atomicAdd(Gd.dW2 + u * 64 + 32 + l31, accW2[1][r]);
+#pragma unroll
+    for (int lt = 0; lt < LT; ++lt) {
+      const int lab = lt * 32 + u;
+      if (lab < n_labs) {
+        atomicAdd(Gd.dB + (size_t)lab * 64 + l31, accB[lt][0][r]);
+        atomicAdd(Gd.dB + (size_t)lab * 64 + 32 + l31, accB[lt][1][r]);
+      }
+    }
+  }
+  w3acc += __shfl_xor(w3acc, 32, 64);
+  b2acc += __shfl_xor(b2acc, 32, 64);
+  b3acc = wave_sum(b3acc);
+  if (lane < 32) { atomicAdd(Gd.dW3 + lane, w3acc); atomicAdd(Gd.db2 + lane, b2acc); }
+  if (lane == 0) atomicAdd(Gd.db3, b3acc);
+}
+
 inline unsigned pair_grid(int64_t n) {
   int64_t t = (n + PT - 1) / PT;
   if (t > 1024) t = 1024;
@@ -263,18 +478,32 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
   MMG_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pair_head_bwd: drop_p out of range");
   HeadDev H{head->A, head->B, head->W2, head->b2, head->W3, head->b3};
   HeadGradDev G{grad->dA, grad->dB, grad->dW2, grad->db2, grad->dW3, grad->db3};
-  size_t lds = BWD_LDS_FIXED;
-  int lds_db = 0;
-  if (lds + (size_t)n_labs * 64 * 4 <= BWD_LDS_MAX) { lds += (size_t)n_labs * 64 * 4; lds_db = 1; }
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipFuncSetAttribute((const void*)k_pair_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_MAX);
-    attr = BWD_LDS_MAX;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_labs <= 128) {
+    // MFMA path: one wave per 32-pair tile, 4 waves per workgroup, persistent grid
+    int64_t g = ((n_pairs + TP - 1) / TP + 3) / 4;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+#define MMG_LAUNCH_PBWD(LT_)                                                                                          \
+  hipLaunchKernelGGL((k_pair_bwd_mfma<LT_>), dim3((unsigned)g), dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, \
+                     want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, pair_id, dpred)
+    if (n_labs <= 64) MMG_LAUNCH_PBWD(2);
+    else MMG_LAUNCH_PBWD(4);
+#undef MMG_LAUNCH_PBWD
+  } else {
+    size_t lds = BWD_LDS_FIXED;
+    int lds_db = 0;
+    if (lds + (size_t)n_labs * 64 * 4 <= BWD_LDS_MAX) { lds += (size_t)n_labs * 64 * 4; lds_db = 1; }
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)k_pair_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_MAX);
+      attr = true;
+    }
+    int64_t g = (n_pairs + PT - 1) / PT;
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(k_pair_bwd, dim3((unsigned)g), dim3(PT), lds, st, H, G, pi, li, deg, degree_threshold,
+                       want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, pair_id, dpred);
   }
-  int64_t g = (n_pairs + PT - 1) / PT;
-  if (g > 512) g = 512;
-  hipLaunchKernelGGL(k_pair_bwd, dim3((unsigned)g), dim3(PT), lds, (hipStream_t)stream, H, G, pi, li, deg,
-                     degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, pair_id, dpred);
   MMG_CHECK_LAUNCH("pair_head_bwd");
   return MMG_OK;
 }

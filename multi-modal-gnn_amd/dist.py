@@ -1,0 +1,149 @@
+"""Patient-axis sharding over the GPUs of one node (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The reference is single-process and full-batch; the faithful decomposition of its ONE
+graph is by contiguous patient ranges: every relation has exactly one patient endpoint
+(src/graph_build.py:128-141), so no patient<->patient halo exists.  Each rank owns its patients'
+embedding rows, their CSR rows of every relation and the supervision pairs of those patients; vocab
+tables and all weights are replicated.  Exchanges per step (all SUM all-reduces, all tiny, latency-bound):
+  * per conv layer forward : the [sum V_t, D] patient->vocab partial sums        (1 message)
+  * per conv layer backward: the [sum V_t, D] grads of the transformed vocab tables (1 message)
+  * per patient-axis BatchNorm: [2, D] fp64 statistics, forward and backward (Sync-BN semantics,
+    required for parity with the single-device reference)
+  * heads backward: [V_lab, 64] lab-side grads (+ the [64, D] first-layer weight grad)
+  * end of backward: one flat bucket with every per-shard partial parameter gradient.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .data import GraphPlan, HeteroGraph, ROW_TYPE
+
+
+class ShardComm:
+    """Collectives used by the sharded step.  ``n_calls``/``n_bytes`` are counted for the tests/bench."""
+
+    def __init__(self, group=None, pair_ids: Optional[torch.Tensor] = None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.pair_ids = pair_ids          # global pair ids of this rank's pairs (keys the head dropout RNG)
+        self.n_calls = 0
+        self.n_bytes = 0
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        self.n_calls += 1
+        self.n_bytes += t.numel() * t.element_size()
+        return t
+
+    def all_reduce_list(self, ts: Sequence[torch.Tensor]):
+        """One bucket for many small tensors (the end-of-backward gradient exchange)."""
+        ts = [t for t in ts if t is not None]
+        if not ts:
+            return
+        flat = torch.cat([t.reshape(-1).float() for t in ts])
+        self.all_reduce(flat)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+def partition_rows(row_weights: torch.Tensor, world: int) -> List[int]:
+    """Contiguous row ranges balanced by weight (nnz): returns world+1 boundaries.
+    boundaries[r] = first row of rank r; greedy on the prefix sum, every rank gets >= 1 row when possible."""
+    n = int(row_weights.numel())
+    if world <= 0:
+        raise ValueError("world must be positive")
+    csum = torch.cumsum(row_weights.to(torch.float64).cpu() + 1e-9, 0)
+    total = float(csum[-1]) if n else 0.0
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        b = int(torch.searchsorted(csum, torch.tensor(target, dtype=torch.float64)).item()) if n else 0
+        b = max(b, bounds[-1] + (1 if bounds[-1] < n else 0))
+        b = min(b, n - (world - r) if n >= world else n)
+        b = max(b, bounds[-1])
+        bounds.append(b)
+    bounds.append(n)
+    return bounds
+
+
+def patient_weights(data) -> torch.Tensor:
+    """nnz per patient over all relations (the partition's balance criterion)."""
+    P = int(data[ROW_TYPE].num_nodes)
+    w = None
+    for et in data.edge_types:
+        s, _, d = et
+        ei = data[et].edge_index
+        idx = ei[0] if s == ROW_TYPE else ei[1]
+        c = torch.bincount(idx, minlength=P)
+        w = c if w is None else w + c
+    return w if w is not None else torch.zeros(P, dtype=torch.long)
+
+
+def shard_graph(data, lo: int, hi: int) -> HeteroGraph:
+    """The sub-graph of patients [lo, hi) with LOCAL patient indices; vocab node sets unchanged.
+    Edge order inside the shard keeps the original relative order."""
+    g = HeteroGraph()
+    for t in data.node_types:
+        g[t].num_nodes = (hi - lo) if t == ROW_TYPE else int(data[t].num_nodes)
+    for et in data.edge_types:
+        s, _, d = et
+        ei = data[et].edge_index
+        prow = 0 if s == ROW_TYPE else 1
+        keep = (ei[prow] >= lo) & (ei[prow] < hi)
+        sub = ei[:, keep].clone()
+        sub[prow] -= lo
+        g[et].edge_index = sub.contiguous()
+        st = data[et]
+        if "edge_attr" in st:
+            g[et].edge_attr = st.edge_attr[keep]
+    g.row_range = (lo, hi)
+    return g
+
+
+def shard_pairs(pi: torch.Tensor, li: torch.Tensor, lo: int, hi: int):
+    """Pairs of patients [lo,hi): (local pi, li, global pair ids)."""
+    keep = (pi >= lo) & (pi < hi)
+    ids = torch.nonzero(keep).flatten()
+    return (pi[keep] - lo).contiguous(), li[keep].contiguous(), ids
+
+
+def shard_plan(plan: GraphPlan, comm: ShardComm, row_offset: int, n_rows_global: int) -> GraphPlan:
+    """Turn a rank-local plan into a shard of the global graph: vocab in-degrees become global
+    (one all-reduce of the [sum V_t] counts at setup), rows get their global offset."""
+    from . import ops  # noqa: F401
+    done = set()
+    for et, rel in plan.rels.items():
+        if id(rel.col_cnt) in done:
+            continue
+        done.add(id(rel.col_cnt))
+        cnt = rel.col_cnt.to(torch.int64)
+        comm.all_reduce(cnt)
+        inv = 1.0 / cnt.clamp(min=1).to(torch.float32)
+        rel.inv_col.copy_(inv)
+    plan.row_offset = int(row_offset)
+    plan.n_rows_global = int(n_rows_global)
+    return plan
+
+
+def shard_model(model, comm: ShardComm):
+    model._comm = comm
+    return model
+
+
+def shard_state(sd: Dict[str, torch.Tensor], lo: int, hi: int) -> Dict[str, torch.Tensor]:
+    """Slice the patient embedding rows of a global state_dict for one shard."""
+    out = dict(sd)
+    k = f"embeddings.{ROW_TYPE}.weight"
+    if k in out:
+        out[k] = out[k][lo:hi].clone()
+    return out

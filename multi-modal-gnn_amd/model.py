@@ -478,15 +478,16 @@ class _Run:
             rec["Wsum"] = Wsum
         # ---- dst = vocab type v: y_v = mean_scatter(x_P) W_l^T + b + x_v W_r^T   (summed over relations into v)
         if rout:
-            aggs = []
-            rels = []
+            aggs, rels, off = [], [], 0
+            buf = torch.empty(sum(r.n_cols for r in rout), D, device=self.dev)   # one buffer = one all-reduce
             for r in rout:
-                agg = torch.empty(r.n_cols, D, device=self.dev)
+                agg = buf[off:off + r.n_cols]
+                off += r.n_cols
                 rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg))
                 aggs.append(agg)
             ops.scatter_rows(rels, P, D, xP)
+            self.allreduce(buf)                          # partial sums over patient shards
             for r, agg in zip(rout, aggs):
-                self.allreduce(agg)                      # partial sums over patient shards
                 nme = self.conv_name(l, r.edge_type)
                 first = r.other not in y
                 y[r.other] = ops.linear_fwd(agg, self.W(nme + ".lin_l.weight"), self.W(nme + ".lin_l.bias"),
@@ -536,15 +537,17 @@ class _Run:
             dWsum = ops.linear_wgrad(dyP, xP)
             dbsum = ops.col_reduce2(dyP)[0].float()
             add(ROW_TYPE, ops.linear_fwd(dyP, rec["Wsum"].t().contiguous()))
-            rels, dTs = [], []
+            rels, dTs, off = [], [], 0
+            buf = torch.empty(sum(r.n_cols for r in rec["rin"]), D, device=self.dev)
             for r in rec["rin"]:
-                dT = torch.empty(r.n_cols, D, device=self.dev)
+                dT = buf[off:off + r.n_cols]
+                off += r.n_cols
                 rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=dT))
                 dTs.append(dT)
             ops.scatter_rows(rels, P, D, dyP)
+            self.allreduce(buf)
             for r, dT in zip(rec["rin"], dTs):
                 nme = self.conv_name(l, r.edge_type)
-                self.allreduce(dT)
                 self.acc(nme + ".lin_r.weight", dWsum, partial=True)
                 self.acc(nme + ".lin_l.bias", dbsum, partial=True)
                 self.acc(nme + ".lin_l.weight", ops.linear_wgrad(dT, x[r.other]))

@@ -36,6 +36,51 @@ def _p(t: Optional[torch.Tensor], dtype=torch.float32, name="tensor"):
     return C.c_void_p(t.data_ptr())
 
 
+# ------------------------------------------------------------------------------------------
+# optional per-op timing (bench.py): HIP events recorded on the stream the kernels are launched on
+class OpProfiler:
+    """Collects (op, ms, algorithmic bytes, flops) per call; `only` restricts it to some op names."""
+
+    def __init__(self, only=None):
+        self.only = set(only) if only else None
+        self.rows = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, nbytes, flops in self.rows:
+            d = out.setdefault(name, dict(calls=0, ms=0.0, bytes=0, flops=0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nbytes
+            d["flops"] += flops
+        return out
+
+
+_PROF: Optional[OpProfiler] = None
+
+
+def set_profiler(p: Optional[OpProfiler]):
+    global _PROF
+    _PROF = p
+
+
+def _pb(name):
+    if _PROF is None or (_PROF.only is not None and name not in _PROF.only):
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _pe(tok, name, nbytes=0, flops=0):
+    if tok is None:
+        return
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    _PROF.rows.append((name, tok, e, int(nbytes), int(flops)))
+
+
 _WS = {}
 
 
@@ -118,6 +163,19 @@ class Rel:
     out: Optional[torch.Tensor] = None
 
 
+def _agg_bytes(rels, n_rows, D, accumulate):
+    """Algorithmic (compulsory) bytes of one fused aggregate launch: every index once, every distinct
+    feature row once (the patient tensor is counted ONCE for the fused relations)."""
+    b = 4 * D * n_rows * (2 if accumulate else 1)
+    for r in rels:
+        b += 4 * r.col.numel() + 4 * (n_rows + 1) + 4 * D * r.n_cols
+        if r.rowscale is not None:
+            b += 4 * n_rows
+        if r.colscale is not None:
+            b += 4 * r.n_cols
+    return b
+
+
 def _rels(rels: Sequence[Rel], D: int, need_table=False, need_out=False):
     if not 1 <= len(rels) <= _lib.MMG_MAX_REL:
         raise ValueError(f"1..{_lib.MMG_MAX_REL} relations per launch")
@@ -140,7 +198,9 @@ def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, acc
         if r.rowptr.numel() != n_rows + 1:
             raise ValueError("gather_rows: rowptr length")
     arr = _rels(rels, D, need_table=True)
+    _tok = _pb("gather_rows")
     check(lib.mmg_gather_rows(arr, len(rels), n_rows, D, _p(out), int(accumulate), _stream()), "mmg_gather_rows")
+    _pe(_tok, "gather_rows", _agg_bytes(rels, n_rows, D, accumulate), 0)
     return out
 
 
@@ -155,8 +215,10 @@ def scatter_rows(rels: Sequence[Rel], n_rows: int, D: int, x: torch.Tensor):
     arr = _rels(rels, D, need_out=True)
     nb = lib.mmg_scatter_rows_ws_bytes(arr, len(rels), n_rows, D)
     ws = workspace(nb, x.device)
+    _tok = _pb("scatter_rows")
     check(lib.mmg_scatter_rows(arr, len(rels), n_rows, D, _p(x), _p(ws, torch.uint8), ws.numel(), _stream()),
           "mmg_scatter_rows")
+    _pe(_tok, "scatter_rows", _agg_bytes(rels, n_rows, D, False), 0)
 
 
 # ------------------------------------------------------------------------------------------ dense
@@ -174,8 +236,10 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (M, N):
         raise ValueError("linear_fwd: out shape")
+    _tok = _pb("linear_fwd")
     check(lib.mmg_linear_fwd(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"), _p(out, name="out"),
                              M, N, K, int(accumulate), _stream()), "mmg_linear_fwd")
+    _pe(_tok, "linear_fwd", 4 * (M * K + N * K + M * N * (2 if accumulate else 1)), 2 * M * N * K)
     return out
 
 
@@ -192,8 +256,10 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, o
         accumulate = False
     nb = lib.mmg_linear_wgrad_ws_bytes(M, N, K)
     ws = workspace(nb, x.device)
+    _tok = _pb("linear_wgrad")
     check(lib.mmg_linear_wgrad(_p(dy), _p(x), _pro(pro), _p(out), M, N, K, int(accumulate), _p(ws, torch.uint8),
                                ws.numel(), _stream()), "mmg_linear_wgrad")
+    _pe(_tok, "linear_wgrad", 4 * (M * N + M * K + N * K), 2 * M * N * K)
     return out
 
 
@@ -204,8 +270,10 @@ def col_reduce2(a: torch.Tensor, b: Optional[torch.Tensor] = None):
     out = torch.empty(2, N, dtype=torch.float64, device=a.device)
     nb = lib.mmg_col_reduce2_ws_bytes(M, N)
     ws = workspace(nb, a.device)
+    _tok = _pb("col_reduce2")
     check(lib.mmg_col_reduce2(_p(a), _p(b), _p(out, torch.float64), M, N, _p(ws, torch.uint8), ws.numel(), _stream()),
           "mmg_col_reduce2")
+    _pe(_tok, "col_reduce2", 4 * M * N * (2 if b is not None else 1), 0)
     return out
 
 
@@ -235,7 +303,9 @@ def affine_act_drop(y: torch.Tensor, pro: Pro, out: Optional[torch.Tensor] = Non
     lib = _lib.load()
     M, N = y.shape
     out = torch.empty_like(y) if out is None else out
+    _tok = _pb("affine_act_drop")
     check(lib.mmg_affine_act_drop(_p(y), _pro(pro), _p(out), M, N, _stream()), "mmg_affine_act_drop")
+    _pe(_tok, "affine_act_drop", 8 * M * N, 0)
     return out
 
 
@@ -245,8 +315,10 @@ def bn_bwd_stats(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold):
     out = torch.empty(2, N, dtype=torch.float64, device=y.device)
     nb = lib.mmg_col_reduce2_ws_bytes(M, N)
     ws = workspace(nb, y.device)
+    _tok = _pb("bn_bwd_stats")
     check(lib.mmg_bn_bwd_stats(_p(g), _p(y), _pro(pro), _p(fold.mean), _p(fold.rstd), _p(out, torch.float64), M, N,
                                _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_bn_bwd_stats")
+    _pe(_tok, "bn_bwd_stats", 8 * M * N, 0)
     return out
 
 
@@ -255,9 +327,11 @@ def bn_bwd_apply(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFo
     lib = _lib.load()
     M, N = y.shape
     out = torch.empty_like(y) if out is None else out
+    _tok = _pb("bn_bwd_apply")
     check(lib.mmg_bn_bwd_apply(_p(g), _p(y), _pro(pro), _p(fold.mean) if fold else None,
                                _p(fold.rstd) if fold else None, _p(c0), _p(c1), _p(out), M, N, _stream()),
           "mmg_bn_bwd_apply")
+    _pe(_tok, "bn_bwd_apply", 12 * M * N, 0)
     return out
 
 
@@ -266,7 +340,9 @@ def l2norm_fwd(z: torch.Tensor):
     M, N = z.shape
     out = torch.empty_like(z)
     rn = torch.empty(M, dtype=torch.float32, device=z.device)
+    _tok = _pb("l2norm_fwd")
     check(lib.mmg_l2norm_fwd(_p(z), _p(out), _p(rn), M, N, L2_EPS, _stream()), "mmg_l2norm_fwd")
+    _pe(_tok, "l2norm_fwd", 8 * M * N, 0)
     return out, rn
 
 
@@ -274,7 +350,9 @@ def l2norm_bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor):
     lib = _lib.load()
     M, N = out.shape
     dz = torch.empty_like(out)
+    _tok = _pb("l2norm_bwd")
     check(lib.mmg_l2norm_bwd(_p(g), _p(out), _p(rn), _p(dz), M, N, L2_EPS, _stream()), "mmg_l2norm_bwd")
+    _pe(_tok, "l2norm_bwd", 12 * M * N, 0)
     return dz
 
 
@@ -306,9 +384,11 @@ def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, s
     lib = _lib.load()
     n = pi.numel()
     h = head.c()
+    _tok = _pb("pair_head_fwd")
     check(lib.mmg_pair_head_fwd(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
                                 int(want_low), n, float(p), seed & 0xFFFFFFFFFFFFFFFF, _p(pair_id, torch.int64),
                                 _p(pred), _stream()), "mmg_pair_head_fwd")
+    _pe(_tok, "pair_head_fwd", n * 12 + 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (64 * 32 + 32 + 64))
 
 
 def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool, n_labs: int, p: float, seed: int,
@@ -318,6 +398,8 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
     n = pi.numel()
     h = head.c()
     g = HeadGradT(_p(grads.A), _p(grads.B), _p(grads.W2), _p(grads.b2), _p(grads.W3), _p(grads.b3))
+    _tok = _pb("pair_head_bwd")
     check(lib.mmg_pair_head_bwd(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32),
                                 thr, int(want_low), n, n_labs, float(p), seed & 0xFFFFFFFFFFFFFFFF,
                                 _p(pair_id, torch.int64), _p(dpred), _stream()), "mmg_pair_head_bwd")
+    _pe(_tok, "pair_head_bwd", n * 12 + 2 * 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (4 * 64 * 32))

@@ -1,0 +1,229 @@
+"""Caller side of the hot path: the counterparts of the reference's ``src/train.py`` pieces that drive
+``predict_lab_values`` (EdgeMasker :37-176, Trainer :183-561).  Same class / method names, argument
+meaning and error behaviour; the graph and the model live on the GPU.
+
+Differences that are switches, not silent fixes:
+  * ``train_embeddings=False`` (default) reproduces the reference: the optimizer is built from
+    ``model.parameters()`` BEFORE the lazy embeddings exist, so they are never updated;
+  * the per-epoch supervision mask draws from ``mask_generator`` when given, else from the wall-clock
+    seed exactly as train.py:156 does (CPU RNG, then moved to the device);
+  * ``ReduceLROnPlateau`` is built without the ``verbose`` kwarg torch >= 2.7 removed.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import time
+from pathlib import Path
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from .model import build_model, compute_regression_loss
+
+LAB_EDGE = ("patient", "has_lab", "lab")
+
+
+class EdgeMasker:
+    """train.py:37-176 -- edge-level 70/15/15 split (seed 42) + per-epoch supervision mask."""
+
+    def __init__(self, data, train_split: float = 0.7, val_split: float = 0.15, test_split: float = 0.15,
+                 mask_fraction: float = 0.2, seed: int = 42, mask_generator: Optional[torch.Generator] = None):
+        self.data = data
+        self.train_split, self.val_split, self.test_split = train_split, val_split, test_split
+        self.mask_fraction = mask_fraction
+        self.seed = seed
+        self.mask_generator = mask_generator
+        assert abs(train_split + val_split + test_split - 1.0) < 1e-6, "Splits must sum to 1.0"
+        self.edge_type = LAB_EDGE
+        self.edge_index = data[self.edge_type].edge_index
+        self.edge_attr = data[self.edge_type].edge_attr
+        self.num_edges = self.edge_index.shape[1]
+        self.train_mask, self.val_mask, self.test_mask = self._create_splits()
+        self._cache = {}
+        logging.info("Edge splits created:")
+        logging.info(f"  Train: {self.train_mask.sum()} edges ({100 * train_split:.1f}%)")
+        logging.info(f"  Val: {self.val_mask.sum()} edges ({100 * val_split:.1f}%)")
+        logging.info(f"  Test: {self.test_mask.sum()} edges ({100 * test_split:.1f}%)")
+
+    def _create_splits(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        # CPU generator on purpose: bit-identical to train.py:110-127 for the same seed
+        torch.manual_seed(self.seed)
+        np.random.seed(self.seed)
+        perm = torch.randperm(self.num_edges)
+        n_train = int(self.train_split * self.num_edges)
+        n_val = int(self.val_split * self.num_edges)
+        masks = [torch.zeros(self.num_edges, dtype=torch.bool) for _ in range(3)]
+        masks[0][perm[:n_train]] = True
+        masks[1][perm[n_train:n_train + n_val]] = True
+        masks[2][perm[n_train + n_val:]] = True
+        dev = self.edge_index.device
+        return tuple(m.to(dev) for m in masks)
+
+    def get_masked_data(self, split: str = "train"):
+        if split == "train":
+            mask = self.train_mask
+            n = int(mask.sum())
+            if self.mask_fraction > 0:
+                if self.mask_generator is None:
+                    torch.manual_seed(int(time.time()))                          # train.py:156
+                    supervision_mask = torch.rand(n) < self.mask_fraction
+                else:
+                    supervision_mask = torch.rand(n, generator=self.mask_generator) < self.mask_fraction
+            else:
+                supervision_mask = torch.ones(n, dtype=torch.bool)
+        elif split in ("val", "test"):
+            mask = self.val_mask if split == "val" else self.test_mask
+            supervision_mask = torch.ones(int(mask.sum()), dtype=torch.bool)
+        else:
+            raise ValueError(f"Unknown split: {split}")
+        # the split is static: keep ONE tensor object per split so the model's pair cache (sorted pairs) hits
+        if split not in self._cache:
+            self._cache[split] = (self.edge_index[:, mask].contiguous(), self.edge_attr[mask].squeeze(-1).contiguous())
+        edge_indices, edge_values = self._cache[split]
+        return edge_indices, edge_values, mask, supervision_mask.to(edge_indices.device)
+
+
+class Trainer:
+    """train.py:183-561."""
+
+    def __init__(self, model: nn.Module, data, masker: EdgeMasker, config: Dict, device: torch.device,
+                 train_embeddings: bool = False):
+        self.model = model.to(device)
+        self.data = data.to(device)
+        self.masker = masker
+        self.config = config
+        self.device = device
+        tc = config["train"]
+        if train_embeddings and len(self.model.embeddings) == 0:
+            self.model._init_embeddings(self.data)          # switch: make the tables visible to the optimizer
+        self.optimizer = self._build_optimizer(tc["optimizer"])
+        self.scheduler = self._build_scheduler(tc.get("lr_scheduler", {}))
+        self.loss_fn = tc["loss"]
+        self.epochs = tc["epochs"]
+        self.early_stopping_patience = tc["early_stopping_patience"]
+        self.best_val_loss = float("inf")
+        self.patience_counter = 0
+        self.train_losses, self.val_losses = [], []
+        self.lab_weights = self._compute_lab_weights()
+        self._pairs = {}
+
+    def _build_optimizer(self, oc: Dict) -> optim.Optimizer:
+        kind = oc.get("type", "adam").lower()
+        if kind == "adam":
+            return optim.Adam(self.model.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"])
+        if kind == "sgd":
+            return optim.SGD(self.model.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"],
+                             momentum=oc.get("momentum", 0.9))
+        raise ValueError(f"Unknown optimizer: {kind}")
+
+    def _build_scheduler(self, sc: Dict):
+        if not sc.get("enabled", False):
+            return None
+        kind = sc.get("type", "reduce_on_plateau")
+        if kind == "reduce_on_plateau":
+            return optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=sc.get("factor", 0.5),
+                                                        patience=sc.get("patience", 10))
+        if kind == "step":
+            return optim.lr_scheduler.StepLR(self.optimizer, step_size=sc.get("step_size", 30), gamma=sc.get("gamma", 0.1))
+        raise ValueError(f"Unknown scheduler: {kind}")
+
+    def _compute_lab_weights(self) -> torch.Tensor:
+        """train.py:295-330: w_l = L * (1/(var_l + 1e-6)) / sum, unbiased var over TRAIN edges (1.0 if <= 1 sample)."""
+        edge_indices, edge_values, _, _ = self.masker.get_masked_data("train")
+        lab = edge_indices[1]
+        L = int(self.data["lab"].num_nodes)
+        v = edge_values.double()
+        cnt = torch.zeros(L, dtype=torch.float64, device=v.device).index_add_(0, lab, torch.ones_like(v))
+        s1 = torch.zeros(L, dtype=torch.float64, device=v.device).index_add_(0, lab, v)
+        mean = s1 / cnt.clamp(min=1)
+        s2 = torch.zeros(L, dtype=torch.float64, device=v.device).index_add_(0, lab, (v - mean[lab]) ** 2)
+        var = torch.where(cnt > 1, s2 / (cnt - 1).clamp(min=1), torch.ones_like(s2))
+        w = 1.0 / (var + 1e-6)
+        w = w * L / w.sum()
+        return w.float()
+
+    def _split_pairs(self, split):
+        edge_indices, edge_values, _, sup = self.masker.get_masked_data(split)
+        if split not in self._pairs:          # keep the SAME tensor objects across epochs (pair-cache key)
+            self._pairs[split] = (edge_indices[0].contiguous(), edge_indices[1].contiguous())
+        pi, li = self._pairs[split]
+        return pi, li, edge_values, sup
+
+    def train_epoch(self) -> float:
+        """train.py:332-392."""
+        self.model.train()
+        pi, li, y, sup = self._split_pairs("train")
+        self.optimizer.zero_grad()
+        pred = self.model.predict_lab_values(self.data, pi, li)
+        sp, st, sl = pred[sup], y[sup], li[sup]
+        if self.loss_fn == "mae":
+            per = torch.abs(sp - st)
+        elif self.loss_fn == "mse":
+            per = (sp - st) ** 2
+        else:
+            loss = compute_regression_loss(sp, st, loss_type=self.loss_fn)
+            loss.backward()
+            self.optimizer.step()
+            return loss.item()
+        loss = (per * self.lab_weights[sl]).mean()
+        loss.backward()
+        self.optimizer.step()
+        return loss.item()
+
+    @torch.no_grad()
+    def validate(self, split: str = "val") -> float:
+        """train.py:394-431."""
+        self.model.eval()
+        pi, li, y, _ = self._split_pairs(split)
+        pred = self.model.predict_lab_values(self.data, pi, li)
+        return compute_regression_loss(pred, y, loss_type=self.loss_fn).item()
+
+    def train(self, output_dir: Path) -> Dict:
+        """train.py:433-544 (same files: best_model.pt, checkpoint_epoch_N.pt, training_history.json)."""
+        output_dir = Path(output_dir)
+        output_dir.mkdir(parents=True, exist_ok=True)
+        lc = self.config.get("logging", {})
+        history = {"train_loss": [], "val_loss": [], "learning_rates": [], "epoch_times": []}
+        for epoch in range(1, self.epochs + 1):
+            t0 = time.time()
+            tl = self.train_epoch()
+            vl = self.validate("val")
+            history["train_loss"].append(tl)
+            history["val_loss"].append(vl)
+            history["learning_rates"].append(self.optimizer.param_groups[0]["lr"])
+            history["epoch_times"].append(time.time() - t0)
+            if self.scheduler is not None:
+                if isinstance(self.scheduler, optim.lr_scheduler.ReduceLROnPlateau):
+                    self.scheduler.step(vl)
+                else:
+                    self.scheduler.step()
+            if vl < self.best_val_loss:
+                self.best_val_loss = vl
+                self.patience_counter = 0
+                if lc.get("save_checkpoints", True):
+                    self._save(output_dir / "best_model.pt", epoch, vl)
+            else:
+                self.patience_counter += 1
+            if lc.get("save_checkpoints", True) and epoch % lc.get("checkpoint_interval", 10) == 0:
+                self._save(output_dir / f"checkpoint_epoch_{epoch}.pt", epoch, vl)
+            if self.patience_counter >= self.early_stopping_patience:
+                logging.info(f"Early stopping at epoch {epoch}")
+                break
+        with open(output_dir / "training_history.json", "w") as f:
+            json.dump(history, f, indent=2)
+        self.train_losses, self.val_losses = history["train_loss"], history["val_loss"]
+        return history
+
+    def _save(self, path, epoch, val_loss):
+        torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(),
+                    "optimizer_state_dict": self.optimizer.state_dict(), "val_loss": val_loss,
+                    "config": self.config}, path)                                   # train.py:501-509
+
+    def load_best_model(self, output_dir: Path):
+        ck = torch.load(Path(output_dir) / "best_model.pt", map_location=self.device, weights_only=False)
+        self.model.load_state_dict(ck["model_state_dict"])
+        logging.info(f"Loaded best model from epoch {ck['epoch']} (val_loss: {ck['val_loss']:.4f})")
