@@ -11,6 +11,8 @@
 
 namespace {
 
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
 struct RelDev {
   const int32_t* rowptr; const int32_t* col; const float* rowscale; const float* colscale;
   const float* table; float* out; int32_t n_cols; int32_t acc_off;   // acc_off: first accumulator row
@@ -75,6 +77,113 @@ __global__ __launch_bounds__(256) void k_gather(RelPack rp, int64_t n_rows, floa
   for (int v = 0; v < VEC; ++v) dst[v] = accumulate ? dst[v] + tot[v] : tot[v];
 }
 
+// gather with the vocab tables resident in LDS (they are tiny: 264 x 128 x 4 B = 135 KB at the eICU
+// shape).  Every edge then costs one conflict-free ds_read of the row slice instead of an L2 round trip
+// (the L2-served version above tops out at the L2 gather rate, ~16 TB/s of row reads for 0.8 TB/s of
+// algorithmic traffic).  1024 threads (16 waves) per CU hide the rowptr -> col -> LDS dependency chain.
+constexpr int GL_THREADS = 1024;
+constexpr size_t GL_LDS_BUDGET = 150 * 1024;
+
+template <int VECC>   // floats per lane inside the column chunk: DC = 64*VECC
+__global__ __launch_bounds__(GL_THREADS) void k_gather_lds(RelPack rp, int64_t n_rows, int64_t rows_per_blk, int D,
+                                                           float* __restrict__ out, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];
+  constexpr int DC = VECC * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = GL_THREADS / 64;
+  const int d0 = blockIdx.y * DC;
+  // ---- stage the table slices [acc_off + c][DC] (pre-multiplied by colscale)
+  for (int r = 0; r < rp.n; ++r) {
+    const RelDev& R = rp.r[r];
+    const int n4 = R.n_cols * (DC / 4);
+    for (int i = tid; i < n4; i += GL_THREADS) {
+      const int c = i / (DC / 4), q = i - c * (DC / 4);
+      f32x4s v = *reinterpret_cast<const f32x4s*>(R.table + (size_t)c * D + d0 + q * 4);
+      if (R.colscale) v *= R.colscale[c];
+      *reinterpret_cast<f32x4s*>(tab + (size_t)(R.acc_off + c) * DC + q * 4) = v;
+    }
+  }
+  __syncthreads();
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_blk, r_end = min(n_rows, r_beg + rows_per_blk);
+  // Software pipeline over this wave's rows (row_i = r_beg + wid + i*nw): the rowptr pair of row i+2 and
+  // the column ids of row i+1 are in flight while row i is reduced out of LDS, so the dependent
+  // rowptr -> col -> LDS chain never stalls the wave.
+  int b0[MMG_MAX_REL], e0[MMG_MAX_REL], b1[MMG_MAX_REL], e1[MMG_MAX_REL], c0[MMG_MAX_REL];
+  auto meta = [&](int64_t row, int* bb, int* ee) {
+    const int64_t rr = row < r_end ? row : (r_end - 1);
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      bb[r] = 0; ee[r] = 0;
+      if (r < rp.n && row < r_end) { bb[r] = rp.r[r].rowptr[rr]; ee[r] = rp.r[r].rowptr[rr + 1]; }
+    }
+  };
+  auto cols = [&](const int* bb, const int* ee, int* cc) {
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      cc[r] = 0;
+      if (r < rp.n && bb[r] + lane < ee[r]) cc[r] = rp.r[r].col[bb[r] + lane];
+    }
+  };
+  int64_t row = r_beg + wid;
+  if (row >= r_end) return;
+  meta(row, b0, e0);
+  meta(row + nw, b1, e1);
+  cols(b0, e0, c0);
+  for (; row < r_end; row += nw) {
+    int b2[MMG_MAX_REL], e2[MMG_MAX_REL], c1[MMG_MAX_REL];
+    meta(row + 2 * nw, b2, e2);
+    cols(b1, e1, c1);
+    float rsv[MMG_MAX_REL];        // issued now, consumed after the LDS reduction of each relation
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) rsv[r] = (r < rp.n && rp.r[r].rowscale) ? rp.r[r].rowscale[row] : 1.f;
+    float prev[VECC];
+    float* dst = out + (size_t)row * D + d0 + lane * VECC;
+#pragma unroll
+    for (int v = 0; v < VECC; ++v) prev[v] = accumulate ? dst[v] : 0.f;
+    float tot[VECC];
+#pragma unroll
+    for (int v = 0; v < VECC; ++v) tot[v] = 0.f;
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      if (r >= rp.n || b0[r] == e0[r]) continue;
+      const RelDev& R = rp.r[r];
+      float acc[VECC];
+#pragma unroll
+      for (int v = 0; v < VECC; ++v) acc[v] = 0.f;
+      const float* tr = tab + (size_t)R.acc_off * DC + lane * VECC;
+      int cidx = c0[r];
+      for (int base = b0[r]; base < e0[r]; base += 64) {
+        const int cnt = min(64, e0[r] - base);
+        if (base != b0[r]) cidx = (lane < cnt) ? R.col[base + lane] : 0;   // rows with > 64 edges (rare)
+        int j = 0;
+        for (; j + 4 <= cnt; j += 4) {
+          float t[4][VECC];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = __builtin_amdgcn_readlane(cidx, j + u);
+#pragma unroll
+            for (int v = 0; v < VECC; ++v) t[u][v] = tr[(size_t)c * DC + v];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < VECC; ++v) acc[v] += t[u][v];
+        }
+        for (; j < cnt; ++j) {
+          const int c = __builtin_amdgcn_readlane(cidx, j);
+#pragma unroll
+          for (int v = 0; v < VECC; ++v) acc[v] += tr[(size_t)c * DC + v];
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VECC; ++v) tot[v] = fmaf(rsv[r], acc[v], tot[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < VECC; ++v) dst[v] = prev[v] + tot[v];
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) { b0[r] = b1[r]; e0[r] = e1[r]; b1[r] = b2[r]; e1[r] = e2[r]; c0[r] = c1[r]; }
+  }
+}
+
 // ------------------------------------------------------------------------------ scatter
 // out[v, :] = sum_rows Ind[row, v] * x[row, :]  is a tall-skinny product  Ind^T [V x P] . x [P x D].
 // LDS float atomics (ds_add_f32) were measured at ~0.3 adds/clk/CU on gfx950 -- 40x off the HBM
@@ -86,7 +195,6 @@ __global__ __launch_bounds__(256) void k_gather(RelPack rp, int64_t n_rows, floa
 // Each workgroup owns a contiguous row chunk and ALL vocab tiles (accumulators stay in registers for
 // the whole chunk), writes one partial slab; k_scatter_reduce sums the slabs in fixed order.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4s __attribute__((ext_vector_type(4)));
 constexpr int SC_ROWS = 32;     // patient rows per LDS stage (= MFMA K extent per stage)
 constexpr int SC_MAX_NT = 16;   // 32-row vocab tiles per launch (512 padded vocab rows)
 
@@ -213,24 +321,23 @@ __global__ __launch_bounds__(256, 2) void k_scatter_mfma(RelPack rp, int64_t n_r
     }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_reduce(RelPack rp, int D, int total_pad, int n_split,
-                                                        const float* __restrict__ slab) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t n = (int64_t)total_pad * D;
-  if (i >= n) return;
-  const int c = (int)(i / D), d = (int)(i - (int64_t)c * D);
-  for (int r = 0; r < rp.n; ++r) {
-    const RelDev& R = rp.r[r];
-    if (c >= R.acc_off && c < R.acc_off + R.n_cols) {
-      float s = 0.f;
-      for (int b = 0; b < n_split; ++b) s += slab[(size_t)b * n + i];
-      const int j = c - R.acc_off;
-      const float cs = R.colscale ? R.colscale[j] : 1.f;
-      R.out[(size_t)j * D + d] = s * cs;
-      return;
+// epilogue of the slab sum: padded accumulator row -> (relation, vocab row), times colscale
+struct EpiScatter {
+  RelPack rp; int D;
+  __device__ void operator()(int64_t i4, mmg_f4 v) const {
+    const int64_t i = i4 * 4;
+    const int c = (int)(i / D), d = (int)(i - (int64_t)c * D);
+    for (int r = 0; r < rp.n; ++r) {
+      const RelDev& R = rp.r[r];
+      if (c >= R.acc_off && c < R.acc_off + R.n_cols) {
+        const int j = c - R.acc_off;
+        const float cs = R.colscale ? R.colscale[j] : 1.f;
+        *reinterpret_cast<mmg_f4*>(R.out + (size_t)j * D + d) = v * cs;
+        return;
+      }
     }
   }
-}
+};
 
 template <int NT>
 void launch_scatter_mfma(const ScatterPlan& p, const RelPack& rp, int64_t n_rows, int D, const float* x, float* slab,
@@ -296,8 +403,33 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
   int rc = pack(rels, n_rel, &rp, true, false);
   if (rc) return rc;
   if (n_rows == 0) return MMG_OK;
-  const unsigned nb = (unsigned)((n_rows + 3) / 4);
   hipStream_t st = (hipStream_t)stream;
+  int total_cols = 0;
+  for (int r = 0; r < n_rel; ++r) total_cols += rels[r].n_cols;
+  // LDS-resident tables when a column chunk of every table fits; else the L2-served kernel
+  int dc = D >= 128 ? 128 : 64;
+  while (dc > 64 && (size_t)total_cols * dc * 4 > GL_LDS_BUDGET) dc >>= 1;
+  if (total_cols > 0 && (size_t)total_cols * dc * 4 <= GL_LDS_BUDGET && n_rows >= 64) {
+    const size_t lds = (size_t)total_cols * dc * 4;
+    const int n_dchunks = D / dc;
+    int64_t nblk = 256 / n_dchunks;
+    if (nblk < 1) nblk = 1;
+    const int64_t max_blk = (n_rows + 15) / 16;
+    if (nblk > max_blk) nblk = max_blk;
+    const int64_t rows_per_blk = (n_rows + nblk - 1) / nblk;
+    nblk = (n_rows + rows_per_blk - 1) / rows_per_blk;
+    dim3 grid((unsigned)nblk, (unsigned)n_dchunks);
+    if (dc == 128) {
+      (void)hipFuncSetAttribute((const void*)k_gather_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL_LDS_BUDGET);
+      hipLaunchKernelGGL(k_gather_lds<2>, grid, dim3(GL_THREADS), lds, st, rp, n_rows, rows_per_blk, D, out, accumulate);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_gather_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL_LDS_BUDGET);
+      hipLaunchKernelGGL(k_gather_lds<1>, grid, dim3(GL_THREADS), lds, st, rp, n_rows, rows_per_blk, D, out, accumulate);
+    }
+    MMG_CHECK_LAUNCH("gather_rows(lds)");
+    return MMG_OK;
+  }
+  const unsigned nb = (unsigned)((n_rows + 3) / 4);
   if (D == 64) hipLaunchKernelGGL(k_gather<1>, dim3(nb), dim3(256), 0, st, rp, n_rows, out, accumulate);
   else if (D == 128) hipLaunchKernelGGL(k_gather<2>, dim3(nb), dim3(256), 0, st, rp, n_rows, out, accumulate);
   else hipLaunchKernelGGL(k_gather<4>, dim3(nb), dim3(256), 0, st, rp, n_rows, out, accumulate);
@@ -356,8 +488,8 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     default: launch_scatter_mfma<16>(p, rp, n_rows, D, x, slab, st); break;
   }
   const int64_t n = (int64_t)p.total_pad * D;
-  hipLaunchKernelGGL(k_scatter_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rp, D, p.total_pad,
-                     p.n_split, slab);
+  hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiScatter>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4,
+                     p.n_split, EpiScatter{rp, D});
   MMG_CHECK_LAUNCH("scatter_rows");
   return MMG_OK;
 }

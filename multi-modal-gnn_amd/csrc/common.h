@@ -89,3 +89,38 @@ __device__ static inline double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// ------------------------------------------------------------------------------------
+// Deterministic sum over partial slabs: out[i] = epi(sum_s slab[s][i]).  256 threads =
+// 16 float4 elements x 16 split groups; every thread keeps 8 independent 16-B loads in flight,
+// the 16 group partials are combined through LDS in fixed order.  Grid = ceil(n4 / 16).
+// ------------------------------------------------------------------------------------
+typedef float mmg_f4 __attribute__((ext_vector_type(4)));
+template <class Epi>
+__global__ __launch_bounds__(256) void mmg_k_reduce_slabs(const float* __restrict__ slab, int64_t n4, int n_split,
+                                                          Epi epi) {
+  __shared__ mmg_f4 part[16][16];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t i4 = (int64_t)blockIdx.x * 16 + e;
+  mmg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < n4) {
+    const mmg_f4* base = reinterpret_cast<const mmg_f4*>(slab) + i4;
+    int s = g;
+    for (; s + 7 * 16 < n_split; s += 8 * 16) {
+      mmg_f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(s + u * 16) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < n_split; s += 16) acc += base[(size_t)s * n4];
+  }
+  part[g][e] = acc;
+  __syncthreads();
+  if (g == 0 && i4 < n4) {
+    mmg_f4 t = part[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += part[q][e];
+    epi(i4, t);
+  }
+}

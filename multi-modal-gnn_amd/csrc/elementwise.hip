@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_dropout_mask(uint64_t seed, uint32_t si
 
 inline unsigned ew_grid(int64_t n4) {
   int64_t b = (n4 + 255) / 256;
-  if (b > 256 * 16) b = 256 * 16;
+  if (b > 256 * 128) b = 256 * 128;   // everything in flight: these passes are pure HBM streams
   if (b < 1) b = 1;
   return (unsigned)b;
 }

@@ -2,14 +2,15 @@
 // Replaces nn.Linear (+ the BatchNorm/ReLU/Dropout in front of it) of src/model.py:93-105 and the
 // lin_l / lin_r of PyG SAGEConv (call site src/model.py:125-131).
 //
-// linear_fwd : Y[M,N] = prologue(X)[M,K] . W[N,K]^T + b.  The W slice [BN,K] stays resident in LDS;
+// linear_fwd : Y[M,N] = prologue(X)[M,K] . W[N,K]^T + b.  The W fragments stay resident in registers;
 //              a workgroup (4 waves as 2(M) x 2(N)) streams 64-row X tiles through LDS.  The k axis is
 //              split between the two lane halves (lane>>5 takes k in [h*K/2,(h+1)*K/2)), so every
-//              A/B fragment read is a contiguous ds_read_b128 (4 MFMA steps per read).
+//              A fragment read is a contiguous ds_read_b128 (4 MFMA steps per read).
 // linear_wgrad: dW[N,K] = dY^T . prologue(X): each workgroup reduces a row chunk into a [TN,TK]
 //              register tile (operands are read column-wise: consecutive lanes, consecutive floats),
 //              writes one partial slab; a second kernel sums the slabs in fixed order.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -18,91 +19,157 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 64;
 
-template <int K, int BN>
-__global__ __launch_bounds__(256) void k_linear_fwd(const float* __restrict__ X, ProDev pr,
-                                                    const float* __restrict__ W, const float* __restrict__ bias,
-                                                    float* __restrict__ Y, int64_t M, int N, int accumulate) {
+// Y tile = 64 rows x (64*NTW) columns per workgroup; 4 waves as 2(M) x 2(N).
+// The W fragments live in REGISTERS for the whole kernel (lane (c=l&31, h=l>>5) of an N-tile holds
+// W[col c][k in h*K/2 ..]), so LDS only carries the streamed X tile (34 KB at K=128): two workgroups
+// fit per CU and one stages its next tile while the other issues MFMAs.  The next X tile is fetched
+// into registers one tile ahead.
+template <int K, int NTW, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict__ X, ProDev pr,
+                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                       float* __restrict__ Y, int64_t M, int N, int accumulate) {
   constexpr int LDK = K + 4;            // row stride (floats): shifts rows by one 16-B slot
-  constexpr int NT = BN / 64;           // 32x32 accumulator tiles per wave
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ws = smem;                     // [BN][LDK]
-  float* Xs = smem + BN * LDK;          // [BM][LDK]
+  constexpr int BN = 64 * NTW;
+  __shared__ __attribute__((aligned(16))) float Xs[BM * LDK];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int n0 = blockIdx.x * BN;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int n0 = blockIdx.x * BN + wn * (32 * NTW);
 
-  // ---- stage the W slice once
-  constexpr int K4 = K / 4;
-  for (int i = tid; i < BN * K4; i += 256) {
-    const int r = i / K4, c4 = i - r * K4;
-    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (size_t)(n0 + r) * K + c4 * 4);
-    *reinterpret_cast<f32x4*>(Ws + r * LDK + c4 * 4) = w;
+  // ---- W fragments: wr[nt][s] = W[n0 + nt*32 + l31][h*K/2 + s]
+  float wr[NTW][K / 2];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const float* wp = W + (size_t)(n0 + nt * 32 + l31) * K + h * (K / 2);
+#pragma unroll
+    for (int q = 0; q < K / 8; ++q) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wp + q * 4);
+      wr[nt][q * 4 + 0] = w[0]; wr[nt][q * 4 + 1] = w[1]; wr[nt][q * 4 + 2] = w[2]; wr[nt][q * 4 + 3] = w[3];
+    }
   }
+  float bv[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) bv[nt] = bias ? bias[n0 + nt * 32 + l31] : 0.f;
+
   // per-thread prologue constants: this thread always touches the same 4 k's
+  constexpr int K4 = K / 4;
   const int kc4 = tid % K4;               // float4 column
   constexpr int ROWS_PER_PASS = 256 / K4; // rows covered by one pass of the workgroup
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-  if (pr.scale) {
-    sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
-    sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
-  }
 
   const int64_t n_tiles = (M + BM - 1) / BM;
+  constexpr int NP = BM / ROWS_PER_PASS;   // 16-B loads per thread per tile
+  const int prow = tid / K4;
+  f32x4 nx[NP];                            // next tile, raw
+  auto fetch = [&](int64_t tile) {
+    const int64_t row0 = tile * BM;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int64_t gr = row0 + p * ROWS_PER_PASS + prow;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      nx[p] = gr < M ? *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + kc4 * 4) : z;
+    }
+  };
+  if ((int64_t)blockIdx.y < n_tiles) fetch(blockIdx.y);
   for (int64_t t = blockIdx.y; t < n_tiles; t += gridDim.y) {
     const int64_t row0 = t * BM;
-    __syncthreads();   // previous tile's MFMA reads are done (and W is staged on the first trip)
+    __syncthreads();   // previous tile's MFMA reads are done
 #pragma unroll
-    for (int p = 0; p < BM / ROWS_PER_PASS; ++p) {
-      const int r = p * ROWS_PER_PASS + tid / K4;
+    for (int p = 0; p < NP; ++p) {
+      const int r = p * ROWS_PER_PASS + prow;
       const int64_t gr = row0 + r;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gr < M) {
-        v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + kc4 * 4);
-        if (pr.scale || pr.relu || pr.p > 0.f) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = mmg_pro_apply(pr, v[j], sc[j], sh[j], gr, kc4 * 4 + j, K);
+      f32x4 v = nx[p];
+      if (gr < M && (pr.scale || pr.relu || pr.p > 0.f)) {
+        // scale/shift are re-read per tile (L1-resident): keeps 8 VGPRs out of the MFMA loop's live set
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (pr.scale) {
+          sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
+          sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mmg_pro_apply(pr, v[j], sc[j], sh[j], gr, kc4 * 4 + j, K);
       }
       *reinterpret_cast<f32x4*>(Xs + r * LDK + kc4 * 4) = v;
     }
     __syncthreads();
+    if (t + gridDim.y < n_tiles) fetch(t + gridDim.y);
 
-    f32x16 acc[NT];
+    f32x16 acc[NTW];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
-    const int h = lane >> 5, l31 = lane & 31;
     const float* ap = Xs + (wm * 32 + l31) * LDK + h * (K / 2);
-    const float* bp = Ws + (wn * (BN / 2) + l31) * LDK + h * (K / 2);
-#pragma unroll 4
+#pragma unroll
     for (int q = 0; q < K / 8; ++q) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(ap + q * 4);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + nt * 32 * LDK + q * 4);
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc[nt], 0, 0, 0);
-      }
+        for (int nt = 0; nt < NTW; ++nt)
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wr[nt][q * 4 + j], acc[nt], 0, 0, 0);
     }
 
     // ---- epilogue: C/D map col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = n0 + wn * (BN / 2) + nt * 32 + l31;
-      const float bv = bias ? bias[col] : 0.f;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int col = n0 + nt * 32 + l31;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int64_t gr = row0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         if (gr < M) {
           float* dst = Y + (size_t)gr * N + col;
-          float v = acc[nt][i] + bv;
+          float v = acc[nt][i] + bv[nt];
           if (accumulate) v += *dst;
           *dst = v;
         }
       }
+    }
+  }
+}
+
+// Small M (the vocab-side tables: 50..200 rows): one wave per 32x32 output tile, both operands
+// straight from L2 into registers -- no LDS, no barrier, M/32 x N/32 independent waves.
+template <int K>
+__global__ __launch_bounds__(64) void k_linear_small(const float* __restrict__ X, ProDev pr,
+                                                     const float* __restrict__ W, const float* __restrict__ bias,
+                                                     float* __restrict__ Y, int64_t M, int N, int accumulate) {
+  const int lane = threadIdx.x, h = lane >> 5, l31 = lane & 31;
+  const int n0 = blockIdx.x * 32;
+  const int64_t row0 = (int64_t)blockIdx.y * 32;
+  const int64_t ar = row0 + l31;
+  const float* xp = X + (size_t)(ar < M ? ar : 0) * K + h * (K / 2);
+  const float* wp = W + (size_t)(n0 + l31) * K + h * (K / 2);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 4
+  for (int q = 0; q < K / 8; ++q) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(xp + q * 4);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wp + q * 4);
+    if (pr.scale || pr.relu || pr.p > 0.f) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = h * (K / 2) + q * 4 + j;
+        const float s = pr.scale ? pr.scale[k] : 1.f, sh = pr.scale ? pr.shift[k] : 0.f;
+        a[j] = mmg_pro_apply(pr, a[j], s, sh, ar, k, K);
+      }
+    }
+    if (ar >= M) a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[j], acc, 0, 0, 0);
+  }
+  const int col = n0 + l31;
+  const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t gr = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (gr < M) {
+      float* dst = Y + (size_t)gr * N + col;
+      float v = acc[i] + bv;
+      if (accumulate) v += *dst;
+      *dst = v;
     }
   }
 }
@@ -134,32 +201,46 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
   const int h = lane >> 5, l31 = lane & 31;
+  constexpr int NY = WG_ROWS * (TN / 4) / 256, NX = WG_ROWS * (TK / 4) / 256;   // 16-B loads per thread per stage
+  f32x4 ny[NY], nxr[NX];
+  auto fetch = [&](int64_t r0) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NY; ++u) {
+      const int i = tid + u * 256, r = i / (TN / 4), c4 = i - r * (TN / 4);
+      ny[u] = (r0 + r < r_end) ? *reinterpret_cast<const f32x4*>(dY + (size_t)(r0 + r) * N + tn0 + c4 * 4) : z;
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int i = tid + u * 256, r = i / (TK / 4), c4 = i - r * (TK / 4);
+      nxr[u] = (r0 + r < r_end) ? *reinterpret_cast<const f32x4*>(X + (size_t)(r0 + r) * K + tk0 + c4 * 4) : z;
+    }
+  };
+  if (r_beg < r_end) fetch(r_beg);
   for (int64_t r0 = r_beg; r0 < r_end; r0 += WG_ROWS) {
     __syncthreads();
-    for (int i = tid; i < WG_ROWS * (TN / 4); i += 256) {
-      const int r = i / (TN / 4), c4 = i - r * (TN / 4);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r0 + r < r_end) v = *reinterpret_cast<const f32x4*>(dY + (size_t)(r0 + r) * N + tn0 + c4 * 4);
-      *reinterpret_cast<f32x4*>(&Ys[r][c4 * 4]) = v;
-    }
-    for (int i = tid; i < WG_ROWS * (TK / 4); i += 256) {
-      const int r = i / (TK / 4), c4 = i - r * (TK / 4);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int64_t gr = r0 + r;
-      if (gr < r_end) {
-        const int k = tk0 + c4 * 4;
-        v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + k);
-        if (pr.scale || pr.relu || pr.p > 0.f) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float s = pr.scale ? pr.scale[k + j] : 1.f, sh = pr.scale ? pr.shift[k + j] : 0.f;
-            v[j] = mmg_pro_apply(pr, v[j], s, sh, gr, k + j, K);
-          }
+    for (int u = 0; u < NY; ++u) {
+      const int i = tid + u * 256, r = i / (TN / 4), c4 = i - r * (TN / 4);
+      *reinterpret_cast<f32x4*>(&Ys[r][c4 * 4]) = ny[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int i = tid + u * 256, r = i / (TK / 4), c4 = i - r * (TK / 4);
+      f32x4 v = nxr[u];
+      const int64_t gr = r0 + r;
+      if (gr < r_end && (pr.scale || pr.relu || pr.p > 0.f)) {
+        const int k = tk0 + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sc = pr.scale ? pr.scale[k + j] : 1.f, sh = pr.scale ? pr.shift[k + j] : 0.f;
+          v[j] = mmg_pro_apply(pr, v[j], sc, sh, gr, k + j, K);
         }
       }
       *reinterpret_cast<f32x4*>(&Xs[r][c4 * 4]) = v;
     }
     __syncthreads();
+    if (r0 + WG_ROWS < r_end) fetch(r0 + WG_ROWS);
     // A[i=n][k=m] = dY[m][n],  B[k=m][j=kk] = X[m][kk];  lane half h takes m = h*16 + s
 #pragma unroll 4
     for (int s = 0; s < WG_ROWS / 2; ++s) {
@@ -189,14 +270,13 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
       }
 }
 
-__global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slab, float* __restrict__ out, int64_t n,
-                                                     int n_split, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int b = 0; b < n_split; ++b) s += slab[(size_t)b * n + i];
-  out[i] = accumulate ? out[i] + s : s;
-}
+struct EpiStore {
+  float* out; int accumulate;
+  __device__ void operator()(int64_t i4, mmg_f4 v) const {
+    mmg_f4* o = reinterpret_cast<mmg_f4*>(out) + i4;
+    *o = accumulate ? (*o + v) : v;
+  }
+};
 
 struct WgradPlan { int TN, TK, n_tiles, n_split; int64_t rows_per_split; };
 WgradPlan plan_wgrad(int64_t M, int N, int K) {
@@ -218,22 +298,25 @@ WgradPlan plan_wgrad(int64_t M, int N, int K) {
   return p;
 }
 
-template <int K, int BN>
+template <int K, int NTW, int OCC>
 int launch_fwd(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                int accumulate, hipStream_t st) {
-  constexpr size_t lds = (size_t)(BN + BM) * (K + 4) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)k_linear_fwd<K, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  constexpr int BN = 64 * NTW;
   const int n_slices = N / BN;
   const int64_t n_tiles = (M + BM - 1) / BM;
-  int64_t gy = (2 * 256) / n_slices;
+  int64_t gy = (OCC * 256) / n_slices;    // OCC resident workgroups per CU, persistent over the row tiles
   if (gy < 1) gy = 1;
   if (gy > n_tiles) gy = n_tiles;
-  hipLaunchKernelGGL((k_linear_fwd<K, BN>), dim3((unsigned)n_slices, (unsigned)gy), dim3(256), lds, st, X, pr, W, bias,
+  hipLaunchKernelGGL((k_linear_fwd<K, NTW, OCC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(256), 0, st, X, pr, W, bias,
                      Y, M, N, accumulate);
+  return 0;
+}
+
+template <int K>
+int launch_small(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                 int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL((k_linear_small<K>), dim3((unsigned)(N / 32), (unsigned)((M + 31) / 32)), dim3(64), 0, st, X, pr, W,
+                     bias, Y, M, N, accumulate);
   return 0;
 }
 
@@ -243,21 +326,27 @@ extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const f
                               int64_t M, int N, int K, int accumulate, void* stream) {
   MMG_CHECK_ARG(M >= 0, "linear_fwd: M < 0");
   MMG_CHECK_ARG(K == 64 || K == 128 || K == 256, "linear_fwd: K=%d unsupported (64|128|256)", K);
-  MMG_CHECK_ARG(N > 0 && N % 64 == 0 && N <= 1024, "linear_fwd: N=%d must be a multiple of 64", N);
+  MMG_CHECK_ARG(N > 0 && N % 64 == 0 && N <= 4096, "linear_fwd: N=%d must be a multiple of 64", N);
   if (M == 0) return MMG_OK;
   MMG_CHECK_ARG(X && W && Y, "linear_fwd: null buffer");
   MMG_CHECK_ARG(!pro || !pro->scale || pro->shift, "linear_fwd: prologue scale without shift");
   hipStream_t st = (hipStream_t)stream;
   const ProDev pr = mmg_pro_dev(pro);
-  const bool wide = (N % 128 == 0);
-  if (K == 64) {
-    if (wide) launch_fwd<64, 128>(X, pr, W, bias, Y, M, N, accumulate, st);
-    else launch_fwd<64, 64>(X, pr, W, bias, Y, M, N, accumulate, st);
+  if (M <= 512) {          // vocab-side tables
+    if (K == 64) launch_small<64>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else if (K == 128) launch_small<128>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else launch_small<256>(X, pr, W, bias, Y, M, N, accumulate, st);
+  } else if (K == 64) {
+    if (N % 128 == 0) launch_fwd<64, 2, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else launch_fwd<64, 1, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
   } else if (K == 128) {
-    if (wide) launch_fwd<128, 128>(X, pr, W, bias, Y, M, N, accumulate, st);
-    else launch_fwd<128, 64>(X, pr, W, bias, Y, M, N, accumulate, st);
+    // 128-wide column slices need ~290 VGPRs (W fragments 128 + accumulators 32 + prefetch 32): one
+    // workgroup per CU; 64-wide slices fit two per CU but read X twice.  MMG_LINEAR_WIDE picks (A/B knob).
+    static const int wide = [] { const char* e = getenv("MMG_LINEAR_WIDE"); return e ? atoi(e) : 1; }();
+    if (N % 128 == 0 && wide) launch_fwd<128, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else launch_fwd<128, 1, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
   } else {
-    launch_fwd<256, 64>(X, pr, W, bias, Y, M, N, accumulate, st);
+    launch_fwd<256, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
   }
   MMG_CHECK_LAUNCH("linear_fwd");
   return MMG_OK;
@@ -297,7 +386,8 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
   else
     hipLaunchKernelGGL((k_linear_wgrad<64, 64>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
   const int64_t n = (int64_t)N * K;
-  hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, dW, n, p.n_split, accumulate);
+  hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiStore>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4,
+                     p.n_split, EpiStore{dW, accumulate});
   MMG_CHECK_LAUNCH("linear_wgrad");
   return MMG_OK;
 }

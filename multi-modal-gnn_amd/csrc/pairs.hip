@@ -278,21 +278,45 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 
   const int64_t n_tiles = (n + TP - 1) / TP;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid, n_waves = (int64_t)gridDim.x * 4;
-  for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
-    // ---- (a) pair metadata: lane l31 of half 0 owns pair row l31
+  // software pipeline: pair metadata two tiles ahead, the A/B row halves one tile ahead
+  struct Meta { int p_i; int l_i; float dout; uint64_t pid; };
+  auto load_meta = [&](int64_t t) {
+    Meta m{-1, 0, 0.f, 0ull};
     const int64_t k = t * TP + l31;
-    int p_i = -1, l_i = 0;
-    float dout = 0.f;
-    uint64_t pid = 0;
-    if (k < n) {
+    if (t < n_tiles && k < n) {
       const int pp = pi[k];
       if (((int)(deg[pp] < thr)) == want_low) {
-        p_i = pp; l_i = li[k];
-        dout = dpred[k];
-        pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
+        m.p_i = pp; m.l_i = li[k];
+        m.dout = dpred[k];
+        m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
       }
     }
-    if (__ballot(p_i >= 0) == 0ull) continue;      // no pair of this tile belongs to this head (wave-uniform)
+    return m;
+  };
+  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb) {
+    const float* ap = H.A + (size_t)(m.p_i >= 0 ? m.p_i : 0) * 64 + 32 * h;
+    const float* bp = H.B + (size_t)m.l_i * 64 + 32 * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      ra[q] = *reinterpret_cast<const f32x4*>(ap + q * 4);
+      rb[q] = *reinterpret_cast<const f32x4*>(bp + q * 4);
+    }
+  };
+  Meta m0 = load_meta(wave_id), m1 = load_meta(wave_id + n_waves);
+  f32x4 ra[8], rb[8];
+  load_rows(m0, ra, rb);
+  for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
+    const Meta mc = m0;
+    f32x4 ca[8], cb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
+    const Meta m2 = load_meta(t + 2 * n_waves);
+    load_rows(m1, ra, rb);                       // next tile's rows: in flight during this tile's MFMAs
+    m0 = m1; m1 = m2;
+    const int p_i = mc.p_i, l_i = mc.l_i;
+    const float dout = mc.dout;
+    const uint64_t pid = mc.pid;
+    if (__ballot(p_i >= 0) == 0ull) continue;    // no pair of this tile belongs to this head (wave-uniform)
     if (h == 0) {
       PIs[l31] = p_i; LIs[l31] = l_i; DOs[l31] = dout;
       PLo[l31] = (unsigned)pid; PHi[l31] = (unsigned)(pid >> 32);
@@ -300,23 +324,17 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
     }
     // ---- (b) h1[pair=l31][k=32h+s]: gather-add, relu, dropout; kept in registers AND written to LDS
     float h1a[32];
-    {
-      const float* ap = H.A + (size_t)(p_i >= 0 ? p_i : 0) * 64 + 32 * h;
-      const float* bp = H.B + (size_t)l_i * 64 + 32 * h;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ap + q * 4);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + q * 4);
-        f32x4 v;
+    for (int q = 0; q < 8; ++q) {
+      f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float x = fmaxf(a[j] + b[j], 0.f);
-          if (drop_p > 0.f) x = mmg_keep(seed, SITE_H1, pid * 64ull + (32 * h + q * 4 + j), drop_p) ? x * inv_keep : 0.f;
-          v[j] = x;
-          h1a[q * 4 + j] = x;
-        }
-        *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
+      for (int j = 0; j < 4; ++j) {
+        float x = fmaxf(ca[q][j] + cb[q][j], 0.f);
+        if (drop_p > 0.f) x = mmg_keep(seed, SITE_H1, pid * 64ull + (32 * h + q * 4 + j), drop_p) ? x * inv_keep : 0.f;
+        v[j] = x;
+        h1a[q * 4 + j] = x;
       }
+      *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
     }
     // ---- (1) H2pre = H1 . W2^T
     f32x16 acc1;
@@ -397,18 +415,24 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
       H1s[crow(r, h) * LDH + l31] = dh[r][0];
       H1s[crow(r, h) * LDH + 32 + l31] = dh[r][1];
     }
-    {
+    {   // patient ids come from registers (readlane), the 32 tile rows are read from LDS in two batches
       float run = 0.f;
       int cur = -1;
-      for (int q = 0; q < TP; ++q) {
-        const int pp = PIs[q];
-        if (pp < 0) continue;
-        const float v = H1s[q * LDH + lane];
-        if (pp != cur) {
-          if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
-          cur = pp; run = 0.f;
+#pragma unroll
+      for (int bq = 0; bq < 2; ++bq) {
+        float vq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vq[q] = H1s[(bq * 16 + q) * LDH + lane];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int pp = __builtin_amdgcn_readlane(p_i, bq * 16 + q);
+          if (pp < 0) continue;
+          if (pp != cur) {
+            if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
+            cur = pp; run = 0.f;
+          }
+          run += vq[q];
         }
-        run += v;
       }
       if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
     }
