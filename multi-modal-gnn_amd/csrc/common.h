@@ -45,10 +45,15 @@ __host__ __device__ static inline uint32_t mmg_rng_u32(uint64_t seed, uint32_t s
   h = mmg_mix32(h + (uint32_t)(elem >> 32) * 0x27d4eb2fu + 0x165667b1u);
   return h;
 }
-// keep with probability 1-p: 24-bit uniform >= p
+// keep with probability 1-p.  One hash serves FOUR consecutive elements (16 random bits each, p quantised
+// to 1/65536): callers walk elements in aligned groups of 4, so the compiler shares the hash across the group.
 __host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, uint64_t elem, float p) {
-  float u = (float)(mmg_rng_u32(seed, site, elem) >> 8) * (1.0f / 16777216.0f);
-  return u >= p;
+  const uint32_t h1 = mmg_rng_u32(seed, site, elem >> 2);
+  const uint32_t h2 = mmg_mix32(h1 ^ 0x68bc21ebu);
+  const uint32_t sub = (uint32_t)elem & 3u;
+  const uint32_t word = (sub & 2u) ? h2 : h1;
+  const uint32_t bits = (word >> ((sub & 1u) * 16u)) & 0xFFFFu;
+  return bits >= (uint32_t)(p * 65536.0f);
 }
 
 // folded prologue: dropout(relu(x*scale+shift)); returns the transformed value

@@ -459,6 +459,115 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
   if (lane == 0) atomicAdd(Gd.db3, b3acc);
 }
 
+// ---------------------------------------------------------------------------- forward on MFMA
+// Same tiling as the backward: one wave per 32 pairs, H2pre = H1 . W2^T on the matrix cores (32 MFMA), the
+// 32->1 output layer is a butterfly reduction over the 32 unit lanes (16 shuffles per tile).
+__global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32_t* __restrict__ pi,
+                                                          const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
+                                                          int thr, int want_low, int64_t n, float drop_p, uint64_t seed,
+                                                          const int64_t* __restrict__ pair_id, float* __restrict__ pred) {
+  __shared__ unsigned PL[4][TP], PH[4][TP];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float w2b[32];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) w2b[s] = H.W2[l31 * 64 + 32 * h + s];
+  const float b2v = H.b2[l31], w3v = H.W3[l31], b3 = H.b3[0];
+
+  const int64_t n_tiles = (n + TP - 1) / TP;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid, n_waves = (int64_t)gridDim.x * 4;
+  struct Meta { int p_i; int l_i; uint64_t pid; };
+  auto load_meta = [&](int64_t t) {
+    Meta m{-1, 0, 0ull};
+    const int64_t k = t * TP + l31;
+    if (t < n_tiles && k < n) {
+      const int pp = pi[k];
+      if (((int)(deg[pp] < thr)) == want_low) {
+        m.p_i = pp; m.l_i = li[k];
+        m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
+      }
+    }
+    return m;
+  };
+  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb) {
+    const float* ap = H.A + (size_t)(m.p_i >= 0 ? m.p_i : 0) * 64 + 32 * h;
+    const float* bp = H.B + (size_t)m.l_i * 64 + 32 * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      ra[q] = *reinterpret_cast<const f32x4*>(ap + q * 4);
+      rb[q] = *reinterpret_cast<const f32x4*>(bp + q * 4);
+    }
+  };
+  Meta m0 = load_meta(wave_id), m1 = load_meta(wave_id + n_waves);
+  f32x4 ra[8], rb[8];
+  load_rows(m0, ra, rb);
+  for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
+    const Meta mc = m0;
+    f32x4 ca[8], cb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
+    const Meta m2 = load_meta(t + 2 * n_waves);
+    load_rows(m1, ra, rb);
+    m0 = m1; m1 = m2;
+    if (__ballot(mc.p_i >= 0) == 0ull) continue;
+    if (drop_p > 0.f && h == 0) { PL[wid][l31] = (unsigned)mc.pid; PH[wid][l31] = (unsigned)(mc.pid >> 32); }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x = fmaxf(ca[q][j] + cb[q][j], 0.f);
+        if (drop_p > 0.f) x = mmg_keep(seed, SITE_H1, mc.pid * 64ull + (32 * h + q * 4 + j), drop_p) ? x * inv_keep : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, w2b[q * 4 + j], acc, 0, 0, 0);
+      }
+    // C layout: lane = unit u (l31), reg r = pair row crow(r,h).  v[r] = W3[u] * dropout(relu(pre))
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float post = fmaxf(acc[r] + b2v, 0.f);
+      if (drop_p > 0.f) {
+        const int row = crow(r, h);
+        const uint64_t pd = ((uint64_t)PH[wid][row] << 32) | PL[wid][row];
+        post = mmg_keep(seed, SITE_H2, pd * 32ull + l31, drop_p) ? post * inv_keep : 0.f;
+      }
+      v[r] = w3v * post;
+    }
+    // butterfly over the 32 unit lanes: after the 5 steps lane l31 holds the full sum of reg r = l31 >> 1
+    const bool b4 = l31 & 16, b3b = l31 & 8, b2b = l31 & 4, b1b = l31 & 2;
+    float w8[8], w4[4], w2[2], w1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float send = b4 ? v[i] : v[i + 8], keep = b4 ? v[i + 8] : v[i];
+      w8[i] = keep + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float send = b3b ? w8[i] : w8[i + 4], keep = b3b ? w8[i + 4] : w8[i];
+      w4[i] = keep + __shfl_xor(send, 8, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float send = b2b ? w4[i] : w4[i + 2], keep = b2b ? w4[i + 2] : w4[i];
+      w2[i] = keep + __shfl_xor(send, 4, 64);
+    }
+    {
+      const float send = b1b ? w2[0] : w2[1], keep = b1b ? w2[1] : w2[0];
+      w1 = keep + __shfl_xor(send, 2, 64);
+    }
+    w1 += __shfl_xor(w1, 1, 64);
+    const int r = (b4 ? 8 : 0) + (b3b ? 4 : 0) + (b2b ? 2 : 0) + (b1b ? 1 : 0);
+    const int row = crow(r, h);
+    const int owner = __shfl(mc.p_i, row, 64);          // lane `row` (half 0) holds that pair's metadata
+    if ((l31 & 1) == 0 && owner >= 0) {
+      const int64_t k = t * TP + row;
+      if (k < n) pred[k] = w1 + b3;
+    }
+  }
+}
+
 inline unsigned pair_grid(int64_t n) {
   int64_t t = (n + PT - 1) / PT;
   if (t > 1024) t = 1024;
@@ -483,7 +592,10 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   MMG_CHECK_ARG(pi && li && deg && pred, "pair_head_fwd: null buffer");
   MMG_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pair_head_fwd: drop_p out of range");
   HeadDev H{head->A, head->B, head->W2, head->b2, head->W3, head->b3};
-  hipLaunchKernelGGL(k_pair_fwd, dim3(pair_grid(n_pairs)), dim3(PT), 0, (hipStream_t)stream, H, pi, li, deg,
+  int64_t g = ((n_pairs + TP - 1) / TP + 3) / 4;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_pair_fwd_mfma, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, H, pi, li, deg,
                      degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, pair_id, pred);
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;

@@ -62,12 +62,12 @@ def partition_rows(row_weights: torch.Tensor, world: int) -> List[int]:
     n = int(row_weights.numel())
     if world <= 0:
         raise ValueError("world must be positive")
-    csum = torch.cumsum(row_weights.to(torch.float64).cpu() + 1e-9, 0)
+    csum = torch.cumsum(row_weights.to(torch.float64).cpu(), 0)
     total = float(csum[-1]) if n else 0.0
     bounds = [0]
     for r in range(1, world):
         target = total * r / world
-        b = int(torch.searchsorted(csum, torch.tensor(target, dtype=torch.float64)).item()) if n else 0
+        b = int(torch.searchsorted(csum, torch.tensor(target, dtype=torch.float64), right=True).item()) if n else 0
         b = max(b, bounds[-1] + (1 if bounds[-1] < n else 0))
         b = min(b, n - (world - r) if n >= world else n)
         b = max(b, bounds[-1])

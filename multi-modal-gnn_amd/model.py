@@ -140,6 +140,7 @@ class HeteroRGCN(nn.Module):
         self._comm = None            # set by dist.shard_model(): patient-axis sharding
         self._dropout_seed = None    # tests pin the dropout stream through this
         self._pair_cache = {}
+        self._last_run = None
 
     # ------------------------------------------------------------------------------ embeddings
     def _init_embeddings(self, data):
@@ -283,6 +284,7 @@ class _Run:
             self.n_pairs = pi.numel()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params.values())
         self.need_grad = need_grad
+        self.m._last_run = self if need_grad else None      # (tests drive run_backward by hand through this)
         plist = [self.params[n] for n in self.names]
         if need_grad:
             outs = _StepFn.apply(self, mode, 0, *plist)

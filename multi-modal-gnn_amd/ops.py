@@ -85,8 +85,11 @@ _WS = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Growable per-device scratch (stream-ordered reuse: every op runs on the current stream)."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """Growable scratch per (device, host thread).  Reuse is stream-ordered: every op of a thread runs on that
+    thread's current stream, and two host threads never share a buffer."""
+    import threading
+    d = torch.device(device)
+    key = (d.index if d.index is not None else torch.cuda.current_device(), threading.get_ident())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -1,0 +1,148 @@
+"""The product's patient-sharded step on ONE GPU: two shards driven by two host threads whose collectives are
+a thread-barrier all-reduce (same semantics as ShardComm over RCCL).  Must reproduce the unsharded HIP
+model: predictions per shard, summed parameter gradients, Sync-BN running buffers."""
+import threading
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fixtures as fx
+from oracle import model as om
+from oracle import train as ot
+
+CFG = {"model": {"architecture": "RGCN", "hidden_dim": 128, "num_layers": 2, "dropout": 0.0,
+                 "use_batch_norm": True, "activation": "relu"}}
+
+
+class ThreadComm:
+    """all_reduce across host threads that share one device stream."""
+
+    def __init__(self, world, rank, shared):
+        self.world, self.rank, self.sh = world, rank, shared
+        self.pair_ids = None
+        self.n_calls = 0
+
+    def all_reduce(self, t):
+        sh = self.sh
+        sh["slots"][self.rank] = t
+        sh["bar"].wait()
+        tot = sh["slots"][0].clone()
+        for r in range(1, self.world):
+            tot = tot + sh["slots"][r]
+        sh["bar"].wait()
+        t.copy_(tot)
+        self.n_calls += 1
+        return t
+
+    def all_reduce_list(self, ts):
+        ts = [x for x in ts if x is not None]
+        flat = torch.cat([x.reshape(-1).float() for x in ts])
+        self.all_reduce(flat)
+        off = 0
+        for x in ts:
+            x.copy_(flat[off:off + x.numel()].view_as(x))
+            off += x.numel()
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_two_virtual_shards_match_unsharded(dropout):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import mmgnn  # noqa: F401
+    from mmgnn import dist as md
+    from mmgnn.data import build_plan
+    from mmgnn.model import build_model
+    dev = torch.device("cuda:0")
+    world = 2
+    g = fx.graph_from_frames(fx.det_frames(700, 20, 25, 18))
+    gv = om.GraphView(g)
+    sd = fx.det_state(gv.num_nodes, 128)
+    cfg = {"model": dict(CFG["model"], dropout=dropout)}
+    ei, ea = g["patient", "has_lab", "lab"].edge_index, g["patient", "has_lab", "lab"].edge_attr
+    tr, _, _ = ot.edge_splits(ei.shape[1])
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    w = ot.lab_weights(li, y, gv.num_nodes["lab"]).to(dev)
+    sup = ot.supervision_mask(int(tr.sum()), 0.2, torch.Generator().manual_seed(5))
+    n_sup = float(sup.sum())
+    # seed chosen so that no ReLU pre-activation of the 64x32 head layer sits within fp32 rounding of 0 for a
+    # supervised pair (seed 777 has one at 1e-7: its gradient flips with the summation order -- an inherent
+    # kink tie, not a sharding effect; the whole gradient is a sum over only ~1.3k supervised pairs)
+    seed = 778
+
+    def loss_of(pred, sup_d, y_d, li_d):
+        return ((pred[sup_d] - y_d[sup_d]).abs() * w[li_d[sup_d]]).sum() / n_sup
+
+    # ---- unsharded run
+    ref = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
+    gd = g.clone().to(dev)
+    ref._init_embeddings(gd)
+    ref.load_state_dict(sd)
+    ref._dropout_seed = seed
+    ref.train()
+    pred_ref = ref.predict_lab_values(gd, pi.to(dev), li.to(dev))
+    loss_of(pred_ref, sup.to(dev), y.to(dev), li.to(dev)).backward()
+
+    # ---- two shards, two threads
+    b = md.partition_rows(md.patient_weights(g), world)
+    shared = {"slots": [None] * world, "bar": threading.Barrier(world)}
+    out = [None] * world
+    errs = []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(dev)
+            lo, hi = b[rank], b[rank + 1]
+            gs = md.shard_graph(g, lo, hi).to(dev)
+            pil, lil, ids = md.shard_pairs(pi, li, lo, hi)
+            comm = ThreadComm(world, rank, shared)
+            comm.pair_ids = ids.to(dev)
+            m = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
+            m._init_embeddings(gs)
+            m.load_state_dict(md.shard_state(sd, lo, hi))
+            m._dropout_seed = seed
+            plan = build_plan(gs, dev, use_cache=False)
+            md.shard_plan(plan, comm, lo, int(g["patient"].num_nodes))
+            md.shard_model(m, comm)
+            m.train()
+            pil_d, lil_d = pil.to(dev), lil.to(dev)
+            pred = m.predict_lab_values(plan, pil_d, lil_d)
+            loss = loss_of(pred, sup[ids].to(dev), y[ids].to(dev), lil_d)
+            # The autograd engine has ONE worker thread per device, so two shards' backward passes that
+            # rendezvous in a collective would deadlock inside it: drive the hand-written backward directly.
+            (dpred,) = torch.autograd.grad(loss, pred)
+            grads = m._last_run.run_backward((dpred,))
+            for (_, p_), g_ in zip(m.named_parameters(), grads):
+                p_.grad = g_
+            out[rank] = (m, pred.detach(), ids, lo, hi)
+        except Exception:  # pragma: no cover
+            import traceback
+            errs.append(traceback.format_exc())
+            shared["bar"].abort()
+
+    ths = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not errs, errs[0]
+    torch.cuda.synchronize()
+
+    pmax = float(pred_ref.detach().abs().max())
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for rank in range(world):
+        m, pred, ids, lo, hi = out[rank]
+        assert float((pred - pred_ref.detach()[ids.to(dev)]).abs().max()) <= 1e-4 * pmax
+        for (k, p), (_, pr_) in zip(m.named_parameters(), ref.named_parameters()):
+            gref = pr_.grad if pr_.grad is not None else torch.zeros_like(pr_)
+            got = p.grad if p.grad is not None else torch.zeros_like(p)
+            if k == "embeddings.patient.weight":
+                gref = gref[lo:hi]
+            # replicated parameters: every shard ends the step with the FULL gradient
+            assert float((got - gref).abs().max()) <= 2e-4 * float(gref.abs().max()) + 2e-6 * gmax, (rank, k)
+        for (k, bf), (_, br) in zip(m.named_buffers(), ref.named_buffers()):
+            if k.endswith("num_batches_tracked"):
+                assert int(bf) == int(br), k
+            else:
+                assert float((bf - br).abs().max()) <= 1e-4 * float(br.abs().max()), k
