@@ -74,7 +74,10 @@ typedef struct {
   const float* table;      /* gather: [n_cols, D] source rows */
   float* out;              /* scatter: [n_cols, D] destination rows */
   int32_t n_cols;
+  uint32_t flags;          /* MMG_REL_SIMPLE: no (row, col) pair occurs twice -- enables the 0/1 indicator
+                              (bf16-split MFMA) kernels; multigraphs take the counting fp32 path */
 } mmg_rel_t;
+#define MMG_REL_SIMPLE 1u
 
 int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
                     float* out, int accumulate, void* stream);
@@ -99,6 +102,8 @@ typedef struct {
   uint64_t seed;           /* dropout RNG: keep(seed, site, global_row*K + k) */
   uint32_t site;
   int64_t row_offset;      /* global index of row 0 (patient sharding) */
+  const uint64_t* seed_ptr;/* optional DEVICE pointer: when non-NULL the seed is read from it at run time
+                              (lets a captured hipGraph draw fresh masks on every replay) */
 } mmg_prologue_t;
 
 /* Y[M,N] = prologue(X)[M,K] . W[N,K]^T (+ bias[N]) (+ Y if accumulate)            */
@@ -148,8 +153,8 @@ int mmg_l2norm_bwd(const float* G, const float* out, const float* rnorm, float* 
                    float eps, void* stream);
 
 /* keep-mask of the dropout RNG, for injected-mask parity tests: mask[i] in {0,1}     */
-int mmg_dropout_mask(uint64_t seed, uint32_t site, int64_t first_elem, int64_t n_elems, float p,
-                     uint8_t* mask, void* stream);
+int mmg_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_t site, int64_t first_elem, int64_t n_elems,
+                     float p, uint8_t* mask, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Degree-gated dual edge head (src/model.py:305-333, EdgeRegressionHead :342-396).
@@ -181,15 +186,16 @@ typedef struct {
  * (want_low = 1: deg[pi] < degree_threshold -> tabular_mlp; 0: the GNN edge_predictor);
  * other pairs are left untouched in pred / contribute nothing to the gradients.
  * pair_id (nullable) = original position of each pair, used only to key the dropout RNG so that
- * a permuted (patient-sorted) pair list draws the same masks. */
+ * a permuted (patient-sorted) pair list draws the same masks.  seed_ptr (nullable, device): overrides
+ * `seed` at run time (hipGraph replays). */
 int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li,
                       const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs,
-                      float drop_p, uint64_t seed, const int64_t* pair_id,
+                      float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
                       float* pred, void* stream);
 int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,
                       const int32_t* pi, const int32_t* li, const int32_t* deg, int degree_threshold,
                       int want_low, int64_t n_pairs, int n_labs, float drop_p, uint64_t seed,
-                      const int64_t* pair_id, const float* dpred, void* stream);
+                      const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred, void* stream);
 
 #ifdef __cplusplus
 }

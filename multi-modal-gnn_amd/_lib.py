@@ -21,12 +21,12 @@ class MmgError(RuntimeError):
 class RelT(C.Structure):
     _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("rowscale", C.c_void_p),
                 ("colscale", C.c_void_p), ("table", C.c_void_p), ("out", C.c_void_p),
-                ("n_cols", C.c_int32)]
+                ("n_cols", C.c_int32), ("flags", C.c_uint32)]
 
 
 class PrologueT(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("relu", C.c_int), ("drop_p", C.c_float),
-                ("seed", C.c_uint64), ("site", C.c_uint32), ("row_offset", C.c_int64)]
+                ("seed", C.c_uint64), ("site", C.c_uint32), ("row_offset", C.c_int64), ("seed_ptr", C.c_void_p)]
 
 
 class HeadT(C.Structure):
@@ -66,10 +66,10 @@ SIGNATURES = {
     "mmg_bn_bwd_apply": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mmg_l2norm_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmg_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
-    "mmg_dropout_mask": (C.c_int, [_u64, _u32, _i64, _i64, _f32, _vp, _vp]),
-    "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _f32, _u64, _vp, _vp, _vp]),
+    "mmg_dropout_mask": (C.c_int, [_u64, _vp, _u32, _i64, _i64, _f32, _vp, _vp]),
+    "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _f32, _u64, _vp, _vp, _vp, _vp]),
     "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64,
-                                    _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -8,6 +8,7 @@
 //           cores, keeping the [V, D] accumulators in registers; ONE partial slab per workgroup, summed
 //           by a second kernel in fixed order (bitwise reproducible).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -16,6 +17,7 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 struct RelDev {
   const int32_t* rowptr; const int32_t* col; const float* rowscale; const float* colscale;
   const float* table; float* out; int32_t n_cols; int32_t acc_off;   // acc_off: first accumulator row
+  uint32_t flags;
 };
 struct RelPack { RelDev r[MMG_MAX_REL]; int n; };
 
@@ -181,6 +183,174 @@ __global__ __launch_bounds__(GL_THREADS) void k_gather_lds(RelPack rp, int64_t n
     for (int v = 0; v < VECC; ++v) dst[v] = prev[v] + tot[v];
 #pragma unroll
     for (int r = 0; r < MMG_MAX_REL; ++r) { b0[r] = b1[r]; e0[r] = e1[r]; b1[r] = b2[r]; e1[r] = e2[r]; c0[r] = c1[r]; }
+  }
+}
+
+// ------------------------------------------------------------------------------ gather on bf16 matrix cores
+// For simple graphs (MMG_REL_SIMPLE) the per-row indicator is 0/1, which bf16 holds exactly, and an fp32
+// table value splits exactly into three bf16 pieces (hi + mid + lo, 8 significant bits each).  So
+//     out[i, :] = sum_r rs_r[i] * sum_v Ind_r[i, v] * T'_r[v, :]        (T' = colscale * T)
+// is three v_mfma_f32_32x32x16_bf16 per 16 vocab columns with EXACT products and fp32 accumulation: the
+// fp32 result up to summation order, at 16x the fp32 matrix rate.  The three split tables stay in LDS for
+// the whole workgroup ([piece][d][v], v contiguous = the B-fragment order), the 32-row indicator tile is
+// rebuilt per stage ([row][v]); one accumulator per relation keeps the per-relation mean scaling exact.
+// Column ids of the next stage and row bounds of the stage after are prefetched into registers.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gf32x16 __attribute__((ext_vector_type(16)));
+constexpr int GB_ROWS = 32, GB_DH = 64, GB_PF = 8;
+constexpr size_t GB_LDS_MAX = 156 * 1024;
+
+__device__ inline void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)v;
+  const float r1 = v - (float)a;
+  b = (__bf16)r1;
+  c = (__bf16)(r1 - (float)b);
+}
+
+__global__ __launch_bounds__(256) void k_gather_bf16(RelPack rp, int64_t n_rows, int64_t rows_per_blk, int D, int vp,
+                                                     float* __restrict__ out, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int ldv = vp + 8;                                   // bf16 elements per LDS row (16-B multiple)
+  __bf16* TT = reinterpret_cast<__bf16*>(lds_raw);          // [3][GB_DH][ldv]
+  __bf16* CT = TT + 3 * GB_DH * ldv;                        // [GB_ROWS][ldv]
+  float* RS = reinterpret_cast<float*>(CT + GB_ROWS * ldv); // [MMG_MAX_REL][GB_ROWS]
+  float* PART = RS + MMG_MAX_REL * GB_ROWS;                 // [2][32][32]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int dt = wid & 1, kh = wid >> 1;
+  const int d0 = blockIdx.y * GB_DH;
+  const int nks = vp / 16, kmid = nks / 2;
+
+  // ---- stage the split tables once
+  {
+    const mmg_f4 z = {0.f, 0.f, 0.f, 0.f};
+    mmg_f4* t4 = reinterpret_cast<mmg_f4*>(TT);
+    for (int i = tid; i < 3 * GB_DH * ldv / 8; i += 256) t4[i] = z;
+  }
+  __syncthreads();
+  for (int r = 0; r < rp.n; ++r) {
+    const RelDev& R = rp.r[r];
+    for (int i = tid; i < R.n_cols * GB_DH; i += 256) {
+      const int c = i / GB_DH, dd = i - c * GB_DH;
+      float v = R.table[(size_t)c * D + d0 + dd];
+      if (R.colscale) v *= R.colscale[c];
+      __bf16 a, b, cc;
+      split3(v, a, b, cc);
+      TT[(0 * GB_DH + dd) * ldv + R.acc_off + c] = a;
+      TT[(1 * GB_DH + dd) * ldv + R.acc_off + c] = b;
+      TT[(2 * GB_DH + dd) * ldv + R.acc_off + c] = cc;
+    }
+  }
+
+  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_blk, r_end = min(n_rows, r_beg + rows_per_blk);
+  const int m = tid >> 3, q = tid & 7;                      // 8 lanes per indicator row
+  // software pipeline state: bounds of the next stage's row, prefetched column ids of the current one
+  int cb[MMG_MAX_REL], ce[MMG_MAX_REL], nb[MMG_MAX_REL], ne[MMG_MAX_REL], cc[MMG_MAX_REL][GB_PF];
+  auto bounds = [&](int64_t row, int* bb, int* ee) {
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      bb[r] = 0; ee[r] = 0;
+      if (r < rp.n && row < r_end) { bb[r] = rp.r[r].rowptr[row]; ee[r] = rp.r[r].rowptr[row + 1]; }
+    }
+  };
+  auto fetch_cols = [&](const int* bb, const int* ee, int (*dst)[GB_PF]) {
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r)
+#pragma unroll
+      for (int i = 0; i < GB_PF; ++i) {
+        const int k = bb[r] + q + 8 * i;
+        dst[r][i] = (r < rp.n && k < ee[r]) ? rp.r[r].col[k] : -1;
+      }
+  };
+  bounds(r_beg + m, cb, ce);
+  bounds(r_beg + GB_ROWS + m, nb, ne);
+  fetch_cols(cb, ce, cc);
+
+  gf32x16 acc[MMG_MAX_REL];
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += GB_ROWS) {
+    __syncthreads();                                        // previous stage done with CT / PART / RS
+    {
+      const mmg_f4 z = {0.f, 0.f, 0.f, 0.f};
+      mmg_f4* c4 = reinterpret_cast<mmg_f4*>(CT);
+      for (int i = tid; i < GB_ROWS * ldv / 8; i += 256) c4[i] = z;
+      if (tid < MMG_MAX_REL * GB_ROWS) {
+        const int r = tid / GB_ROWS, mm = tid - r * GB_ROWS;
+        float v = 1.f;
+        if (r < rp.n && rp.r[r].rowscale && r0 + mm < r_end) v = rp.r[r].rowscale[r0 + mm];
+        RS[tid] = v;
+      }
+    }
+    float prev[16];
+    if (kh == 0) {                                          // accumulate: issue the old values early
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t gr = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        prev[i] = (accumulate && gr < r_end) ? out[(size_t)gr * D + d0 + dt * 32 + l31] : 0.f;
+      }
+    }
+    __syncthreads();                                        // zero-fill visible before the ones land
+    {
+      unsigned short* c16 = reinterpret_cast<unsigned short*>(CT) + m * ldv;
+#pragma unroll
+      for (int r = 0; r < MMG_MAX_REL; ++r) {
+        if (r >= rp.n) continue;
+        const int off = rp.r[r].acc_off;
+#pragma unroll
+        for (int i = 0; i < GB_PF; ++i)
+          if (cc[r][i] >= 0) c16[off + cc[r][i]] = 0x3F80;                    // bf16 1.0
+        for (int k = cb[r] + q + 8 * GB_PF; k < ce[r]; k += 8) c16[off + rp.r[r].col[k]] = 0x3F80;   // > 64 edges (rare)
+      }
+    }
+    // prefetch: column ids for the next stage (bounds known), bounds for the one after
+    int tb[MMG_MAX_REL], te[MMG_MAX_REL], tc[MMG_MAX_REL][GB_PF];
+    fetch_cols(nb, ne, tc);
+    bounds(r0 + 2 * GB_ROWS + m, tb, te);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+    const int kb = kh ? kmid : 0, ke = kh ? nks : kmid;
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      if (r >= rp.n) continue;
+      const int k0 = rp.r[r].acc_off / 16;
+      const int k1 = k0 + ((rp.r[r].n_cols + 15) >> 4);
+      for (int ks = max(k0, kb); ks < min(k1, ke); ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(CT + l31 * ldv + 16 * ks + 8 * h);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(TT + (p * GB_DH + dt * 32 + l31) * ldv + 16 * ks + 8 * h);
+          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r], 0, 0, 0);
+        }
+      }
+    }
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < MMG_MAX_REL; ++r)
+        if (r < rp.n) t = fmaf(RS[r * GB_ROWS + row], acc[r][i], t);
+      v[i] = t;
+      if (kh == 1) PART[(dt * 32 + row) * 32 + l31] = t;
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int64_t gr = r0 + row;
+        if (gr < r_end) out[(size_t)gr * D + d0 + dt * 32 + l31] = prev[i] + v[i] + PART[(dt * 32 + row) * 32 + l31];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      cb[r] = nb[r]; ce[r] = ne[r]; nb[r] = tb[r]; ne[r] = te[r];
+#pragma unroll
+      for (int i = 0; i < GB_PF; ++i) cc[r][i] = tc[r][i];
+    }
   }
 }
 
@@ -386,7 +556,7 @@ int pack(const mmg_rel_t* rels, int n_rel, RelPack* rp, bool need_table, bool ne
     MMG_CHECK_ARG(!need_table || rels[r].table, "aggregate: relation %d has null table", r);
     MMG_CHECK_ARG(!need_out || rels[r].out, "aggregate: relation %d has null out", r);
     rp->r[r] = RelDev{rels[r].rowptr, rels[r].col, rels[r].rowscale, rels[r].colscale, rels[r].table,
-                      rels[r].out, rels[r].n_cols, off};
+                      rels[r].out, rels[r].n_cols, off, rels[r].flags};
     off += pad_cols ? ((rels[r].n_cols + 31) & ~31) : rels[r].n_cols;
   }
   return MMG_OK;
@@ -406,6 +576,35 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
   hipStream_t st = (hipStream_t)stream;
   int total_cols = 0;
   for (int r = 0; r < n_rel; ++r) total_cols += rels[r].n_cols;
+  // bf16-split matrix-core path: simple relations, tables + indicator tile fit LDS, D a multiple of 64
+  {
+    bool simple = true;
+    int vp = 0;
+    for (int r = 0; r < n_rel; ++r) { simple &= (rels[r].flags & MMG_REL_SIMPLE) != 0; vp += (rels[r].n_cols + 15) & ~15; }
+    // Measured on MI355X (x100, D=128): 0.53 ms per launch vs 0.16 ms for the LDS-table kernel below -- the
+    // 45 four-barrier stages per workgroup expose one global round trip each at one workgroup per CU.
+    // Kept (parity-tested, opt-in) as the base for a deeper-pipelined version: MMG_AGG_BF16=1.
+    static const int use_bf16 = [] { const char* e = getenv("MMG_AGG_BF16"); return e ? atoi(e) : 0; }();
+    const size_t lds = (size_t)(3 * GB_DH + GB_ROWS) * (vp + 8) * 2 + (size_t)MMG_MAX_REL * GB_ROWS * 4 + 2 * 32 * 32 * 4;
+    if (use_bf16 && simple && vp > 0 && lds <= GB_LDS_MAX && n_rows >= 256) {
+      RelPack rb = rp;
+      int off = 0;
+      for (int r = 0; r < n_rel; ++r) { rb.r[r].acc_off = off; off += (rels[r].n_cols + 15) & ~15; }
+      const int n_dh = D / GB_DH;
+      int64_t nblk = 256 / n_dh;
+      if (nblk < 1) nblk = 1;
+      const int64_t max_blk = (n_rows + 4 * GB_ROWS - 1) / (4 * GB_ROWS);
+      if (nblk > max_blk) nblk = max_blk;
+      int64_t rows_per_blk = (n_rows + nblk - 1) / nblk;
+      rows_per_blk = (rows_per_blk + GB_ROWS - 1) / GB_ROWS * GB_ROWS;
+      nblk = (n_rows + rows_per_blk - 1) / rows_per_blk;
+      (void)hipFuncSetAttribute((const void*)k_gather_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS_MAX);
+      hipLaunchKernelGGL(k_gather_bf16, dim3((unsigned)nblk, (unsigned)n_dh), dim3(256), lds, st, rb, n_rows, rows_per_blk, D,
+                         vp, out, accumulate);
+      MMG_CHECK_LAUNCH("gather_rows(bf16)");
+      return MMG_OK;
+    }
+  }
   // LDS-resident tables when a column chunk of every table fits; else the L2-served kernel
   int dc = D >= 128 ? 128 : 64;
   while (dc > 64 && (size_t)total_cols * dc * 4 > GL_LDS_BUDGET) dc >>= 1;

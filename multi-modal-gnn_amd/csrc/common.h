@@ -59,17 +59,19 @@ __host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, ui
 // folded prologue: dropout(relu(x*scale+shift)); returns the transformed value
 struct ProDev {
   const float* scale; const float* shift; int relu; float p; float inv_keep; uint64_t seed; uint32_t site;
-  int64_t row_offset;
+  int64_t row_offset; const uint64_t* seed_ptr;
+  // resolve a device-resident seed (hipGraph replays); call once at kernel entry
+  __device__ inline void resolve() { if (seed_ptr) seed = *seed_ptr; }
 };
 static inline ProDev mmg_pro_dev(const mmg_prologue_t* pro) {
   ProDev d;
   if (pro) {
     d.scale = pro->scale; d.shift = pro->shift; d.relu = pro->relu; d.p = pro->drop_p;
     d.inv_keep = pro->drop_p > 0.f ? 1.0f / (1.0f - pro->drop_p) : 1.0f;
-    d.seed = pro->seed; d.site = pro->site; d.row_offset = pro->row_offset;
+    d.seed = pro->seed; d.site = pro->site; d.row_offset = pro->row_offset; d.seed_ptr = pro->seed_ptr;
   } else {
     d.scale = nullptr; d.shift = nullptr; d.relu = 0; d.p = 0.f; d.inv_keep = 1.f; d.seed = 0; d.site = 0;
-    d.row_offset = 0;
+    d.row_offset = 0; d.seed_ptr = nullptr;
   }
   return d;
 }

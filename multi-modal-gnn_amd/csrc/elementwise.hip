@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ A,
                                                     ProDev pr, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, double* __restrict__ partial,
                                                     int64_t M, int N, int64_t rows_per_blk) {
+  pr.resolve();
   __shared__ double red[2 * 1024];   // [rl][2][N] with rl*N == 1024
   const int cg = N / 4, rl = 256 / cg;
   const int c4 = threadIdx.x % cg, rr = threadIdx.x / cg;
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ 
 
 __global__ __launch_bounds__(256) void k_affine_act_drop(const float* __restrict__ Y, ProDev pr, float* __restrict__ out,
                                                          int64_t M, int N) {
+  pr.resolve();
   const int64_t n4 = M * (int64_t)(N / 4);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / (N / 4);
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ c0, const float* __restrict__ c1,
                                                       float* __restrict__ dY, int64_t M, int N) {
+  pr.resolve();
   const int64_t n4 = M * (int64_t)(N / 4);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / (N / 4);
@@ -226,8 +229,9 @@ __global__ __launch_bounds__(256) void k_l2norm_bwd(const float* __restrict__ G,
   for (int j = 0; j < VEC; ++j) dZ[(size_t)row * N + lane * VEC + j] = r * (g[j] - o[j] * dot);
 }
 
-__global__ __launch_bounds__(256) void k_dropout_mask(uint64_t seed, uint32_t site, int64_t first, int64_t n, float p,
-                                                      uint8_t* mask) {
+__global__ __launch_bounds__(256) void k_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_t site, int64_t first,
+                                                      int64_t n, float p, uint8_t* mask) {
+  if (seed_ptr) seed = *seed_ptr;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) mask[i] = mmg_keep(seed, site, (uint64_t)(first + i), p) ? 1 : 0;
 }
@@ -350,12 +354,12 @@ extern "C" int mmg_l2norm_bwd(const float* G, const float* out, const float* rno
   return MMG_OK;
 }
 
-extern "C" int mmg_dropout_mask(uint64_t seed, uint32_t site, int64_t first_elem, int64_t n_elems, float p, uint8_t* mask,
-                                void* stream) {
+extern "C" int mmg_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_t site, int64_t first_elem, int64_t n_elems,
+                                float p, uint8_t* mask, void* stream) {
   MMG_CHECK_ARG(n_elems >= 0 && (mask || n_elems == 0), "dropout_mask: bad args");
   if (n_elems == 0) return MMG_OK;
-  hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, site,
-                     first_elem, n_elems, p, mask);
+  hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, seed_ptr,
+                     site, first_elem, n_elems, p, mask);
   MMG_CHECK_LAUNCH("dropout_mask");
   return MMG_OK;
 }

@@ -28,6 +28,7 @@ template <int K, int NTW, int OCC>
 __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict__ X, ProDev pr,
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        float* __restrict__ Y, int64_t M, int N, int accumulate) {
+  pr.resolve();
   constexpr int LDK = K + 4;            // row stride (floats): shifts rows by one 16-B slot
   constexpr int BN = 64 * NTW;
   __shared__ __attribute__((aligned(16))) float Xs[BM * LDK];
@@ -135,6 +136,7 @@ template <int K>
 __global__ __launch_bounds__(64) void k_linear_small(const float* __restrict__ X, ProDev pr,
                                                      const float* __restrict__ W, const float* __restrict__ bias,
                                                      float* __restrict__ Y, int64_t M, int N, int accumulate) {
+  pr.resolve();
   const int lane = threadIdx.x, h = lane >> 5, l31 = lane & 31;
   const int n0 = blockIdx.x * 32;
   const int64_t row0 = (int64_t)blockIdx.y * 32;
@@ -181,6 +183,7 @@ template <int TN, int TK>
 __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
                                                       ProDev pr, float* __restrict__ slab, int64_t M, int N, int K,
                                                       int64_t rows_per_split) {
+  pr.resolve();
   // grid: x = output tile (tn-major over N/TN x K/TK), y = row split
   constexpr int MT = TN / 64, KT = TK / 64;   // 32x32 tiles per wave along n and k
   __shared__ __attribute__((aligned(16))) float Ys[WG_ROWS][TN];

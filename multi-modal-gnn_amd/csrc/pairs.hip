@@ -52,36 +52,6 @@ __device__ inline float head_unit2(const float* W2s, const float* b2s, const flo
   return s;
 }
 
-__global__ __launch_bounds__(PT) void k_pair_fwd(HeadDev H, const int32_t* __restrict__ pi, const int32_t* __restrict__ li,
-                                                 const int32_t* __restrict__ deg, int thr, int want_low, int64_t n,
-                                                 float drop_p, uint64_t seed, const int64_t* __restrict__ pair_id,
-                                                 float* __restrict__ pred) {
-  __shared__ __attribute__((aligned(16))) float W2s[32 * 64];
-  __shared__ float b2s[32], W3s[32];
-  for (int i = threadIdx.x; i < 2048; i += PT) W2s[i] = H.W2[i];
-  if (threadIdx.x < 32) { b2s[threadIdx.x] = H.b2[threadIdx.x]; W3s[threadIdx.x] = H.W3[threadIdx.x]; }
-  __syncthreads();
-  const float b3 = H.b3[0];
-  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  for (int64_t k = (int64_t)blockIdx.x * PT + threadIdx.x; k < n; k += (int64_t)gridDim.x * PT) {
-    const int p_i = pi[k];
-    const bool low = deg[p_i] < thr;
-    if ((int)low != want_low) continue;
-    const uint64_t pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
-    float h1[64];
-    head_layer1(H, p_i, li[k], pid, drop_p, inv_keep, seed, h1);
-    float o = b3;
-    // rolled on purpose: a full unroll lets the scheduler hoist all 512 LDS weight reads (spills)
-#pragma unroll 2
-    for (int i = 0; i < 32; ++i) {
-      float v = fmaxf(head_unit2(W2s, b2s, h1, i), 0.f);
-      if (drop_p > 0.f) v = mmg_keep(seed, SITE_H2, pid * 32ull + i, drop_p) ? v * inv_keep : 0.f;
-      o = fmaf(W3s[i], v, o);
-    }
-    pred[k] = o;
-  }
-}
-
 // ---------------------------------------------------------------------------- backward
 // LDS layout (floats).  T1t/T2t are TRANSPOSED tiles [unit][pair] with row stride LDT so that
 // thread-per-pair writes are conflict-free and the dW2 pass reads 4 pairs per ds_read_b128.
@@ -103,8 +73,10 @@ constexpr size_t BWD_LDS_MAX = 160 * 1024;
 __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                  const int32_t* __restrict__ li, const int32_t* __restrict__ deg, int thr,
                                                  int want_low, int64_t n, int n_labs, int lds_db, float drop_p,
-                                                 uint64_t seed, const int64_t* __restrict__ pair_id,
+                                                 uint64_t seed, const uint64_t* __restrict__ seed_ptr,
+                                                 const int64_t* __restrict__ pair_id,
                                                  const float* __restrict__ dpred) {
+  if (seed_ptr) seed = *seed_ptr;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* W2s = sm + OFF_W2; float* b2s = sm + OFF_B2; float* W3s = sm + OFF_W3;
   float* T1t = sm + OFF_T1; float* T2t = sm + OFF_T2;
@@ -241,8 +213,10 @@ template <int LT>
 __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                        const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                        int thr, int want_low, int64_t n, int n_labs, float drop_p,
-                                                       uint64_t seed, const int64_t* __restrict__ pair_id,
+                                                       uint64_t seed, const uint64_t* __restrict__ seed_ptr,
+                                                       const int64_t* __restrict__ pair_id,
                                                        const float* __restrict__ dpred) {
+  if (seed_ptr) seed = *seed_ptr;
   __shared__ __attribute__((aligned(16))) float sm[4 * WAVE_LDS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -465,7 +439,9 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32_t* __restrict__ pi,
                                                           const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                           int thr, int want_low, int64_t n, float drop_p, uint64_t seed,
+                                                          const uint64_t* __restrict__ seed_ptr,
                                                           const int64_t* __restrict__ pair_id, float* __restrict__ pred) {
+  if (seed_ptr) seed = *seed_ptr;
   __shared__ unsigned PL[4][TP], PH[4][TP];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -584,7 +560,7 @@ int check_head(const mmg_head_t* h, const char* what) {
 
 extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
                                  int degree_threshold, int want_low, int64_t n_pairs, float drop_p, uint64_t seed,
-                                 const int64_t* pair_id, float* pred, void* stream) {
+                                 const uint64_t* seed_ptr, const int64_t* pair_id, float* pred, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0, "pair_head_fwd: n_pairs < 0");
   if (n_pairs == 0) return MMG_OK;
   int rc = check_head(head, "pair_head_fwd");
@@ -596,14 +572,15 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(k_pair_fwd_mfma, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, H, pi, li, deg,
-                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, pair_id, pred);
+                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred);
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;
 }
 
 extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi, const int32_t* li,
                                  const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
-                                 float drop_p, uint64_t seed, const int64_t* pair_id, const float* dpred, void* stream) {
+                                 float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
+                                 const float* dpred, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0 && n_labs >= 0, "pair_head_bwd: negative size");
   if (n_pairs == 0) return MMG_OK;
   int rc = check_head(head, "pair_head_bwd");
@@ -622,7 +599,7 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     if (g < 1) g = 1;
 #define MMG_LAUNCH_PBWD(LT_)                                                                                          \
   hipLaunchKernelGGL((k_pair_bwd_mfma<LT_>), dim3((unsigned)g), dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, \
-                     want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, pair_id, dpred)
+                     want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, seed_ptr, pair_id, dpred)
     if (n_labs <= 64) MMG_LAUNCH_PBWD(2);
     else MMG_LAUNCH_PBWD(4);
 #undef MMG_LAUNCH_PBWD
@@ -638,7 +615,7 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     int64_t g = (n_pairs + PT - 1) / PT;
     if (g > 512) g = 512;
     hipLaunchKernelGGL(k_pair_bwd, dim3((unsigned)g), dim3(PT), lds, st, H, G, pi, li, deg, degree_threshold,
-                       want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, pair_id, dpred);
+                       want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, seed_ptr, pair_id, dpred);
   }
   MMG_CHECK_LAUNCH("pair_head_bwd");
   return MMG_OK;

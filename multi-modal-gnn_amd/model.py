@@ -139,6 +139,7 @@ class HeteroRGCN(nn.Module):
 
         self._comm = None            # set by dist.shard_model(): patient-axis sharding
         self._dropout_seed = None    # tests pin the dropout stream through this
+        self._seed_dev = None        # int64[1] device tensor: dropout seed read at run time (hipGraph replays)
         self._pair_cache = {}
         self._last_run = None
 
@@ -236,7 +237,8 @@ class _Run:
         self.plan: GraphPlan = data if isinstance(data, GraphPlan) else build_plan(data, self.dev)
         self.T = model.training
         self.p = float(model.dropout) if self.T else 0.0
-        if self.p > 0:
+        self.seed_dev = model._seed_dev if self.p > 0 else None
+        if self.p > 0 and self.seed_dev is None:
             self.seed = model._dropout_seed if model._dropout_seed is not None else int(
                 torch.randint(0, 2 ** 62, (1,)).item())
         else:
@@ -393,10 +395,10 @@ class _Run:
         off = self.plan.row_offset
         z1 = ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach())
         f1 = self.bn_fold(z1, pt[1], n_updates, sharded=True)
-        pro1 = Pro(f1.scale, f1.shift, True, self.p, self.seed, 2 * call, off)
+        pro1 = Pro(f1.scale, f1.shift, True, self.p, self.seed, 2 * call, off, self.seed_dev)
         z2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1)
         f2 = self.bn_fold(z2, pt[5], n_updates, sharded=True)
-        pro2 = Pro(f2.scale, f2.shift, True, self.p, self.seed, 2 * call + 1, off)
+        pro2 = Pro(f2.scale, f2.shift, True, self.p, self.seed, 2 * call + 1, off, self.seed_dev)
         z3 = ops.linear_fwd(z2, pt[8].weight.detach(), pt[8].bias.detach(), pro=pro2)
         x0, rn = ops.l2norm_fwd(z3)
         return dict(E=E, z1=z1, z2=z2, x0=x0, rn=rn, f1=f1, f2=f2, pro1=pro1, pro2=pro2)
@@ -474,7 +476,7 @@ class _Run:
             rels = []
             for r, nme in zip(rin, names):
                 Tv = ops.linear_fwd(x[r.other], self.W(nme + ".lin_l.weight"))
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv))
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv, simple=r.simple))
             ops.gather_rows(rels, P, D, yP, accumulate=True)
             y[ROW_TYPE] = yP
             rec["Wsum"] = Wsum
@@ -485,7 +487,7 @@ class _Run:
             for r in rout:
                 agg = buf[off:off + r.n_cols]
                 off += r.n_cols
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg))
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg, simple=r.simple))
                 aggs.append(agg)
             ops.scatter_rows(rels, P, D, xP)
             self.allreduce(buf)                          # partial sums over patient shards
@@ -506,7 +508,7 @@ class _Run:
             sharded = t == ROW_TYPE
             fold = self.bn_fold(y[t], self.m.batch_norms[l][t], 1, sharded) if self.m.use_batch_norm else None
             pro = Pro(fold.scale if fold else None, fold.shift if fold else None, True, p, self.seed,
-                      SITE_CONV + 8 * l + ti, plan.row_offset if sharded else 0)
+                      SITE_CONV + 8 * l + ti, plan.row_offset if sharded else 0, self.seed_dev)
             out[t] = ops.affine_act_drop(y[t], pro)
             folds[t], pros[t] = fold, pro
         rec.update(y=y, folds=folds, pros=pros, l=l)
@@ -544,7 +546,7 @@ class _Run:
             for r in rec["rin"]:
                 dT = buf[off:off + r.n_cols]
                 off += r.n_cols
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=dT))
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=dT, simple=r.simple))
                 dTs.append(dT)
             ops.scatter_rows(rels, P, D, dyP)
             self.allreduce(buf)
@@ -567,7 +569,7 @@ class _Run:
                 self.acc(nme + ".lin_r.weight", ops.linear_wgrad(dyv, x[r.other]))
                 add(r.other, ops.linear_fwd(dyv, self.W(nme + ".lin_r.weight").t().contiguous()))
                 dagg = ops.linear_fwd(dyv, self.W(nme + ".lin_l.weight").t().contiguous())
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=dagg))
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=dagg, simple=r.simple))
             if rels:
                 if g_in[ROW_TYPE] is None:
                     g_in[ROW_TYPE] = torch.empty(P, D, device=self.dev)
@@ -598,7 +600,7 @@ class _Run:
         rec = dict(init=init, fin=fin)
         for which, src, want_low in (("edge_predictor", fin, False), ("tabular_mlp", init, True)):
             head, w1a, w1b = self.head_tensors(which, src[ROW_TYPE], src["lab"])
-            ops.pair_head_fwd(head, pi, li, plan.lab_deg, thr, want_low, self.p, self.seed, ids, pred_s)
+            ops.pair_head_fwd(head, pi, li, plan.lab_deg, thr, want_low, self.p, self.seed, ids, pred_s, self.seed_dev)
             rec[which] = (head, w1a, w1b)
         pred = torch.empty_like(pred_s)
         pred[perm] = pred_s                      # back to the caller's pair order
@@ -615,7 +617,7 @@ class _Run:
             head, w1a, w1b = rec[which]
             g = ops.Head(torch.zeros_like(head.A), torch.zeros_like(head.B), torch.zeros_like(head.W2),
                          torch.zeros_like(head.b2), torch.zeros_like(head.W3), torch.zeros_like(head.b3))
-            ops.pair_head_bwd(head, g, pi, li, plan.lab_deg, thr, want_low, n_lab, self.p, self.seed, ids, dps)
+            ops.pair_head_bwd(head, g, pi, li, plan.lab_deg, thr, want_low, n_lab, self.p, self.seed, ids, dps, self.seed_dev)
             self.allreduce(g.B)                  # lab-side partials from sharded pairs
             self.acc(f"{which}.mlp.3.weight", g.W2, partial=True)
             self.acc(f"{which}.mlp.3.bias", g.b2, partial=True)

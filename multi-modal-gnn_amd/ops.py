@@ -107,10 +107,12 @@ class Pro:
     seed: int = 0
     site: int = 0
     row_offset: int = 0
+    seed_dev: Optional[torch.Tensor] = None     # int64 [1] on the device: overrides `seed` at run time (hipGraph replays)
 
     def c(self):
         return PrologueT(_p(self.scale, name="pro.scale"), _p(self.shift, name="pro.shift"), int(self.relu),
-                         float(self.p), int(self.seed) & 0xFFFFFFFFFFFFFFFF, int(self.site), int(self.row_offset))
+                         float(self.p), int(self.seed) & 0xFFFFFFFFFFFFFFFF, int(self.site), int(self.row_offset),
+                         _p(self.seed_dev, torch.int64, "pro.seed_dev"))
 
 
 def _pro(pro: Optional[Pro]):
@@ -164,6 +166,7 @@ class Rel:
     colscale: Optional[torch.Tensor] = None
     table: Optional[torch.Tensor] = None
     out: Optional[torch.Tensor] = None
+    simple: bool = False          # no duplicate (row, col) pair (MMG_REL_SIMPLE)
 
 
 def _agg_bytes(rels, n_rows, D, accumulate):
@@ -189,7 +192,7 @@ def _rels(rels: Sequence[Rel], D: int, need_table=False, need_out=False):
         if need_out and (r.out is None or tuple(r.out.shape) != (r.n_cols, D)):
             raise ValueError(f"relation {i}: out must be [{r.n_cols},{D}]")
         arr[i] = RelT(_p(r.rowptr, torch.int32), _p(r.col, torch.int32), _p(r.rowscale), _p(r.colscale),
-                      _p(r.table), _p(r.out), r.n_cols)
+                      _p(r.table), _p(r.out), r.n_cols, 1 if r.simple else 0)
     return arr
 
 
@@ -359,13 +362,13 @@ def l2norm_bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor):
     return dz
 
 
-def dropout_mask(seed: int, site: int, n_rows: int, width: int, p: float, device, row_offset: int = 0):
+def dropout_mask(seed: int, site: int, n_rows: int, width: int, p: float, device, row_offset: int = 0, seed_dev=None):
     """The keep-mask ([n_rows, width] uint8) the kernels draw for (seed, site) -- used to inject the
     same masks into the CPU oracle in parity tests."""
     lib = _lib.load()
     m = torch.empty(n_rows, width, dtype=torch.uint8, device=device)
-    check(lib.mmg_dropout_mask(seed & 0xFFFFFFFFFFFFFFFF, site, row_offset * width, n_rows * width, float(p),
-                               _p(m, torch.uint8), _stream()), "mmg_dropout_mask")
+    check(lib.mmg_dropout_mask(seed & 0xFFFFFFFFFFFFFFFF, _p(seed_dev, torch.int64), site, row_offset * width,
+                               n_rows * width, float(p), _p(m, torch.uint8), _stream()), "mmg_dropout_mask")
     return m
 
 
@@ -383,19 +386,19 @@ class Head:
         return HeadT(_p(self.A), _p(self.B), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3))
 
 
-def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred):
+def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred, seed_dev=None):
     lib = _lib.load()
     n = pi.numel()
     h = head.c()
     _tok = _pb("pair_head_fwd")
     check(lib.mmg_pair_head_fwd(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
-                                int(want_low), n, float(p), seed & 0xFFFFFFFFFFFFFFFF, _p(pair_id, torch.int64),
-                                _p(pred), _stream()), "mmg_pair_head_fwd")
+                                int(want_low), n, float(p), seed & 0xFFFFFFFFFFFFFFFF, _p(seed_dev, torch.int64),
+                                _p(pair_id, torch.int64), _p(pred), _stream()), "mmg_pair_head_fwd")
     _pe(_tok, "pair_head_fwd", n * 12 + 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (64 * 32 + 32 + 64))
 
 
 def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool, n_labs: int, p: float, seed: int,
-                  pair_id, dpred):
+                  pair_id, dpred, seed_dev=None):
     """`grads` mirrors `head` (dA,dB,dW2,db2,dW3,db3), accumulated in place."""
     lib = _lib.load()
     n = pi.numel()
@@ -404,5 +407,6 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
     _tok = _pb("pair_head_bwd")
     check(lib.mmg_pair_head_bwd(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32),
                                 thr, int(want_low), n, n_labs, float(p), seed & 0xFFFFFFFFFFFFFFFF,
-                                _p(pair_id, torch.int64), _p(dpred), _stream()), "mmg_pair_head_bwd")
+                                _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _stream()),
+          "mmg_pair_head_bwd")
     _pe(_tok, "pair_head_bwd", n * 12 + 2 * 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (4 * 64 * 32))

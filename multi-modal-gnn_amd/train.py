@@ -227,3 +227,57 @@ class Trainer:
         ck = torch.load(Path(output_dir) / "best_model.pt", map_location=self.device, weights_only=False)
         self.model.load_state_dict(ck["model_state_dict"])
         logging.info(f"Loaded best model from epoch {ck['epoch']} (val_loss: {ck['val_loss']:.4f})")
+
+
+class GraphedTrainStep:
+    """One whole training step -- zero_grad, predict_lab_values, weighted loss, backward, optimizer.step --
+    captured ONCE into a hipGraph and replayed per epoch (the eICU-scale graph is launch-bound: ~250 kernel
+    launches of a few microseconds each).  Shapes are static: the per-epoch supervision mask is a float
+    vector updated in place, the dropout seed lives in device memory and is redrawn before every replay.
+
+    Same arithmetic as ``Trainer.train_epoch`` (train.py:332-392 of the reference) with the boolean indexing
+    ``pred[mask]`` replaced by a multiplication with the mask.
+    """
+
+    def __init__(self, model, data, pi, li, y, lab_weights, optimizer, sup_mask, loss_fn: str = "mae",
+                 n_sup_global: Optional[float] = None, warmup: int = 3):
+        self.model, self.data, self.opt = model, data, optimizer
+        dev = pi.device
+        self.pi, self.li, self.y = pi, li, y
+        self.wl = lab_weights[li].contiguous()
+        self.sup = sup_mask.to(torch.float32).contiguous()          # update in place: set_mask()
+        self.n_sup_global = n_sup_global
+        self.loss_fn = loss_fn
+        if loss_fn not in ("mae", "mse"):
+            raise ValueError(f"GraphedTrainStep supports 'mae'/'mse', got {loss_fn}")
+        model._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.loss = torch.zeros((), device=dev)
+        model.train()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+
+    def _body(self):
+        self.opt.zero_grad(set_to_none=True)
+        pred = self.model.predict_lab_values(self.data, self.pi, self.li)
+        d = pred - self.y
+        per = d.abs() if self.loss_fn == "mae" else d * d
+        den = self.sup.sum() if self.n_sup_global is None else self.n_sup_global
+        loss = (per * self.wl * self.sup).sum() / den
+        loss.backward()
+        self.opt.step()
+        self.loss.copy_(loss.detach())
+
+    def set_mask(self, sup_mask):
+        self.sup.copy_(sup_mask.to(torch.float32))
+
+    def step(self) -> torch.Tensor:
+        self.model._seed_dev.random_(0, 2 ** 62)     # fresh dropout masks for this replay
+        self.graph.replay()
+        return self.loss

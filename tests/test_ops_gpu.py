@@ -140,6 +140,62 @@ def test_scatter_rows_rowscale_and_global_atomic_fallback(ops, dev):
     assert rel(out, ref) <= 1e-5
 
 
+def simple_edges(gen, n_rows, n_cols, max_deg):
+    """Edges without duplicate (row, col) pairs and with ragged degrees (some rows empty)."""
+    order = torch.rand(n_rows, n_cols, generator=gen).argsort(1)
+    deg = torch.randint(0, min(max_deg, n_cols) + 1, (n_rows,), generator=gen)
+    deg[::7] = 0
+    keep = torch.arange(n_cols)[None, :] < deg[:, None]
+    r, k = torch.nonzero(keep, as_tuple=True)
+    ei = torch.stack([r, order[r, k]])
+    return ei[:, torch.randperm(ei.shape[1], generator=gen)].contiguous()
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("n_rows", [257, 1834, 5000])
+def test_aggregates_simple_graph_paths(ops, dev, D, n_rows):
+    """MMG_REL_SIMPLE relations (no repeated (row, col) pair).  With MMG_AGG_BF16=1 the gather takes the
+    0/1-indicator x 3-way bf16 split matrix-core kernel: products are exact, so either way the result must be
+    fp32-accurate (1e-6 of an fp64 reference)."""
+    gen = torch.Generator().manual_seed(7 * D + n_rows)
+    sizes, degs = [50, 114, 100], [50, 9, 25]
+    x = torch.randn(n_rows, D, generator=gen) * 3 + 0.5
+    grels, srels, gref, srefs = [], [], torch.zeros(n_rows, D, dtype=torch.float64), []
+    for nc, md in zip(sizes, degs):
+        ei = simple_edges(gen, n_rows, nc, md)
+        tab = torch.randn(nc, D, generator=gen) * 2 - 0.3
+        rp, col = _csr(ops, dev, ei, n_rows)
+        _, inv = ops.row_degree(rp)
+        cnt, cinv = ops.col_degree(col, nc)
+        grels.append(ops.Rel(rp, col, nc, rowscale=inv, colscale=cinv, table=tab.to(dev), simple=True))
+        gref += scatter_mean((tab.double() * cinv.cpu().double()[:, None]), ei.flip(0), n_rows)
+        out = torch.full((nc, D), -3.0, device=dev)
+        srels.append(ops.Rel(rp, col, nc, colscale=cinv, out=out, simple=True))
+        srefs.append(scatter_mean(x.double(), ei, nc))
+    base = torch.randn(n_rows, D, generator=gen)
+    o = base.to(dev).clone()
+    ops.gather_rows(grels, n_rows, D, o, accumulate=True)
+    assert rel(o, gref + base.double()) <= 1e-6
+    o2 = torch.empty(n_rows, D, device=dev)
+    ops.gather_rows(grels, n_rows, D, o2, accumulate=False)
+    assert rel(o2, gref) <= 1e-6
+    ops.scatter_rows(srels, n_rows, D, x.to(dev))
+    for r, ref in zip(srels, srefs):
+        assert rel(r.out, ref) <= 1e-6
+    # backward use of scatter: per-relation rowscale
+    for r in srels:
+        r.colscale = None
+    rs = [torch.rand(n_rows, generator=gen) + 0.25 for _ in srels]
+    for r, w in zip(srels, rs):
+        r.rowscale = w.to(dev)
+    ops.scatter_rows(srels, n_rows, D, x.to(dev))
+    for r, w in zip(srels, rs):
+        ei_r = torch.stack([torch.repeat_interleave(torch.arange(n_rows), (r.rowptr[1:] - r.rowptr[:-1]).cpu().long()),
+                            r.col.cpu().long()])
+        ref = torch.zeros(r.n_cols, D, dtype=torch.float64).index_add_(0, ei_r[1], (x.double() * w.double()[:, None])[ei_r[0]])
+        assert rel(r.out, ref) <= 1e-6
+
+
 # ------------------------------------------------------------------------------------------ dense
 @pytest.mark.parametrize("M,N,K", [(1, 64, 64), (50, 128, 128), (1834, 128, 128), (1834, 64, 128), (1000, 128, 64),
                                    (777, 256, 256), (333, 64, 256), (114, 128, 128), (5000, 256, 128)])
