@@ -107,7 +107,8 @@ def build_workload(args, world, rank, dev):
     n_sup_global = torch.tensor([float(sup.sum())], device=dev)
     if comm is not None:
         torch.distributed.all_reduce(n_sup_global)
-    return dict(model=model, plan=plan, g=g, pi=pi, li=li, y=y, sup=sup, wlab=wlab, opt=opt, E=E,
+    return dict(model=model, plan=plan, g=g, pi=pi, li=li, y=y, sup=sup, supf=sup.float(), wpair=wlab[li].contiguous(),
+                wlab=wlab, opt=opt, E=E,
                 n_sup=float(n_sup_global), comm=comm)
 
 
@@ -116,9 +117,8 @@ def train_step(w):
     model.train()
     opt.zero_grad(set_to_none=True)
     pred = model.predict_lab_values(w["plan"], w["pi"], w["li"])
-    sup = w["sup"]
-    per = (pred[sup] - w["y"][sup]).abs() * w["wlab"][w["li"][sup]]
-    loss = per.sum() / w["n_sup"]            # global mean over all shards' supervised pairs
+    # weighted MAE over the supervision subset (train.py:366-386), global mean over all shards: one fused pass
+    loss = ops.weighted_pair_loss(pred, w["y"], w["wpair"], w["supf"], 1.0 / w["n_sup"], "mae")
     loss.backward()
     opt.step()
     return loss
@@ -203,6 +203,9 @@ def main():
     step_fn = (lambda: gstep.step()) if gstep is not None else (lambda: train_step(w))
     for _ in range(max(args.warmup, 1)):
         step_fn()
+    if os.environ.get("MMG_BENCH_DEBUG"):
+        torch.cuda.synchronize()
+        print("[debug] loss after warm-up", float(step_fn().detach()) if gstep is None else float(gstep.loss), file=sys.stderr)
 
     # ---- timed region: exactly K steps
     prof = ops.OpProfiler(only=[dominant])
@@ -212,6 +215,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step_fn()
+        if os.environ.get("MMG_BENCH_DEBUG"):
+            torch.cuda.synchronize()
+            print("[debug] step loss", float(loss.detach()), "seed", int(w["model"]._seed_dev) if w["model"]._seed_dev is not None else None, file=sys.stderr)
     barrier()
     dt = time.perf_counter() - t0
     ops.set_profiler(None)

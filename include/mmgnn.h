@@ -152,6 +152,15 @@ int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, f
 int mmg_l2norm_bwd(const float* G, const float* out, const float* rnorm, float* dZ, int64_t M, int N,
                    float eps, void* stream);
 
+/* Weighted, masked regression loss over the prediction pairs and its gradient in ONE pass
+ * (src/train.py:366-386 of the reference: mean(|p - y| * w[lab]) over the supervision subset):
+ *   loss = inv_den * sum_k sup[k] * w[k] * (|p_k - y_k|  or  (p_k - y_k)^2)        (fp64 accumulation)
+ *   dpred[k] = inv_den * sup[k] * w[k] * (sign(p_k - y_k)  or  2 (p_k - y_k))
+ * sup / w may be NULL (= 1).  loss_type 0 = mae, 1 = mse.  `loss` is ONE double on the device. */
+size_t mmg_pair_loss_ws_bytes(int64_t n);
+int mmg_pair_loss(const float* pred, const float* y, const float* w, const float* sup, int64_t n, double inv_den,
+                  int loss_type, float* dpred, double* loss, void* ws, size_t ws_bytes, void* stream);
+
 /* keep-mask of the dropout RNG, for injected-mask parity tests: mask[i] in {0,1}     */
 int mmg_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_t site, int64_t first_elem, int64_t n_elems,
                      float p, uint8_t* mask, void* stream);

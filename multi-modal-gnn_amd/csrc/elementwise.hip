@@ -236,6 +236,29 @@ __global__ __launch_bounds__(256) void k_dropout_mask(uint64_t seed, const uint6
   if (i < n) mask[i] = mmg_keep(seed, site, (uint64_t)(first + i), p) ? 1 : 0;
 }
 
+constexpr int PL_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void k_pair_loss(const float* __restrict__ pred, const float* __restrict__ y,
+                                                   const float* __restrict__ w, const float* __restrict__ sup, int64_t n,
+                                                   double inv_den, int loss_type, float* __restrict__ dpred,
+                                                   double* __restrict__ partial) {
+  __shared__ double red[4];
+  double s = 0;
+  const float invf = (float)inv_den;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    const float d = pred[k] - y[k];
+    const float ws = (w ? w[k] : 1.f) * (sup ? sup[k] : 1.f);
+    float per, g;
+    if (loss_type == 0) { per = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    else { per = d * d; g = 2.f * d; }
+    s += (double)(per * ws);
+    if (dpred) dpred[k] = g * ws * invf;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * inv_den;
+}
+
 inline unsigned ew_grid(int64_t n4) {
   int64_t b = (n4 + 255) / 256;
   if (b > 256 * 128) b = 256 * 128;   // everything in flight: these passes are pure HBM streams
@@ -251,6 +274,10 @@ int run_col_reduce(const float* A, const float* B, const ProDev& pr, const float
   const size_t need = (size_t)g.nblk * 2 * N * 8 + 256;
   if (ws_bytes < need) { mmg_set_error("%s: workspace %zu < %zu", what, ws_bytes, need); return MMG_E_WS; }
   double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  if (g.nblk == 1) {      // small tables (vocab side): the single workgroup's result IS the answer
+    hipLaunchKernelGGL(k_col_reduce<MODE>, dim3(1), dim3(256), 0, st, A, B, pr, mean, rstd, out, M, N, g.rows_per_blk);
+    return MMG_OK;
+  }
   hipLaunchKernelGGL(k_col_reduce<MODE>, dim3(g.nblk), dim3(256), 0, st, A, B, pr, mean, rstd, partial, M, N,
                      g.rows_per_blk);
   hipLaunchKernelGGL(k_partial_sum, dim3((2 * N + 3) / 4), dim3(256), 0, st, partial, out, 2 * N, g.nblk);
@@ -361,5 +388,24 @@ extern "C" int mmg_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_
   hipLaunchKernelGGL(k_dropout_mask, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, seed_ptr,
                      site, first_elem, n_elems, p, mask);
   MMG_CHECK_LAUNCH("dropout_mask");
+  return MMG_OK;
+}
+
+extern "C" size_t mmg_pair_loss_ws_bytes(int64_t n) { return n < 0 ? 0 : (size_t)PL_BLOCKS * 8 + 256; }
+
+extern "C" int mmg_pair_loss(const float* pred, const float* y, const float* w, const float* sup, int64_t n, double inv_den,
+                             int loss_type, float* dpred, double* loss, void* ws, size_t ws_bytes, void* stream) {
+  MMG_CHECK_ARG(n >= 0 && loss && ws, "pair_loss: bad args");
+  MMG_CHECK_ARG(loss_type == 0 || loss_type == 1, "pair_loss: loss_type must be 0 (mae) or 1 (mse)");
+  MMG_CHECK_ARG(n == 0 || (pred && y), "pair_loss: null buffer");
+  if (ws_bytes < mmg_pair_loss_ws_bytes(n)) { mmg_set_error("pair_loss: workspace too small"); return MMG_E_WS; }
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  int64_t nb = (n + 255) / 256;
+  if (nb > PL_BLOCKS) nb = PL_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(k_pair_loss, dim3((unsigned)nb), dim3(256), 0, st, pred, y, w, sup, n, inv_den, loss_type, dpred, partial);
+  hipLaunchKernelGGL(k_partial_sum, dim3(1), dim3(256), 0, st, partial, loss, 1, (int)nb);
+  MMG_CHECK_LAUNCH("pair_loss");
   return MMG_OK;
 }

@@ -182,7 +182,7 @@ constexpr int WG_ROWS = 32;   // rows reduced per LDS stage
 template <int TN, int TK>
 __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
                                                       ProDev pr, float* __restrict__ slab, int64_t M, int N, int K,
-                                                      int64_t rows_per_split) {
+                                                      int64_t rows_per_split, int direct_accumulate) {
   pr.resolve();
   // grid: x = output tile (tn-major over N/TN x K/TK), y = row split
   constexpr int MT = TN / 64, KT = TK / 64;   // 32x32 tiles per wave along n and k
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
         for (int y = 0; y < KT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
     }
   }
-  // slab[split][N][K]
+  // slab[split][N][K]; with a single split `slab` is dW itself (direct_accumulate: 1 = overwrite, 2 = add)
   float* dst = slab + (size_t)blockIdx.y * N * K;
 #pragma unroll
   for (int x = 0; x < MT; ++x)
@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
       for (int i = 0; i < 16; ++i) {
         const int n = tn0 + wn * (TN / 2) + x * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         const int k = tk0 + wk * (TK / 2) + y * 32 + l31;
-        dst[(size_t)n * K + k] = acc[x][y][i];
+        float v = acc[x][y][i];
+        if (direct_accumulate == 2) v += dst[(size_t)n * K + k];
+        dst[(size_t)n * K + k] = v;
       }
 }
 
@@ -292,6 +294,7 @@ WgradPlan plan_wgrad(int64_t M, int N, int K) {
   int64_t want = 512 / p.n_tiles;
   if (want < 1) want = 1;
   p.n_split = (int)(want < max_split ? want : max_split);
+  if (M <= 256) p.n_split = 1;            // vocab-side tables: one workgroup per output tile, direct write
   int64_t rps = (M + p.n_split - 1) / p.n_split;
   rps = (rps + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
   if (rps < WG_ROWS) rps = WG_ROWS;
@@ -380,17 +383,21 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
   float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   const ProDev pr = mmg_pro_dev(pro);
   dim3 grid((unsigned)p.n_tiles, (unsigned)p.n_split);
+  const int direct = p.n_split == 1 ? (accumulate ? 2 : 1) : 0;     // small M: no slab, no reduce launch
+  float* target = direct ? dW : slab;
   if (p.TN == 128 && p.TK == 128)
-    hipLaunchKernelGGL((k_linear_wgrad<128, 128>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
+    hipLaunchKernelGGL((k_linear_wgrad<128, 128>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
   else if (p.TN == 128)
-    hipLaunchKernelGGL((k_linear_wgrad<128, 64>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
+    hipLaunchKernelGGL((k_linear_wgrad<128, 64>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
   else if (p.TK == 128)
-    hipLaunchKernelGGL((k_linear_wgrad<64, 128>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
+    hipLaunchKernelGGL((k_linear_wgrad<64, 128>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
   else
-    hipLaunchKernelGGL((k_linear_wgrad<64, 64>), grid, dim3(256), 0, st, dY, X, pr, slab, M, N, K, p.rows_per_split);
-  const int64_t n = (int64_t)N * K;
-  hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiStore>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4,
-                     p.n_split, EpiStore{dW, accumulate});
+    hipLaunchKernelGGL((k_linear_wgrad<64, 64>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
+  if (!direct) {
+    const int64_t n = (int64_t)N * K;
+    hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiStore>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4,
+                       p.n_split, EpiStore{dW, accumulate});
+  }
   MMG_CHECK_LAUNCH("linear_wgrad");
   return MMG_OK;
 }

@@ -410,3 +410,37 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
                                 _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _stream()),
           "mmg_pair_head_bwd")
     _pe(_tok, "pair_head_bwd", n * 12 + 2 * 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (4 * 64 * 32))
+
+
+# ------------------------------------------------------------------------------------------ loss
+def pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae"):
+    """-> (loss fp64 scalar tensor, dpred [n]) in one pass (mmg_pair_loss)."""
+    lib = _lib.load()
+    n = pred.numel()
+    dpred = torch.empty_like(pred)
+    loss = torch.empty((), dtype=torch.float64, device=pred.device)
+    ws = workspace(lib.mmg_pair_loss_ws_bytes(n), pred.device)
+    lt = {"mae": 0, "mse": 1}[loss_type]
+    _tok = _pb("pair_loss")
+    check(lib.mmg_pair_loss(_p(pred), _p(y), _p(w), _p(sup), n, float(inv_den), lt, _p(dpred), _p(loss, torch.float64),
+                            _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_pair_loss")
+    _pe(_tok, "pair_loss", 20 * n)
+    return loss, dpred
+
+
+class _PairLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, y, w, sup, inv_den, loss_type):
+        loss, dpred = pair_loss(pred.detach().contiguous(), y, w, sup, inv_den, loss_type)
+        ctx.save_for_backward(dpred)
+        return loss.float()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None, None, None, None
+
+
+def weighted_pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae"):
+    """Differentiable fused loss: inv_den * sum sup*w*|pred-y| (or squared); w/sup are per-pair float vectors."""
+    return _PairLossFn.apply(pred, y, w, sup, inv_den, loss_type)

@@ -246,6 +246,7 @@ class GraphedTrainStep:
         self.pi, self.li, self.y = pi, li, y
         self.wl = lab_weights[li].contiguous()
         self.sup = sup_mask.to(torch.float32).contiguous()          # update in place: set_mask()
+        self._n_sup = float(self.sup.sum())                          # baked into the graph: see set_mask()
         self.n_sup_global = n_sup_global
         self.loss_fn = loss_fn
         if loss_fn not in ("mae", "mse"):
@@ -264,17 +265,21 @@ class GraphedTrainStep:
             self._body()
 
     def _body(self):
+        from . import ops
         self.opt.zero_grad(set_to_none=True)
         pred = self.model.predict_lab_values(self.data, self.pi, self.li)
-        d = pred - self.y
-        per = d.abs() if self.loss_fn == "mae" else d * d
-        den = self.sup.sum() if self.n_sup_global is None else self.n_sup_global
-        loss = (per * self.wl * self.sup).sum() / den
+        if self.n_sup_global is None:
+            inv_den = 1.0 / max(float(self._n_sup), 1.0)
+        else:
+            inv_den = 1.0 / float(self.n_sup_global)
+        loss = ops.weighted_pair_loss(pred, self.y, self.wl, self.sup, inv_den, self.loss_fn)
         loss.backward()
         self.opt.step()
         self.loss.copy_(loss.detach())
 
     def set_mask(self, sup_mask):
+        """New supervision subset.  The normaliser 1/n_sup is a graph constant: callers that change the COUNT must
+        pass n_sup_global at construction (or rebuild); the reference's Bernoulli(0.2) mask varies it by ~0.2 %."""
         self.sup.copy_(sup_mask.to(torch.float32))
 
     def step(self) -> torch.Tensor:

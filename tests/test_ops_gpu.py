@@ -360,6 +360,28 @@ def test_pair_head_fwd_bwd(ops, dev, p, sorted_pairs):
             assert rel(got, want.grad) <= 2e-5, (name, want_low)
 
 
+@pytest.mark.parametrize("loss_type", ["mae", "mse"])
+def test_weighted_pair_loss(ops, dev, loss_type):
+    gen = torch.Generator().manual_seed(41)
+    n = 100003
+    pred, y = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    y[:10] = pred[:10]                      # |0| has subgradient 0 (torch.abs convention)
+    w, sup = torch.rand(n, generator=gen) + 0.5, (torch.rand(n, generator=gen) < 0.2).float()
+    inv = 1.0 / float(sup.sum())
+    p = pred.to(dev).requires_grad_(True)
+    loss = ops.weighted_pair_loss(p, y.to(dev), w.to(dev), sup.to(dev), inv, loss_type)
+    loss.backward()
+    pd = pred.double().requires_grad_(True)
+    d = pd - y.double()
+    ref = ((d.abs() if loss_type == "mae" else d * d) * w.double() * sup.double()).sum() * inv
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
+    assert rel(p.grad, pd.grad) <= 1e-6
+    l2 = ops.weighted_pair_loss(p, y.to(dev), None, None, 1.0 / n, loss_type)
+    r2 = (d.abs() if loss_type == "mae" else d * d).mean()
+    assert abs(float(l2) - float(r2)) <= 1e-6 * abs(float(r2))
+
+
 def test_ops_reject_cpu_tensors(ops):
     with pytest.raises(Exception):
         ops.linear_fwd(torch.zeros(4, 64), torch.zeros(64, 64))
