@@ -58,11 +58,19 @@ def setup_dist(args):
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
+    n_dev = max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("MMG_DIST_BACKEND", "nccl")     # "gloo": rehearse N ranks on fewer GPUs (tests only)
+    if world > n_dev and backend == "nccl":
+        raise SystemExit(f"{world} ranks need {world} GPUs with the RCCL backend ({n_dev} visible)")
+    local = local % n_dev
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
     return world, rank, torch.device("cuda", local)
 
 
@@ -252,6 +260,14 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": hbm_frac, "traffic": None}
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload (never guessed)
+        try:
+            if args.scale == 100 and args.dim == 128 and not args.strong:
+                tr_ = json.load(open(os.path.join(REPO, "profiles", "r1_traffic_x100.json")))
+                roof["traffic"] = tr_["per_op"][dominant]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r1_traffic_x100.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
+        except Exception:
+            roof["traffic"] = None
         roof.update({"kernel": dominant, "avg_launch_ms": avg_ms, "launches_timed": launches,
                      "timing": ("HIP events on the launch stream, eager re-run of the same kernels right after the "
                                 "graph-replay timed region" if gstep is not None else
