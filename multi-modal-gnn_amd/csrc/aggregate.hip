@@ -197,8 +197,7 @@ __global__ __launch_bounds__(GL_THREADS) void k_gather_lds(RelPack rp, int64_t n
 // Column ids of the next stage and row bounds of the stage after are prefetched into registers.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float gf32x16 __attribute__((ext_vector_type(16)));
-constexpr int GB_ROWS = 32, GB_DH = 64, GB_PF = 8;
-constexpr size_t GB_LDS_MAX = 156 * 1024;
+constexpr int GB_ROWS = 32, GB_PF = 8;
 
 __device__ inline void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
   a = (__bf16)v;
@@ -207,151 +206,196 @@ __device__ inline void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
   c = (__bf16)(r1 - (float)b);
 }
 
-__global__ __launch_bounds__(256) void k_gather_bf16(RelPack rp, int64_t n_rows, int64_t rows_per_blk, int D, int vp,
-                                                     float* __restrict__ out, int accumulate) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int ldv = vp + 8;                                   // bf16 elements per LDS row (16-B multiple)
-  __bf16* TT = reinterpret_cast<__bf16*>(lds_raw);          // [3][GB_DH][ldv]
-  __bf16* CT = TT + 3 * GB_DH * ldv;                        // [GB_ROWS][ldv]
-  float* RS = reinterpret_cast<float*>(CT + GB_ROWS * ldv); // [MMG_MAX_REL][GB_ROWS]
-  float* PART = RS + MMG_MAX_REL * GB_ROWS;                 // [2][32][32]
+// v2 layout: every wave owns one 32-column slice of the output and keeps ITS slice of the three split tables
+// in registers for the whole kernel (NKS k16-steps x 3 pieces x 4 VGPRs), so LDS only carries the
+// double-buffered 32-row indicator tile: one workgroup barrier per stage, no cross-wave reduction, and the
+// column ids are read once for the full feature width.
+template <int NKS, int NDT>      // NKS: padded vocab columns / 16;  NDT: D / 32 = waves per workgroup
+__global__ __launch_bounds__(NDT * 64) void k_gather_bf16(RelPack rp, int64_t n_rows, int64_t rows_per_blk, int D,
+                                                          float* __restrict__ out, int accumulate, int dbg) {
+  constexpr int VP = NKS * 16, LDV = VP + 8, NT = NDT * 64;
+  __shared__ __attribute__((aligned(16))) __bf16 CT[2][GB_ROWS * LDV];
+  __shared__ float RS[2][MMG_MAX_REL * GB_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int dt = wid & 1, kh = wid >> 1;
-  const int d0 = blockIdx.y * GB_DH;
-  const int nks = vp / 16, kmid = nks / 2;
+  const int dcol = blockIdx.y * (NDT * 32) + wid * 32 + l31; // this lane's output column
 
-  // ---- stage the split tables once
+  // ---- table fragments: tb[ks][p] = piece p of T'[v = 16ks + 8h + j][dcol], j = 0..7
+  bf16x8 tb[NKS][3];
+  int kend[MMG_MAX_REL];                                     // first k-step AFTER each relation
+#pragma unroll
+  for (int r = 0; r < MMG_MAX_REL; ++r) kend[r] = r < rp.n ? (rp.r[r].acc_off + ((rp.r[r].n_cols + 15) & ~15)) / 16 : NKS + 1;
   {
-    const mmg_f4 z = {0.f, 0.f, 0.f, 0.f};
-    mmg_f4* t4 = reinterpret_cast<mmg_f4*>(TT);
-    for (int i = tid; i < 3 * GB_DH * ldv / 8; i += 256) t4[i] = z;
-  }
-  __syncthreads();
-  for (int r = 0; r < rp.n; ++r) {
-    const RelDev& R = rp.r[r];
-    for (int i = tid; i < R.n_cols * GB_DH; i += 256) {
-      const int c = i / GB_DH, dd = i - c * GB_DH;
-      float v = R.table[(size_t)c * D + d0 + dd];
-      if (R.colscale) v *= R.colscale[c];
-      __bf16 a, b, cc;
-      split3(v, a, b, cc);
-      TT[(0 * GB_DH + dd) * ldv + R.acc_off + c] = a;
-      TT[(1 * GB_DH + dd) * ldv + R.acc_off + c] = b;
-      TT[(2 * GB_DH + dd) * ldv + R.acc_off + c] = cc;
+    // staged through LDS in chunks of 2 k-steps (32 vocab rows x this workgroup's columns, fp32, coalesced
+    // loads all in flight); the indicator buffers are not live yet, so their space is reused
+    constexpr int DCOLS = NDT * 32;
+    float* stage = reinterpret_cast<float*>(&CT[0][0]);
+    static_assert(sizeof(CT) >= 32 * DCOLS * 4, "staging chunk must fit the indicator buffers");
+    const int dbase = blockIdx.y * DCOLS;
+#pragma unroll
+    for (int ch = 0; ch < (NKS + 1) / 2; ++ch) {
+      __syncthreads();
+      for (int i = tid; i < 32 * (DCOLS / 4); i += NT) {
+        const int vr = i / (DCOLS / 4), c4 = i - vr * (DCOLS / 4);
+        const int v = ch * 32 + vr;
+        mmg_f4 val = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rp.n; ++r) {
+          const int c = v - rp.r[r].acc_off;
+          if (c >= 0 && c < rp.r[r].n_cols) {
+            val = *reinterpret_cast<const mmg_f4*>(rp.r[r].table + (size_t)c * D + dbase + c4 * 4);
+            if (rp.r[r].colscale) val *= rp.r[r].colscale[c];
+          }
+        }
+        *reinterpret_cast<mmg_f4*>(stage + vr * DCOLS + c4 * 4) = val;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ks = ch * 2 + kk;
+        if (ks < NKS) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float val = stage[(kk * 16 + 8 * h + j) * DCOLS + wid * 32 + l31];
+            __bf16 a, b, c3;
+            split3(val, a, b, c3);
+            tb[ks][0][j] = a; tb[ks][1][j] = b; tb[ks][2][j] = c3;
+          }
+        }
+      }
     }
+    __syncthreads();
   }
 
   const int64_t r_beg = (int64_t)blockIdx.x * rows_per_blk, r_end = min(n_rows, r_beg + rows_per_blk);
-  const int m = tid >> 3, q = tid & 7;                      // 8 lanes per indicator row
-  // software pipeline state: bounds of the next stage's row, prefetched column ids of the current one
-  int cb[MMG_MAX_REL], ce[MMG_MAX_REL], nb[MMG_MAX_REL], ne[MMG_MAX_REL], cc[MMG_MAX_REL][GB_PF];
-  auto bounds = [&](int64_t row, int* bb, int* ee) {
+  // indicator rows are built by fixed 8-lane groups (same wave: zero-fill then ones need no workgroup barrier)
+  constexpr int BUILD_T = NT < 256 ? NT : 256;               // threads that build indicator rows
+  constexpr int ROWS_PER_PASS = BUILD_T / 8;                 // rows covered by the workgroup in one pass
+  constexpr int NPASS = GB_ROWS / ROWS_PER_PASS;
+  const bool builder = tid < BUILD_T;
+  const int mrow = tid >> 3, q = tid & 7;
+  int cb[NPASS][MMG_MAX_REL], ce[NPASS][MMG_MAX_REL], nb[NPASS][MMG_MAX_REL], ne[NPASS][MMG_MAX_REL];
+  int cc[NPASS][MMG_MAX_REL][GB_PF];
+  auto bounds = [&](int64_t row0, int (*bb)[MMG_MAX_REL], int (*ee)[MMG_MAX_REL]) {
 #pragma unroll
-    for (int r = 0; r < MMG_MAX_REL; ++r) {
-      bb[r] = 0; ee[r] = 0;
-      if (r < rp.n && row < r_end) { bb[r] = rp.r[r].rowptr[row]; ee[r] = rp.r[r].rowptr[row + 1]; }
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int64_t row = row0 + ps * ROWS_PER_PASS + mrow;
+#pragma unroll
+      for (int r = 0; r < MMG_MAX_REL; ++r) {
+        bb[ps][r] = 0; ee[ps][r] = 0;
+        if (builder && r < rp.n && row < r_end) { bb[ps][r] = rp.r[r].rowptr[row]; ee[ps][r] = rp.r[r].rowptr[row + 1]; }
+      }
     }
   };
-  auto fetch_cols = [&](const int* bb, const int* ee, int (*dst)[GB_PF]) {
+  auto fetch_cols = [&](int (*bb)[MMG_MAX_REL], int (*ee)[MMG_MAX_REL], int (*dst)[MMG_MAX_REL][GB_PF]) {
 #pragma unroll
-    for (int r = 0; r < MMG_MAX_REL; ++r)
+    for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
-      for (int i = 0; i < GB_PF; ++i) {
-        const int k = bb[r] + q + 8 * i;
-        dst[r][i] = (r < rp.n && k < ee[r]) ? rp.r[r].col[k] : -1;
-      }
+      for (int r = 0; r < MMG_MAX_REL; ++r)
+#pragma unroll
+        for (int i = 0; i < GB_PF; ++i) {
+          const int k = bb[ps][r] + q + 8 * i;
+          dst[ps][r][i] = (r < rp.n && k < ee[ps][r]) ? rp.r[r].col[k] : -1;
+        }
   };
-  bounds(r_beg + m, cb, ce);
-  bounds(r_beg + GB_ROWS + m, nb, ne);
-  fetch_cols(cb, ce, cc);
-
-  gf32x16 acc[MMG_MAX_REL];
-  for (int64_t r0 = r_beg; r0 < r_end; r0 += GB_ROWS) {
-    __syncthreads();                                        // previous stage done with CT / PART / RS
-    {
+  auto build = [&](int buf, int64_t row0, int (*bb)[MMG_MAX_REL], int (*ee)[MMG_MAX_REL], int (*cols)[MMG_MAX_REL][GB_PF]) {
+    if (!builder) return;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int m = ps * ROWS_PER_PASS + mrow;
+      __bf16* rowp = &CT[buf][m * LDV];
       const mmg_f4 z = {0.f, 0.f, 0.f, 0.f};
-      mmg_f4* c4 = reinterpret_cast<mmg_f4*>(CT);
-      for (int i = tid; i < GB_ROWS * ldv / 8; i += 256) c4[i] = z;
-      if (tid < MMG_MAX_REL * GB_ROWS) {
-        const int r = tid / GB_ROWS, mm = tid - r * GB_ROWS;
-        float v = 1.f;
-        if (r < rp.n && rp.r[r].rowscale && r0 + mm < r_end) v = rp.r[r].rowscale[r0 + mm];
-        RS[tid] = v;
-      }
-    }
-    float prev[16];
-    if (kh == 0) {                                          // accumulate: issue the old values early
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int64_t gr = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        prev[i] = (accumulate && gr < r_end) ? out[(size_t)gr * D + d0 + dt * 32 + l31] : 0.f;
-      }
-    }
-    __syncthreads();                                        // zero-fill visible before the ones land
-    {
-      unsigned short* c16 = reinterpret_cast<unsigned short*>(CT) + m * ldv;
+      for (int i = q; i < LDV / 8; i += 8) reinterpret_cast<mmg_f4*>(rowp)[i] = z;
+      unsigned short* c16 = reinterpret_cast<unsigned short*>(rowp);
 #pragma unroll
       for (int r = 0; r < MMG_MAX_REL; ++r) {
         if (r >= rp.n) continue;
         const int off = rp.r[r].acc_off;
 #pragma unroll
         for (int i = 0; i < GB_PF; ++i)
-          if (cc[r][i] >= 0) c16[off + cc[r][i]] = 0x3F80;                    // bf16 1.0
-        for (int k = cb[r] + q + 8 * GB_PF; k < ce[r]; k += 8) c16[off + rp.r[r].col[k]] = 0x3F80;   // > 64 edges (rare)
-      }
-    }
-    // prefetch: column ids for the next stage (bounds known), bounds for the one after
-    int tb[MMG_MAX_REL], te[MMG_MAX_REL], tc[MMG_MAX_REL][GB_PF];
-    fetch_cols(nb, ne, tc);
-    bounds(r0 + 2 * GB_ROWS + m, tb, te);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < MMG_MAX_REL; ++r)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
-    const int kb = kh ? kmid : 0, ke = kh ? nks : kmid;
-#pragma unroll
-    for (int r = 0; r < MMG_MAX_REL; ++r) {
-      if (r >= rp.n) continue;
-      const int k0 = rp.r[r].acc_off / 16;
-      const int k1 = k0 + ((rp.r[r].n_cols + 15) >> 4);
-      for (int ks = max(k0, kb); ks < min(k1, ke); ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(CT + l31 * ldv + 16 * ks + 8 * h);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(TT + (p * GB_DH + dt * 32 + l31) * ldv + 16 * ks + 8 * h);
-          acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r], 0, 0, 0);
+          if (cols[ps][r][i] >= 0) c16[off + cols[ps][r][i]] = 0x3F80;           // bf16 1.0
+        for (int k = bb[ps][r] + q + 8 * GB_PF; k < ee[ps][r]; k += 8) c16[off + rp.r[r].col[k]] = 0x3F80;
+        if (q == 0) {
+          const int64_t row = row0 + m;
+          RS[buf][r * GB_ROWS + m] = (rp.r[r].rowscale && row < r_end) ? rp.r[r].rowscale[row] : 1.f;
         }
       }
     }
-    float v[16];
+  };
+  if (r_beg >= r_end) return;
+  bounds(r_beg, cb, ce);
+  fetch_cols(cb, ce, cc);
+  bounds(r_beg + GB_ROWS, nb, ne);
+  build(0, r_beg, cb, ce, cc);
+  __syncthreads();
+
+  int buf = 0;
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += GB_ROWS, buf ^= 1) {
+    // ---- prefetch: columns of the next stage, bounds of the one after, old output values of this one
+    int tc[NPASS][MMG_MAX_REL][GB_PF], tb2[NPASS][MMG_MAX_REL], te2[NPASS][MMG_MAX_REL];
+    if (!(dbg & 8)) { fetch_cols(nb, ne, tc); bounds(r0 + 2 * GB_ROWS, tb2, te2); }
+    else {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int r = 0; r < MMG_MAX_REL; ++r) { tb2[ps][r] = 0; te2[ps][r] = 0;
+#pragma unroll
+          for (int i = 0; i < GB_PF; ++i) tc[ps][r][i] = -1; }
+    }
+    float prev[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < MMG_MAX_REL; ++r)
-        if (r < rp.n) t = fmaf(RS[r * GB_ROWS + row], acc[r][i], t);
-      v[i] = t;
-      if (kh == 1) PART[(dt * 32 + row) * 32 + l31] = t;
+      const int64_t gr = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      prev[i] = (accumulate && gr < r_end && !(dbg & 4)) ? out[(size_t)gr * D + dcol] : 0.f;
     }
-    __syncthreads();
-    if (kh == 0) {
+    // ---- matrix products of this stage; the per-relation accumulator is folded at relation boundaries
+    gf32x16 acc;
+    float tot[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int64_t gr = r0 + row;
-        if (gr < r_end) out[(size_t)gr * D + d0 + dt * 32 + l31] = prev[i] + v[i] + PART[(dt * 32 + row) * 32 + l31];
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; tot[i] = 0.f; }
+    int rcur = 0;
+    if (!(dbg & 1))
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&CT[buf][l31 * LDV + 16 * ks + 8 * h]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tb[ks][p], acc, 0, 0, 0);
+      if (ks + 1 == kend[rcur] || ks + 1 == NKS) {          // wave-uniform: end of a relation's columns
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+          tot[i] = fmaf(RS[buf][rcur * GB_ROWS + row], acc[i], tot[i]);
+          acc[i] = 0.f;
+        }
+        rcur = min(rcur + 1, MMG_MAX_REL - 1);
       }
     }
 #pragma unroll
-    for (int r = 0; r < MMG_MAX_REL; ++r) {
-      cb[r] = nb[r]; ce[r] = ne[r]; nb[r] = tb[r]; ne[r] = te[r];
-#pragma unroll
-      for (int i = 0; i < GB_PF; ++i) cc[r][i] = tc[r][i];
+    for (int i = 0; i < 16; ++i) {
+      const int64_t gr = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (gr < r_end && (!(dbg & 4) || i == 0)) out[(size_t)gr * D + dcol] = prev[i] + tot[i];
     }
+    // ---- build the next stage's indicator tile in the other buffer (its columns arrived during the MFMAs)
+    if (r0 + GB_ROWS < r_end && !(dbg & 2)) build(buf ^ 1, r0 + GB_ROWS, nb, ne, tc);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+      for (int r = 0; r < MMG_MAX_REL; ++r) { nb[ps][r] = tb2[ps][r]; ne[ps][r] = te2[ps][r]; }
+    __syncthreads();                                         // tile s+1 complete, tile s free
   }
+}
+
+template <int NKS>
+void launch_gather_bf16(const RelPack& rb, int64_t n_rows, int D, float* out, int accumulate, hipStream_t st) {
+  const char* de = getenv("MMG_GB_DBG");
+  const int dbg = de ? atoi(de) : 0;
+  int64_t nblk = D > 128 ? 128 : 256;
+  const int64_t max_blk = (n_rows + 2 * GB_ROWS - 1) / (2 * GB_ROWS);
+  if (nblk > max_blk) nblk = max_blk;
+  int64_t rows_per_blk = (n_rows + nblk - 1) / nblk;
+  rows_per_blk = (rows_per_blk + GB_ROWS - 1) / GB_ROWS * GB_ROWS;
+  nblk = (n_rows + rows_per_blk - 1) / rows_per_blk;
+  if (D == 64) hipLaunchKernelGGL((k_gather_bf16<NKS, 2>), dim3((unsigned)nblk), dim3(128), 0, st, rb, n_rows, rows_per_blk, D, out, accumulate, dbg);
+  else hipLaunchKernelGGL((k_gather_bf16<NKS, 4>), dim3((unsigned)nblk, (unsigned)(D / 128)), dim3(256), 0, st, rb, n_rows, rows_per_blk, D, out, accumulate, dbg);
 }
 
 // ------------------------------------------------------------------------------ scatter
@@ -576,31 +620,23 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
   hipStream_t st = (hipStream_t)stream;
   int total_cols = 0;
   for (int r = 0; r < n_rel; ++r) total_cols += rels[r].n_cols;
-  // bf16-split matrix-core path: simple relations, tables + indicator tile fit LDS, D a multiple of 64
+  // bf16-split matrix-core path: simple relations whose padded vocab fits the register-resident table slices
   {
     bool simple = true;
     int vp = 0;
     for (int r = 0; r < n_rel; ++r) { simple &= (rels[r].flags & MMG_REL_SIMPLE) != 0; vp += (rels[r].n_cols + 15) & ~15; }
-    // Measured on MI355X (x100, D=128): 0.53 ms per launch vs 0.16 ms for the LDS-table kernel below -- the
-    // 45 four-barrier stages per workgroup expose one global round trip each at one workgroup per CU.
-    // Kept (parity-tested, opt-in) as the base for a deeper-pipelined version: MMG_AGG_BF16=1.
+    // Opt-in (MMG_AGG_BF16=1).  Measured on MI355X at x100 / D=128: 200-208 us per launch vs 159-167 us for the
+    // LDS-table kernel below.  Ablation (MMG_GB_DBG bits): skeleton + table setup 50 us, matrix phase 42 us
+    // (one dependent accumulator chain), indicator build 38 us, output read-modify-write 40 us, index prefetch
+    // 30 us -- and at one wave per SIMD (the register-resident table slices need ~500 VGPRs) the phases ADD
+    // instead of overlapping.  Next: split MFMA / loader wave roles and two accumulators.
     static const int use_bf16 = [] { const char* e = getenv("MMG_AGG_BF16"); return e ? atoi(e) : 0; }();
-    const size_t lds = (size_t)(3 * GB_DH + GB_ROWS) * (vp + 8) * 2 + (size_t)MMG_MAX_REL * GB_ROWS * 4 + 2 * 32 * 32 * 4;
-    if (use_bf16 && simple && vp > 0 && lds <= GB_LDS_MAX && n_rows >= 256) {
+    if (use_bf16 && simple && vp > 0 && vp <= 20 * 16 && n_rows >= 256) {
       RelPack rb = rp;
       int off = 0;
       for (int r = 0; r < n_rel; ++r) { rb.r[r].acc_off = off; off += (rels[r].n_cols + 15) & ~15; }
-      const int n_dh = D / GB_DH;
-      int64_t nblk = 256 / n_dh;
-      if (nblk < 1) nblk = 1;
-      const int64_t max_blk = (n_rows + 4 * GB_ROWS - 1) / (4 * GB_ROWS);
-      if (nblk > max_blk) nblk = max_blk;
-      int64_t rows_per_blk = (n_rows + nblk - 1) / nblk;
-      rows_per_blk = (rows_per_blk + GB_ROWS - 1) / GB_ROWS * GB_ROWS;
-      nblk = (n_rows + rows_per_blk - 1) / rows_per_blk;
-      (void)hipFuncSetAttribute((const void*)k_gather_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GB_LDS_MAX);
-      hipLaunchKernelGGL(k_gather_bf16, dim3((unsigned)nblk, (unsigned)n_dh), dim3(256), lds, st, rb, n_rows, rows_per_blk, D,
-                         vp, out, accumulate);
+      if (vp <= 12 * 16) launch_gather_bf16<12>(rb, n_rows, D, out, accumulate, st);
+      else launch_gather_bf16<20>(rb, n_rows, D, out, accumulate, st);
       MMG_CHECK_LAUNCH("gather_rows(bf16)");
       return MMG_OK;
     }

@@ -137,19 +137,23 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ 
   if (rstd_out) rstd_out[i] = rstd;
 }
 
+// Both passes are pure HBM streams: the per-column constants are hoisted into registers (the grid stride is a
+// multiple of N/4, so a thread always works on the same four columns) -- per-element L1 lookups had capped
+// the pass at ~2 TB/s.
 __global__ __launch_bounds__(256) void k_affine_act_drop(const float* __restrict__ Y, ProDev pr, float* __restrict__ out,
                                                          int64_t M, int N) {
   pr.resolve();
   const int64_t n4 = M * (int64_t)(N / 4);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;          // host guarantees stride % (N/4) == 0
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(i % (N / 4)) * 4;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (pr.scale) { sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c); }
+  for (; i < n4; i += stride) {
     const int64_t r = i / (N / 4);
-    const int c = (int)(i - r * (N / 4)) * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float s = pr.scale ? pr.scale[c + j] : 1.f, sh = pr.scale ? pr.shift[c + j] : 0.f;
-      v[j] = mmg_pro_apply(pr, v[j], s, sh, r, c + j, N);
-    }
+    for (int j = 0; j < 4; ++j) v[j] = mmg_pro_apply(pr, v[j], sc[j], sh[j], r, c + j, N);
     *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
   }
 }
@@ -160,17 +164,26 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       float* __restrict__ dY, int64_t M, int N) {
   pr.resolve();
   const int64_t n4 = M * (int64_t)(N / 4);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)(i % (N / 4)) * 4;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc = one, sh = zero, mu = zero, rs = one, a0 = zero, a1 = zero;
+  if (pr.scale) {
+    sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c);
+    mu = *reinterpret_cast<const f32x4*>(mean + c); rs = *reinterpret_cast<const f32x4*>(rstd + c);
+    if (c0) a0 = *reinterpret_cast<const f32x4*>(c0 + c);
+    if (c1) a1 = *reinterpret_cast<const f32x4*>(c1 + c);
+  }
+  for (; i < n4; i += stride) {
     const int64_t r = i / (N / 4);
-    const int c = (int)(i - r * (N / 4)) * 4;
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(G + (size_t)i * 4);
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = c + j;
-      const float sc = pr.scale ? pr.scale[k] : 1.f, sh = pr.scale ? pr.shift[k] : 0.f;
-      const float act = pr.scale ? fmaf(y4[j], sc, sh) : y4[j];
+      const float act = pr.scale ? fmaf(y4[j], sc[j], sh[j]) : y4[j];
       float g = g4[j];
       if (pr.relu && !(act > 0.f)) g = 0.f;
       if (pr.p > 0.f) {
@@ -178,9 +191,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
         g = mmg_keep(pr.seed, pr.site, e, pr.p) ? g * pr.inv_keep : 0.f;
       }
       if (pr.scale) {
-        const float xh = (y4[j] - mean[k]) * rstd[k];
-        const float a0 = c0 ? c0[k] : 0.f, a1 = c1 ? c1[k] : 0.f;
-        g = sc * (g - a0 - xh * a1);
+        const float xh = (y4[j] - mu[j]) * rs[j];
+        g = sc[j] * (g - a0[j] - xh * a1[j]);
       }
       o[j] = g;
     }
@@ -317,7 +329,7 @@ extern "C" int mmg_bn_finalize(const double* sums, int64_t count, const float* g
 }
 
 extern "C" int mmg_affine_act_drop(const float* Y, const mmg_prologue_t* pro, float* out, int64_t M, int N, void* stream) {
-  MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0, "affine_act_drop: N=%d must be a multiple of 4", N);
+  MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0 && 256 % (N / 4) == 0, "affine_act_drop: N=%d must be 4*2^k <= 1024", N);
   if (M == 0) return MMG_OK;
   MMG_CHECK_ARG(Y && out, "affine_act_drop: null buffer");
   hipLaunchKernelGGL(k_affine_act_drop, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, Y, mmg_pro_dev(pro),
@@ -342,7 +354,7 @@ extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prolog
 extern "C" int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
                                 const float* rstd, const float* c0, const float* c1, float* dY, int64_t M, int N,
                                 void* stream) {
-  MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0, "bn_bwd_apply: N=%d must be a multiple of 4", N);
+  MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0 && 256 % (N / 4) == 0, "bn_bwd_apply: N=%d must be 4*2^k <= 1024", N);
   if (M == 0) return MMG_OK;
   MMG_CHECK_ARG(G && Y && dY, "bn_bwd_apply: null buffer");
   MMG_CHECK_ARG(!pro || !pro->scale || (mean && rstd), "bn_bwd_apply: affine prologue needs mean/rstd");

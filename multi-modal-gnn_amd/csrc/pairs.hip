@@ -198,10 +198,11 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
 //   (1) H2pre[pair,u]   = H1[pair,:] . W2[u,:]            32 MFMA   (A = h1 rows in registers)
 //   (2) dW2[u,k]       += D2[pair,u] * H1[pair,k]          32 MFMA   (A = the C-layout of (1): no lane movement)
 //   (3) dH1[pair,k]     = D2[pair,:] . W2[:,k]             32 MFMA   (A = D2 transposed through a 4 KB LDS tile)
-//   (4) dB[lab,k]      += [li[pair]==lab] * dH1[pair,k]    16*LT*2 MFMA (one-hot A built on the fly)
+//   (4) dB[lab,k]      += [li[pair]==lab] * dH1[pair,k]    12*LT bf16 MFMA (exact: one-hot x 3-way bf16 split of dH1)
 // dA[pi] is flushed with run-length pre-reduction (pairs arrive sorted by patient).  No workgroup
 // barrier anywhere: waves are independent.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 constexpr int TP = 32;                 // pairs per wave tile
 constexpr int LDH = 68;                // H1 / dH1 tile row stride (floats)
 constexpr int LDD = 36;                // D2 tile row stride
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
                                                        const float* __restrict__ dpred) {
   if (seed_ptr) seed = *seed_ptr;
   __shared__ __attribute__((aligned(16))) float sm[4 * WAVE_LDS];
+  __shared__ __attribute__((aligned(16))) float W2s[32 * LDH];      // W2[u][k], row stride LDH (shared by the 4 waves)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   float* H1s = sm + wid * WAVE_LDS;                 // [32][LDH]  (later: dH1 tile)
@@ -229,16 +231,9 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
   unsigned* PHi = PLo + TP;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 
-  // ---- loop-invariant weight fragments
-  float w2b[32];            // B of (1): W2[u=l31][k=32h+s]
-#pragma unroll
-  for (int s = 0; s < 32; ++s) w2b[s] = H.W2[l31 * 64 + 32 * h + s];
-  float w2c[16][2];         // B of (3): W2[u=16h+s][k=ct*32+l31]
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    w2c[s][0] = H.W2[(16 * h + s) * 64 + l31];
-    w2c[s][1] = H.W2[(16 * h + s) * 64 + 32 + l31];
-  }
+  // ---- W2 lives in LDS (its two fragment views are re-read per tile: keeps ~64 VGPRs out of the live set)
+  for (int i = tid; i < 2048; i += 256) W2s[(i >> 6) * LDH + (i & 63)] = H.W2[i];
+  __syncthreads();
   const float b2v = H.b2[l31], w3v = H.W3[l31];
 
   f32x16 accW2[2], accB[LT][2];
@@ -315,7 +310,11 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[s], w2b[s], acc1, 0, 0, 0);
+    for (int q = 0; q < 8; ++q) {       // B of (1): W2[u=l31][k=32h+4q..]
+      const f32x4 w = *reinterpret_cast<const f32x4*>(W2s + l31 * LDH + 32 * h + q * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[q * 4 + j], w[j], acc1, 0, 0, 0);
+    }
     // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
     float d2c[16];
 #pragma unroll
@@ -361,9 +360,10 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 #pragma unroll
     for (int i = 0; i < 16; ++i) { accH[0][i] = 0.f; accH[1][i] = 0.f; }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      accH[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s], w2c[s][0], accH[0], 0, 0, 0);
-      accH[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s], w2c[s][1], accH[1], 0, 0, 0);
+    for (int s = 0; s < 16; ++s) {      // B of (3): W2[u=16h+s][k=ct*32+l31]
+      const float w0 = W2s[(16 * h + s) * LDH + l31], w1 = W2s[(16 * h + s) * LDH + 32 + l31];
+      accH[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s], w0, accH[0], 0, 0, 0);
+      accH[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s], w1, accH[1], 0, 0, 0);
     }
     // through dropout+relu of layer 1 (h1 > 0 <=> kept and positive); C layout: lane = column, reg = pair row
     float dh[16][2];
@@ -372,15 +372,36 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
       dh[r][0] = h1c[r][0] > 0.f ? accH[0][r] * inv_keep : 0.f;
       dh[r][1] = h1c[r][1] > 0.f ? accH[1][r] * inv_keep : 0.f;
     }
-    // ---- (4) dB[lab,k] += onehot(li[pair])[lab] * dH1[pair,k]
+    // ---- (4) dB[lab,k] += onehot(li[pair])[lab] * dH1[pair,k] on the bf16 matrix cores: the one-hot is exact
+    //      in bf16 and dH1 splits exactly into three bf16 pieces, so the products are exact and the fp32
+    //      accumulation matches the fp32 path up to order -- at 1/5 of its matrix time.  k index of step t,
+    //      lane half h, element j  <->  pair row crow(8t + j, h): exactly the C-layout registers 8t..8t+7.
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int lab = LIs[crow(s, h)];
+    for (int t2 = 0; t2 < 2; ++t2) {
+      pbf16x8 bp[2][3];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = dh[8 * t2 + j][ct];
+          const __bf16 a = (__bf16)v;
+          const float r1 = v - (float)a;
+          const __bf16 b = (__bf16)r1;
+          bp[ct][0][j] = a; bp[ct][1][j] = b; bp[ct][2][j] = (__bf16)(r1 - (float)b);
+        }
+      int labs[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) labs[j] = LIs[crow(8 * t2 + j, h)];
 #pragma unroll
       for (int lt = 0; lt < LT; ++lt) {
-        const float a = (lab == lt * 32 + l31) ? 1.f : 0.f;
-        accB[lt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dh[s][0], accB[lt][0], 0, 0, 0);
-        accB[lt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dh[s][1], accB[lt][1], 0, 0, 0);
+        pbf16x8 oh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oh[j] = (labs[j] == lt * 32 + l31) ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            accB[lt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, bp[ct][p], accB[lt][ct], 0, 0, 0);
       }
     }
     // ---- dA[pi] += dH1: tile to LDS (aliases H1s: all H1 reads are done), then run-length flush
