@@ -146,29 +146,32 @@ __global__ __launch_bounds__(GL_THREADS) void k_gather_lds(RelPack rp, int64_t n
     for (int v = 0; v < VECC; ++v) tot[v] = 0.f;
 #pragma unroll
     for (int r = 0; r < MMG_MAX_REL; ++r) {
-      if (r >= rp.n || b0[r] == e0[r]) continue;
+      if (r >= rp.n) continue;
+      // row bounds are wave-uniform: make that explicit so the edge loops run on the scalar unit
+      const int rb_ = __builtin_amdgcn_readfirstlane(b0[r]), re_ = __builtin_amdgcn_readfirstlane(e0[r]);
+      if (rb_ == re_) continue;
       const RelDev& R = rp.r[r];
-      float acc[VECC];
+      float acc[VECC], acc2[VECC];
 #pragma unroll
-      for (int v = 0; v < VECC; ++v) acc[v] = 0.f;
+      for (int v = 0; v < VECC; ++v) { acc[v] = 0.f; acc2[v] = 0.f; }
       const float* tr = tab + (size_t)R.acc_off * DC + lane * VECC;
       int cidx = c0[r];
-      for (int base = b0[r]; base < e0[r]; base += 64) {
-        const int cnt = min(64, e0[r] - base);
-        if (base != b0[r]) cidx = (lane < cnt) ? R.col[base + lane] : 0;   // rows with > 64 edges (rare)
+      for (int base = rb_; base < re_; base += 64) {
+        const int cnt = min(64, re_ - base);
+        if (base != rb_) cidx = (lane < cnt) ? R.col[base + lane] : 0;     // rows with > 64 edges (rare)
         int j = 0;
-        for (; j + 4 <= cnt; j += 4) {
-          float t[4][VECC];
+        for (; j + 8 <= cnt; j += 8) {             // 8 LDS reads in flight, two independent add chains
+          float t[8][VECC];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 8; ++u) {
             const int c = __builtin_amdgcn_readlane(cidx, j + u);
 #pragma unroll
             for (int v = 0; v < VECC; ++v) t[u][v] = tr[(size_t)c * DC + v];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
+          for (int u = 0; u < 8; u += 2)
 #pragma unroll
-            for (int v = 0; v < VECC; ++v) acc[v] += t[u][v];
+            for (int v = 0; v < VECC; ++v) { acc[v] += t[u][v]; acc2[v] += t[u + 1][v]; }
         }
         for (; j < cnt; ++j) {
           const int c = __builtin_amdgcn_readlane(cidx, j);
@@ -176,6 +179,8 @@ __global__ __launch_bounds__(GL_THREADS) void k_gather_lds(RelPack rp, int64_t n
           for (int v = 0; v < VECC; ++v) acc[v] += tr[(size_t)c * DC + v];
         }
       }
+#pragma unroll
+      for (int v = 0; v < VECC; ++v) acc[v] += acc2[v];
 #pragma unroll
       for (int v = 0; v < VECC; ++v) tot[v] = fmaf(rsv[r], acc[v], tot[v]);
     }

@@ -24,7 +24,7 @@ constexpr int BM = 64;
 // W[col c][k in h*K/2 ..]), so LDS only carries the streamed X tile (34 KB at K=128): two workgroups
 // fit per CU and one stages its next tile while the other issues MFMAs.  The next X tile is fetched
 // into registers one tile ahead.
-template <int K, int NTW, int OCC>
+template <int K, int NTW, int OCC, int PF>
 __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict__ X, ProDev pr,
                                                        const float* __restrict__ W, const float* __restrict__ bias,
                                                        float* __restrict__ Y, int64_t M, int N, int accumulate) {
@@ -71,9 +71,10 @@ __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict
       nx[p] = gr < M ? *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + kc4 * 4) : z;
     }
   };
-  if ((int64_t)blockIdx.y < n_tiles) fetch(blockIdx.y);
+  if (PF && (int64_t)blockIdx.y < n_tiles) fetch(blockIdx.y);
   for (int64_t t = blockIdx.y; t < n_tiles; t += gridDim.y) {
     const int64_t row0 = t * BM;
+    if (!PF) fetch(t);   // no register prefetch: a second resident workgroup hides the latency instead
     __syncthreads();   // previous tile's MFMA reads are done
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict
       *reinterpret_cast<f32x4*>(Xs + r * LDK + kc4 * 4) = v;
     }
     __syncthreads();
-    if (t + gridDim.y < n_tiles) fetch(t + gridDim.y);
+    if (PF && t + gridDim.y < n_tiles) fetch(t + gridDim.y);
 
     f32x16 acc[NTW];
 #pragma unroll
@@ -304,7 +305,7 @@ WgradPlan plan_wgrad(int64_t M, int N, int K) {
   return p;
 }
 
-template <int K, int NTW, int OCC>
+template <int K, int NTW, int OCC, int PF>
 int launch_fwd(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                int accumulate, hipStream_t st) {
   constexpr int BN = 64 * NTW;
@@ -313,7 +314,7 @@ int launch_fwd(const float* X, const ProDev& pr, const float* W, const float* bi
   int64_t gy = (OCC * 256) / n_slices;    // OCC resident workgroups per CU, persistent over the row tiles
   if (gy < 1) gy = 1;
   if (gy > n_tiles) gy = n_tiles;
-  hipLaunchKernelGGL((k_linear_fwd<K, NTW, OCC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(256), 0, st, X, pr, W, bias,
+  hipLaunchKernelGGL((k_linear_fwd<K, NTW, OCC, PF>), dim3((unsigned)n_slices, (unsigned)gy), dim3(256), 0, st, X, pr, W, bias,
                      Y, M, N, accumulate);
   return 0;
 }
@@ -343,16 +344,18 @@ extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const f
     else if (K == 128) launch_small<128>(X, pr, W, bias, Y, M, N, accumulate, st);
     else launch_small<256>(X, pr, W, bias, Y, M, N, accumulate, st);
   } else if (K == 64) {
-    if (N % 128 == 0) launch_fwd<64, 2, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
-    else launch_fwd<64, 1, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
+    if (N % 128 == 0) launch_fwd<64, 2, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else launch_fwd<64, 1, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
   } else if (K == 128) {
-    // 128-wide column slices need ~290 VGPRs (W fragments 128 + accumulators 32 + prefetch 32): one
-    // workgroup per CU; 64-wide slices fit two per CU but read X twice.  MMG_LINEAR_WIDE picks (A/B knob).
-    static const int wide = [] { const char* e = getenv("MMG_LINEAR_WIDE"); return e ? atoi(e) : 1; }();
-    if (N % 128 == 0 && wide) launch_fwd<128, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
-    else launch_fwd<128, 1, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
+    // MMG_LINEAR_WIDE (A/B knob, measured within 1 % of each other at x100): 2 = 128-wide slices, two workgroups
+    // per CU, no register prefetch (default); 1 = 128-wide, one workgroup per CU, X prefetched one tile ahead
+    // (~300 VGPRs); 0 = 64-wide slices, two per CU, X read twice.
+    static const int wide = [] { const char* e = getenv("MMG_LINEAR_WIDE"); return e ? atoi(e) : 2; }();
+    if (N % 128 == 0 && wide == 2) launch_fwd<128, 2, 2, 0>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else if (N % 128 == 0 && wide) launch_fwd<128, 2, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
+    else launch_fwd<128, 1, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
   } else {
-    launch_fwd<256, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
+    launch_fwd<256, 1, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
   }
   MMG_CHECK_LAUNCH("linear_fwd");
   return MMG_OK;

@@ -152,6 +152,29 @@ def test_train_step_matches_oracle_with_injected_dropout(dev, p):
             assert rel_err(b.cpu(), obufs[k]) <= TOL, k
 
 
+@pytest.mark.parametrize("hidden", [64, 256])
+def test_other_hidden_dims_match_oracle(dev, hidden):
+    """BASELINE.json config 4 runs 256-d; the reference's own smoke test builds a 64-d model (model.py:642-648)."""
+    # shape picked kink-free: at (600,30,40,25)/256-d one patient_transform ReLU input sits within fp32 rounding of 0
+    # and its gradient flips with the summation order (fp32 and fp64 oracles disagree with each other there too)
+    n = (640, 30, 40, 25)
+    model, g, gd, gv, sd, ei, ea = make(dev, n, hidden)
+    tr, va, te = ot.edge_splits(ei.shape[1], 0.7, 0.15, 0.15, 42)
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    w = ot.lab_weights(li, y, gv.num_nodes["lab"])
+    sup = ot.supervision_mask(int(tr.sum()), 0.2, torch.Generator().manual_seed(11))
+    model.train()
+    pred = model.predict_lab_values(gd, pi.to(dev), li.to(dev))
+    loss = ((pred[sup.to(dev)] - y[sup].to(dev)).abs() * w[li[sup]].to(dev)).mean()
+    loss.backward()
+    oloss, opred, ograds, obufs = ot.train_step_grads(sd, gv, pi, li, y, w, sup, p=0.0)
+    assert rel_err(pred.detach().cpu(), opred) <= TOL
+    gmax = max(float(v.abs().max()) for v in ograds.values())
+    for k, pm in model.named_parameters():
+        gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
+        assert float((gr - ograds[k]).abs().max()) <= 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax, k
+
+
 def test_forward_and_encode_are_differentiable(dev):
     model, g, gd, gv, sd, ei, ea = make(dev, (300, 12, 15, 10), 64)
     model.train()
