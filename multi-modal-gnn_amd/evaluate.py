@@ -1,0 +1,220 @@
+"""Evaluation reducers around ``HeteroRGCN.predict_lab_values`` -- the caller on the far side of the hot path
+(reference ``src/evaluate.py``; SURVEY.md section 8 "next" row f4).  Same function names, argument meaning, result keys
+and files written as the reference:
+
+  compute_regression_metrics  :36-86     MAE / RMSE / R^2 / MAPE(non-zero targets) in float64
+  compute_per_lab_metrics     :89-141    one row per lab with >= 2 samples, sorted by MAE
+  GlobalMeanBaseline / PerLabMeanBaseline / evaluate_baselines  :152-230
+  stratify_by_patient_degree  :237-287   1-5 / 6-15 / 16+ observed labs
+  stratify_by_lab_frequency   :290-342   quartiles of the non-zero lab counts
+  evaluate_model              :349-570   predict -> per-lab +-3 sigma winsorisation -> metrics -> json / csv
+
+The predictions come from the HIP path (one gather / head launch over all test pairs); the reducers are O(pairs)
+float64 host arithmetic exactly as in the reference (sklearn's MAE/MSE/R^2 are restated in closed form: sklearn is
+not a dependency of this package).  The per-lab loops are segment reductions over a stable sort instead of one boolean
+mask per lab, which keeps the x1000 scale (92 M test pairs) linear.  Golden parity: tests/test_evaluate_cpu.py.
+"""
+from __future__ import annotations
+
+import json
+import logging
+from pathlib import Path
+from typing import Dict, Tuple
+
+import numpy as np
+import pandas as pd
+import torch
+
+
+def compute_regression_metrics(predictions: np.ndarray, targets: np.ndarray) -> Dict[str, float]:
+    predictions = np.asarray(predictions)
+    targets = np.asarray(targets)
+    err = targets - predictions
+    mae = float(np.average(np.abs(err), axis=0))
+    mse = float(np.average(err ** 2, axis=0))        # sklearn hands back a Python float: the sqrt below is float64
+    # r2_score: 1 - SS_res/SS_tot in the INPUT dtype (sklearn >= 1.5 sums fp32 inputs in fp32); a zero SS_res gives 1.0,
+    # a constant target with a non-zero SS_res gives 0.0 (sklearn's force_finite)
+    ss_res = np.sum(err ** 2, axis=0)
+    ss_tot = np.sum((targets - np.average(targets, axis=0)) ** 2, axis=0)
+    if ss_res == 0:
+        r2 = 1.0
+    elif ss_tot != 0:
+        r2 = 1 - ss_res / ss_tot
+    else:
+        r2 = 0.0
+    nz = targets != 0
+    if nz.sum() > 0:
+        mape = np.mean(np.abs((targets[nz] - predictions[nz]) / targets[nz])) * 100
+    else:
+        mape = np.nan
+    return {"mae": float(mae), "rmse": float(np.sqrt(mse)), "r2": float(r2), "mape": float(mape)}
+
+
+def _segments(keys: np.ndarray):
+    """Stable sort by key -> (order, unique keys, segment starts, segment ends).  Within a segment the original
+    element order is kept, so per-segment sums see the same operand order as ``x[keys == k]``."""
+    order = np.argsort(keys, kind="stable")
+    sk = keys[order]
+    if len(sk) == 0:
+        return order, sk, np.empty(0, np.int64), np.empty(0, np.int64)
+    starts = np.flatnonzero(np.concatenate(([True], sk[1:] != sk[:-1])))
+    ends = np.concatenate((starts[1:], [len(sk)]))
+    return order, sk[starts], starts, ends
+
+
+def compute_per_lab_metrics(predictions, targets, lab_indices, lab_names: Dict[int, str]) -> pd.DataFrame:
+    order, labs, starts, ends = _segments(np.asarray(lab_indices))
+    p, t = np.asarray(predictions)[order], np.asarray(targets)[order]
+    results = []
+    for lab_idx, a, b in zip(labs.tolist(), starts.tolist(), ends.tolist()):
+        if b - a < 2:
+            continue
+        m = compute_regression_metrics(p[a:b], t[a:b])
+        m["lab_index"] = int(lab_idx)
+        m["lab_name"] = lab_names.get(int(lab_idx), f"Lab_{lab_idx}")
+        m["num_samples"] = int(b - a)
+        results.append(m)
+    df = pd.DataFrame(results)
+    return df.sort_values("mae")
+
+
+def winsorize_residuals(predictions: np.ndarray, targets: np.ndarray, lab_indices: np.ndarray,
+                        n_sigma: float = 3.0) -> Tuple[np.ndarray, int]:
+    """evaluate.py:417-440: clip every lab's residuals to mean +- 3 std (labs with > 1 sample); returns the adjusted
+    predictions (``targets + clipped residual``, in the predictions' dtype) and the number of capped residuals."""
+    predictions = np.array(predictions, copy=True)
+    residuals = predictions - targets
+    order, _, starts, ends = _segments(np.asarray(lab_indices))
+    num_capped = 0
+    for a, b in zip(starts.tolist(), ends.tolist()):
+        if b - a > 1:
+            sel = order[a:b]
+            r = residuals[sel]
+            sd, mu = np.std(r), np.mean(r)
+            rc = np.clip(r, mu - n_sigma * sd, mu + n_sigma * sd)
+            num_capped += int(np.sum(r != rc))
+            predictions[sel] = targets[sel] + rc
+    return predictions, num_capped
+
+
+class GlobalMeanBaseline:
+    def __init__(self):
+        self.mean = None
+
+    def fit(self, values: np.ndarray):
+        self.mean = np.mean(values)
+
+    def predict(self, n: int) -> np.ndarray:
+        return np.full(n, self.mean)
+
+
+class PerLabMeanBaseline:
+    def __init__(self):
+        self.lab_means = {}
+
+    def fit(self, values: np.ndarray, lab_indices: np.ndarray):
+        order, labs, starts, ends = _segments(np.asarray(lab_indices))
+        v = np.asarray(values)[order]
+        for k, a, b in zip(labs.tolist(), starts.tolist(), ends.tolist()):
+            self.lab_means[k] = v[a:b].mean()
+        self.global_mean = np.mean(values)
+
+    def predict(self, lab_indices: np.ndarray) -> np.ndarray:
+        return np.array([self.lab_means.get(i, self.global_mean) for i in np.asarray(lab_indices).tolist()])
+
+
+def evaluate_baselines(train_data, test_data) -> Dict[str, Dict[str, float]]:
+    train_values, train_lab_indices = train_data
+    test_values, test_lab_indices, _ = test_data
+    results = {}
+    g = GlobalMeanBaseline()
+    g.fit(train_values)
+    results["global_mean"] = compute_regression_metrics(g.predict(len(test_values)), test_values)
+    pl = PerLabMeanBaseline()
+    pl.fit(train_values, train_lab_indices)
+    results["per_lab_mean"] = compute_regression_metrics(pl.predict(test_lab_indices), test_values)
+    return results
+
+
+def _groups(groups, predictions, targets):
+    out = {}
+    for name, mask in groups.items():
+        if mask.sum() > 0:
+            m = compute_regression_metrics(predictions[mask], targets[mask])
+            m["num_samples"] = int(mask.sum())
+            out[name] = m
+    return out
+
+
+def stratify_by_patient_degree(predictions, targets, patient_indices, graph) -> Dict[str, Dict]:
+    ei = graph["patient", "has_lab", "lab"].edge_index
+    degrees = torch.bincount(ei[0], minlength=graph["patient"].num_nodes).cpu().numpy()
+    d = degrees[patient_indices]
+    return _groups({"low (1-5 labs)": (d >= 1) & (d <= 5),
+                    "medium (6-15 labs)": (d >= 6) & (d <= 15),
+                    "high (16+ labs)": d >= 16}, predictions, targets)
+
+
+def stratify_by_lab_frequency(predictions, targets, lab_indices, graph) -> Dict[str, Dict]:
+    ei = graph["patient", "has_lab", "lab"].edge_index
+    lab_counts = torch.bincount(ei[1], minlength=graph["lab"].num_nodes).cpu().numpy()
+    f = lab_counts[lab_indices]
+    q25 = np.percentile(lab_counts[lab_counts > 0], 25)
+    q75 = np.percentile(lab_counts[lab_counts > 0], 75)
+    return _groups({"rare (bottom 25%)": f < q25,
+                    "common (middle 50%)": (f >= q25) & (f <= q75),
+                    "very common (top 25%)": f > q75}, predictions, targets)
+
+
+@torch.no_grad()
+def evaluate_model(model, graph, test_edges, config: Dict, output_dir) -> Dict:
+    """evaluate.py:349-570.  ``model`` is this package's HeteroRGCN (or anything with ``eval()``, ``parameters()`` and
+    ``predict_lab_values``); writes ``per_lab_metrics.csv`` and ``evaluation_results.json`` into ``output_dir``."""
+    output_dir = Path(output_dir)
+    model.eval()
+    device = next(model.parameters()).device
+    graph = graph.to(device)
+    edge_indices, edge_values = test_edges
+    edge_indices = edge_indices.to(device)
+    edge_values = edge_values.to(device)
+    patient_indices, lab_indices = edge_indices[0], edge_indices[1]
+
+    predictions = model.predict_lab_values(graph, patient_indices, lab_indices)
+
+    predictions_np = predictions.cpu().numpy()
+    targets_np = edge_values.cpu().numpy()
+    patient_indices_np = patient_indices.cpu().numpy()
+    lab_indices_np = lab_indices.cpu().numpy()
+
+    predictions_np, num_capped = winsorize_residuals(predictions_np, targets_np, lab_indices_np)
+    logging.info(f"  Capped {num_capped}/{len(predictions_np)} outlier residuals")
+
+    overall_metrics = compute_regression_metrics(predictions_np, targets_np)
+    logging.info(f"Overall: MAE {overall_metrics['mae']:.4f} RMSE {overall_metrics['rmse']:.4f} "
+                 f"R2 {overall_metrics['r2']:.4f} MAPE {overall_metrics['mape']:.2f}%")
+
+    ev = config["evaluation"]
+    if ev.get("per_lab_metrics", True):
+        lab_store = graph["lab"]
+        meta = getattr(lab_store, "metadata", None) if "metadata" in lab_store else None
+        if meta:
+            lab_names = {idx: m["label"] for idx, m in meta.items()}
+        else:
+            lab_names = {i: f"Lab_{i}" for i in range(graph["lab"].num_nodes)}
+        per_lab_df = compute_per_lab_metrics(predictions_np, targets_np, lab_indices_np, lab_names)
+        per_lab_df.to_csv(output_dir / "per_lab_metrics.csv", index=False)
+
+    stratified_results = {}
+    if ev.get("stratify_by"):
+        if "num_labs" in ev["stratify_by"]:
+            stratified_results["by_patient_degree"] = stratify_by_patient_degree(
+                predictions_np, targets_np, patient_indices_np, graph)
+        if "lab_frequency" in ev["stratify_by"]:
+            stratified_results["by_lab_frequency"] = stratify_by_lab_frequency(
+                predictions_np, targets_np, lab_indices_np, graph)
+
+    all_results = {"overall_metrics": overall_metrics, "num_test_samples": len(predictions_np),
+                   "stratified_results": stratified_results}
+    with open(output_dir / "evaluation_results.json", "w") as f:
+        json.dump(all_results, f, indent=2)
+    return all_results

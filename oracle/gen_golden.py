@@ -17,6 +17,7 @@ Pins:
   model_eicu.npz   the same at the eICU shape, D=128 (predictions for the 9,224 test pairs,
                    checksums of everything else)
   metrics.npz      evaluate.compute_regression_metrics + the winsorisation loop semantics
+  eval_small.npz   evaluate.evaluate_model end to end on fixed predictions (results json, per-lab csv, baselines)
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
 """
@@ -244,10 +245,52 @@ def gen_metrics():
     save("metrics.npz", {"pred": p, "target": t}, {"metrics": m})
 
 
+class _FixedModel(torch.nn.Module):
+    """Stands where a trained model would: evaluate_model only calls eval(), parameters() and
+    predict_lab_values(), so fixed predictions pin everything AFTER the hot path."""
+
+    def __init__(self, pred):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.pred = pred
+
+    def predict_lab_values(self, graph, patient_indices, lab_indices):
+        assert len(patient_indices) == len(self.pred)
+        return self.pred.clone()
+
+
+def gen_eval():
+    """evaluate.evaluate_model end to end (winsorisation, overall, per-lab csv, both stratifications)."""
+    import tempfile
+    from pathlib import Path
+    cfg = ref_config()
+    g = ref_graph(fx.det_frames(300, 12, 15, 10), cfg)
+    ei = g["patient", "has_lab", "lab"].edge_index
+    ea = g["patient", "has_lab", "lab"].edge_attr.squeeze()
+    E = ei.shape[1]
+    sel = torch.nonzero(fx.det_uniform((E,), 21, 0, 1) < 0.3).squeeze(1)       # ~30 % "test" pairs
+    tgt = ea[sel].clone()
+    pred = tgt + fx.det_uniform((len(sel),), 22, -0.5, 0.5)
+    pred[::37] += 6.0                                                           # outliers the 3-sigma guard caps
+    pred[5::91] -= 4.0
+    tgt[::29] = 0.0                                                             # exercises the MAPE mask
+    with tempfile.TemporaryDirectory() as d:
+        res = ref_eval.evaluate_model(_FixedModel(pred), g, (ei[:, sel], tgt), cfg, Path(d))
+        per_lab = pd.read_csv(os.path.join(d, "per_lab_metrics.csv"))
+    base = ref_eval.evaluate_baselines((ea.numpy().astype(np.float64), ei[1].numpy()),
+                                       (tgt.numpy().astype(np.float64), ei[1, sel].numpy(), None))
+    t = {"sel": sel, "pred": pred, "target": tgt}
+    for c in ("mae", "rmse", "r2", "mape", "lab_index", "num_samples"):
+        t["per_lab/" + c] = per_lab[c].to_numpy()
+    save("eval_small.npz", t, {"results": res, "per_lab_names": per_lab["lab_name"].tolist(), "baselines": base,
+                               "frames": [300, 12, 15, 10]})
+
+
 if __name__ == "__main__":
     gen_edges()
     gen_splits()
     gen_metrics()
+    gen_eval()
     run_model("small", fx.det_frames(300, 12, 15, 10), 64, full_tensors=True)
     run_model("eicu", fx.det_frames(1834, 50, 114, 100), 128, full_tensors=False)
     print("done")
