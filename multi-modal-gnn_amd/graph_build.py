@@ -14,6 +14,7 @@ through the Python key rule.  Golden parity: tests/test_graph_build_cpu.py again
 from __future__ import annotations
 
 import logging
+from pathlib import Path
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -172,3 +173,87 @@ def build_heterogeneous_graph(cohort, labs, diagnoses, medications, demographics
     data.config = config
     validate_graph(data)
     return data
+
+
+def compute_graph_statistics(data) -> Dict:
+    """graph_build.py:644-720: node / edge counts, patient out-degree moments per relation, has_lab density."""
+    stats = {"node_counts": {t: data[t].num_nodes for t in data.node_types},
+             "edge_counts": {et: int(data[et].edge_index.shape[1]) for et in data.edge_types}}
+    for et in data.edge_types:
+        s, rel, _ = et
+        if s == "patient":
+            deg = torch.bincount(data[et].edge_index[0], minlength=data["patient"].num_nodes)
+            stats[f"patient_degree_{rel}"] = {"mean": deg.float().mean().item(), "std": deg.float().std().item(),
+                                              "min": deg.min().item(), "max": deg.max().item(),
+                                              "median": deg.median().item()}
+    if ("patient", "has_lab", "lab") in data.edge_types:
+        n = data["patient", "has_lab", "lab"].edge_index.shape[1]
+        stats["density_patient_lab"] = n / (data["patient"].num_nodes * data["lab"].num_nodes)
+    return stats
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# graph file: the reference pickles the PyG object (torch.save(graph), graph_build.py:769; torch.load, train.py:601),
+# which needs torch_geometric to read back.  Here a graph file is a plain dict of tensors and builtins, readable with
+# torch.load(weights_only=True) and nothing else; load_graph() also accepts a pickled HeteroData when PyG is installed.
+# ------------------------------------------------------------------------------------------------------------------
+GRAPH_FORMAT = "mmgnn.hetero_graph.v1"
+
+
+def save_graph(data, path) -> None:
+    nodes = {}
+    for t in data.node_types:
+        nodes[t] = {"num_nodes": int(data[t].num_nodes)}
+        md = getattr(data[t], "metadata", None) if hasattr(data[t], "metadata") else None
+        if isinstance(md, dict):
+            nodes[t]["metadata"] = {int(k): dict(v) for k, v in md.items()}
+    edges = []
+    for et in data.edge_types:
+        rec = {"type": tuple(et), "edge_index": data[et].edge_index.cpu().contiguous()}
+        if hasattr(data[et], "edge_attr") and getattr(data[et], "edge_attr", None) is not None:
+            rec["edge_attr"] = data[et].edge_attr.cpu().contiguous()
+        edges.append(rec)
+    blob = {"format": GRAPH_FORMAT, "nodes": nodes, "edges": edges}
+    ix = getattr(data, "indexers", None) if hasattr(data, "indexers") else None
+    if ix is not None:
+        blob["indexers"] = {t: {"ids": list(m["id_to_index"].keys())} for t, m in ix.items()}   # index = position
+    path = Path(path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    torch.save(blob, path)
+
+
+def load_graph(path, map_location=None):
+    try:
+        blob = torch.load(path, map_location=map_location, weights_only=True)
+    except Exception:
+        blob = torch.load(path, map_location=map_location, weights_only=False)      # a pickled HeteroData (needs PyG)
+    if not (isinstance(blob, dict) and blob.get("format") == GRAPH_FORMAT):
+        if hasattr(blob, "edge_types") and hasattr(blob, "node_types"):
+            return blob
+        raise ValueError(f"{path}: not a {GRAPH_FORMAT} file nor a HeteroData pickle")
+    g = HeteroGraph()
+    for t, rec in blob["nodes"].items():
+        g[t].num_nodes = rec["num_nodes"]
+        if "metadata" in rec:
+            g[t].metadata = rec["metadata"]
+    for rec in blob["edges"]:
+        et = tuple(rec["type"])
+        g[et].edge_index = rec["edge_index"]
+        if "edge_attr" in rec:
+            g[et].edge_attr = rec["edge_attr"]
+    if "indexers" in blob:
+        g.indexers = {t: {"id_to_index": {k: i for i, k in enumerate(m["ids"])},
+                          "index_to_id": dict(enumerate(m["ids"]))} for t, m in blob["indexers"].items()}
+    return g
+
+
+def build_graph_from_preprocessed(interim_dir, config: Dict, output_path=None) -> HeteroGraph:
+    """graph_build.py:727-772: the six parquet files of preprocess.py -> graph (-> graph file)."""
+    interim_dir = Path(interim_dir)
+    frames = [pd.read_parquet(interim_dir / f"{n}.parquet")
+              for n in ("cohort", "labs_normalized", "diagnoses", "medications", "demographics", "labitems")]
+    graph = build_heterogeneous_graph(*frames, config)
+    compute_graph_statistics(graph)
+    if output_path:
+        save_graph(graph, output_path)
+    return graph

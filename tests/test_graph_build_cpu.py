@@ -100,3 +100,23 @@ def test_validate_graph_rejects_out_of_bounds():
     g["patient"].num_nodes = 3
     with pytest.raises(ValueError, match="out-of-bounds source index"):
         gb.validate_graph(g)
+
+
+def test_graph_file_round_trip_and_parquet_pipeline(tmp_path):
+    frames = frames_to_pandas(fx.det_frames(60, 9, 11, 8))
+    names = ("cohort", "labs_normalized", "diagnoses", "medications", "demographics", "labitems")
+    for n, f in zip(names, frames):
+        f.to_parquet(tmp_path / f"{n}.parquet")
+    g = gb.build_graph_from_preprocessed(tmp_path, CFG, tmp_path / "out" / "graph.pt")
+    gold, meta = load("edges_small.npz")
+    check(g, gold, meta)
+    h = gb.load_graph(tmp_path / "out" / "graph.pt")
+    check(h, gold, meta)                                   # edge tensors, node counts, indexers incl. order
+    assert h.node_types == g.node_types and h["lab"].metadata == g["lab"].metadata
+    assert h.indexers["patient"]["index_to_id"][3] == g.indexers["patient"]["index_to_id"][3]
+    st = gb.compute_graph_statistics(h)
+    assert st["edge_counts"][("patient", "has_lab", "lab")] == g["patient", "has_lab", "lab"].edge_index.shape[1]
+    assert 0 < st["density_patient_lab"] < 1 and st["patient_degree_has_lab"]["max"] <= 9
+    torch.save({"x": 1}, tmp_path / "junk.pt")
+    with pytest.raises(ValueError):
+        gb.load_graph(tmp_path / "junk.pt")
