@@ -196,15 +196,28 @@ typedef struct {
  * other pairs are left untouched in pred / contribute nothing to the gradients.
  * pair_id (nullable) = original position of each pair, used only to key the dropout RNG so that
  * a permuted (patient-sorted) pair list draws the same masks.  seed_ptr (nullable, device): overrides
- * `seed` at run time (hipGraph replays). */
+ * `seed` at run time (hipGraph replays).
+ * sel / n_sel (both nullable, device): a compacted list of pair positions built by mmg_pair_select -- only
+ * sel[0 .. *n_sel) are visited (in list order) and `n_pairs` is then an upper bound of *n_sel that sizes the
+ * launch.  Forward: the per-head lists (static per pair set) replace the predicated sweep over all pairs.
+ * Backward: pairs whose upstream gradient is exactly 0 (the ~80 % of train pairs outside the supervision
+ * subset, src/train.py:366-370) contribute exactly 0 to every gradient and are skipped. */
 int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li,
                       const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs,
                       float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
-                      float* pred, void* stream);
+                      float* pred, const int32_t* sel, const int32_t* n_sel, void* stream);
 int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,
                       const int32_t* pi, const int32_t* li, const int32_t* deg, int degree_threshold,
                       int want_low, int64_t n_pairs, int n_labs, float drop_p, uint64_t seed,
-                      const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred, void* stream);
+                      const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred,
+                      const int32_t* sel, const int32_t* n_sel, void* stream);
+
+/* Stable two-way compaction of pair positions by head: position k goes to sel_low if deg[pi[k]] < threshold,
+ * else to sel_high -- and only if dpred is NULL or dpred[k] != 0.  Order inside a list = pair order (pairs sorted
+ * by patient stay sorted).  counts[0], counts[1] (device) = list lengths.  sel_low / sel_high: capacity n each. */
+size_t mmg_pair_select_ws_bytes(int64_t n_pairs);
+int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold, const float* dpred, int64_t n_pairs,
+                    int32_t* sel_low, int32_t* sel_high, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -75,8 +75,10 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
                                                  int want_low, int64_t n, int n_labs, int lds_db, float drop_p,
                                                  uint64_t seed, const uint64_t* __restrict__ seed_ptr,
                                                  const int64_t* __restrict__ pair_id,
-                                                 const float* __restrict__ dpred) {
+                                                 const float* __restrict__ dpred, const int32_t* __restrict__ sel,
+                                                 const int32_t* __restrict__ n_sel) {
   if (seed_ptr) seed = *seed_ptr;
+  if (sel) n = *n_sel;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* W2s = sm + OFF_W2; float* b2s = sm + OFF_B2; float* W3s = sm + OFF_W3;
   float* T1t = sm + OFF_T1; float* T2t = sm + OFF_T2;
@@ -95,9 +97,10 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
 
   const int64_t n_tiles = (n + PT - 1) / PT;
   for (int64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const int64_t k = t * PT + tid;
+    int64_t k = t * PT + tid;
     int p_i = -1, l_i = 0;
     if (k < n) {
+      if (sel) k = sel[k];
       const int pp = pi[k];
       if (((int)(deg[pp] < thr)) == want_low) { p_i = pp; l_i = li[k]; }
     }
@@ -216,8 +219,10 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
                                                        int thr, int want_low, int64_t n, int n_labs, float drop_p,
                                                        uint64_t seed, const uint64_t* __restrict__ seed_ptr,
                                                        const int64_t* __restrict__ pair_id,
-                                                       const float* __restrict__ dpred) {
+                                                       const float* __restrict__ dpred, const int32_t* __restrict__ sel,
+                                                       const int32_t* __restrict__ n_sel) {
   if (seed_ptr) seed = *seed_ptr;
+  if (sel) n = *n_sel;                   // compacted pair list (device-resident length): see mmg_pair_select
   __shared__ __attribute__((aligned(16))) float sm[4 * WAVE_LDS];
   __shared__ __attribute__((aligned(16))) float W2s[32 * LDH];      // W2[u][k], row stride LDH (shared by the 4 waves)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -251,8 +256,9 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
   struct Meta { int p_i; int l_i; float dout; uint64_t pid; };
   auto load_meta = [&](int64_t t) {
     Meta m{-1, 0, 0.f, 0ull};
-    const int64_t k = t * TP + l31;
+    int64_t k = t * TP + l31;
     if (t < n_tiles && k < n) {
+      if (sel) k = sel[k];
       const int pp = pi[k];
       if (((int)(deg[pp] < thr)) == want_low) {
         m.p_i = pp; m.l_i = li[k];
@@ -461,8 +467,11 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
                                                           const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                           int thr, int want_low, int64_t n, float drop_p, uint64_t seed,
                                                           const uint64_t* __restrict__ seed_ptr,
-                                                          const int64_t* __restrict__ pair_id, float* __restrict__ pred) {
+                                                          const int64_t* __restrict__ pair_id, float* __restrict__ pred,
+                                                          const int32_t* __restrict__ sel,
+                                                          const int32_t* __restrict__ n_sel) {
   if (seed_ptr) seed = *seed_ptr;
+  if (sel) n = *n_sel;
   __shared__ unsigned PL[4][TP], PH[4][TP];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -474,14 +483,15 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
 
   const int64_t n_tiles = (n + TP - 1) / TP;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid, n_waves = (int64_t)gridDim.x * 4;
-  struct Meta { int p_i; int l_i; uint64_t pid; };
+  struct Meta { int p_i; int l_i; int k; uint64_t pid; };
   auto load_meta = [&](int64_t t) {
-    Meta m{-1, 0, 0ull};
-    const int64_t k = t * TP + l31;
+    Meta m{-1, 0, 0, 0ull};
+    int64_t k = t * TP + l31;
     if (t < n_tiles && k < n) {
+      if (sel) k = sel[k];
       const int pp = pi[k];
       if (((int)(deg[pp] < thr)) == want_low) {
-        m.p_i = pp; m.l_i = li[k];
+        m.p_i = pp; m.l_i = li[k]; m.k = (int)k;
         m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
       }
     }
@@ -558,9 +568,107 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
     const int r = (b4 ? 8 : 0) + (b3b ? 4 : 0) + (b2b ? 2 : 0) + (b1b ? 1 : 0);
     const int row = crow(r, h);
     const int owner = __shfl(mc.p_i, row, 64);          // lane `row` (half 0) holds that pair's metadata
-    if ((l31 & 1) == 0 && owner >= 0) {
-      const int64_t k = t * TP + row;
-      if (k < n) pred[k] = w1 + b3;
+    const int ok = __shfl(mc.k, row, 64);
+    if ((l31 & 1) == 0 && owner >= 0) pred[ok] = w1 + b3;
+  }
+}
+
+// ---------------------------------------------------------------------------- pair selection (stable compaction)
+constexpr int SEL_PER = 8, SEL_CH = 256 * SEL_PER;      // pairs per thread / per workgroup
+
+// packed per-thread counts: low list in bits 0..15, high list in bits 16..31 (a chunk holds 2048 pairs)
+__device__ inline unsigned sel_flags(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg, int thr,
+                                     const float* __restrict__ dpred, int64_t n, int64_t k0, unsigned* bits) {
+  unsigned cnt = 0, lowbits = 0, anybits = 0;
+#pragma unroll
+  for (int j = 0; j < SEL_PER; ++j) {
+    const int64_t k = k0 + j;
+    if (k < n && (!dpred || dpred[k] != 0.f)) {
+      const bool low = deg[pi[k]] < thr;
+      anybits |= 1u << j;
+      if (low) { lowbits |= 1u << j; cnt += 1u; } else cnt += 1u << 16;
+    }
+  }
+  *bits = anybits | (lowbits << 8);
+  return cnt;
+}
+
+__device__ inline unsigned block_excl_scan(unsigned v, unsigned* total, unsigned* sm /*[4]*/) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  unsigned inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) sm[wid] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { if (w < wid) base += sm[w]; tot += sm[w]; }
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_sel_count(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg,
+                                                   int thr, const float* __restrict__ dpred, int64_t n,
+                                                   unsigned* __restrict__ cnt) {
+  __shared__ unsigned sm[4];
+  unsigned bits, tot;
+  const unsigned c = sel_flags(pi, deg, thr, dpred, n, (int64_t)blockIdx.x * SEL_CH + threadIdx.x * SEL_PER, &bits);
+  block_excl_scan(c, &tot, sm);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+
+// one workgroup: exclusive scan of the packed chunk counts (two 32-bit running sums), totals -> counts[2]
+__global__ __launch_bounds__(1024) void k_sel_scan(const unsigned* __restrict__ cnt, int nb, int2* __restrict__ base,
+                                                   int32_t* __restrict__ counts) {
+  __shared__ int2 wsum[16];
+  __shared__ int2 carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry = make_int2(0, 0);
+  __syncthreads();
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int b = b0 + tid;
+    const unsigned c = b < nb ? cnt[b] : 0u;
+    int lo = (int)(c & 0xFFFFu), hi = (int)(c >> 16);
+    int ilo = lo, ihi = hi;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int tl = __shfl_up(ilo, o, 64), th = __shfl_up(ihi, o, 64);
+      if (lane >= o) { ilo += tl; ihi += th; }
+    }
+    if (lane == 63) wsum[wid] = make_int2(ilo, ihi);
+    __syncthreads();
+    int bl = carry.x, bh = carry.y, tl = 0, th = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wid) { bl += wsum[w].x; bh += wsum[w].y; }
+      tl += wsum[w].x; th += wsum[w].y;
+    }
+    if (b < nb) base[b] = make_int2(bl + ilo - lo, bh + ihi - hi);
+    __syncthreads();
+    if (tid == 0) { carry.x += tl; carry.y += th; }
+    __syncthreads();
+  }
+  if (tid == 0) { counts[0] = carry.x; counts[1] = carry.y; }
+}
+
+__global__ __launch_bounds__(256) void k_sel_write(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg,
+                                                   int thr, const float* __restrict__ dpred, int64_t n,
+                                                   const int2* __restrict__ base, int32_t* __restrict__ sel_low,
+                                                   int32_t* __restrict__ sel_high) {
+  __shared__ unsigned sm[4];
+  unsigned bits, tot;
+  const int64_t k0 = (int64_t)blockIdx.x * SEL_CH + threadIdx.x * SEL_PER;
+  const unsigned c = sel_flags(pi, deg, thr, dpred, n, k0, &bits);
+  const unsigned off = block_excl_scan(c, &tot, sm);
+  const int2 b = base[blockIdx.x];
+  int ol = b.x + (int)(off & 0xFFFFu), oh = b.y + (int)(off >> 16);
+#pragma unroll
+  for (int j = 0; j < SEL_PER; ++j) {
+    if (bits & (1u << j)) {
+      if (bits & (1u << (8 + j))) sel_low[ol++] = (int32_t)(k0 + j);
+      else sel_high[oh++] = (int32_t)(k0 + j);
     }
   }
 }
@@ -581,8 +689,10 @@ int check_head(const mmg_head_t* h, const char* what) {
 
 extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
                                  int degree_threshold, int want_low, int64_t n_pairs, float drop_p, uint64_t seed,
-                                 const uint64_t* seed_ptr, const int64_t* pair_id, float* pred, void* stream) {
+                                 const uint64_t* seed_ptr, const int64_t* pair_id, float* pred, const int32_t* sel,
+                                 const int32_t* n_sel, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0, "pair_head_fwd: n_pairs < 0");
+  MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_fwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
   int rc = check_head(head, "pair_head_fwd");
   if (rc) return rc;
@@ -593,7 +703,7 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(k_pair_fwd_mfma, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, H, pi, li, deg,
-                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred);
+                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel);
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;
 }
@@ -601,8 +711,9 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
 extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi, const int32_t* li,
                                  const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
                                  float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
-                                 const float* dpred, void* stream) {
+                                 const float* dpred, const int32_t* sel, const int32_t* n_sel, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0 && n_labs >= 0, "pair_head_bwd: negative size");
+  MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_bwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
   int rc = check_head(head, "pair_head_bwd");
   if (rc) return rc;
@@ -620,7 +731,7 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     if (g < 1) g = 1;
 #define MMG_LAUNCH_PBWD(LT_)                                                                                          \
   hipLaunchKernelGGL((k_pair_bwd_mfma<LT_>), dim3((unsigned)g), dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, \
-                     want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, seed_ptr, pair_id, dpred)
+                     want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel)
     if (n_labs <= 64) MMG_LAUNCH_PBWD(2);
     else MMG_LAUNCH_PBWD(4);
 #undef MMG_LAUNCH_PBWD
@@ -636,8 +747,39 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     int64_t g = (n_pairs + PT - 1) / PT;
     if (g > 512) g = 512;
     hipLaunchKernelGGL(k_pair_bwd, dim3((unsigned)g), dim3(PT), lds, st, H, G, pi, li, deg, degree_threshold,
-                       want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, seed_ptr, pair_id, dpred);
+                       want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel);
   }
   MMG_CHECK_LAUNCH("pair_head_bwd");
+  return MMG_OK;
+}
+
+extern "C" size_t mmg_pair_select_ws_bytes(int64_t n_pairs) {
+  const int64_t nb = (n_pairs + SEL_CH - 1) / SEL_CH;
+  return (size_t)(nb > 0 ? nb : 1) * (sizeof(unsigned) + sizeof(int2)) + 64;
+}
+
+extern "C" int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold, const float* dpred,
+                               int64_t n_pairs, int32_t* sel_low, int32_t* sel_high, int32_t* counts, void* ws,
+                               size_t ws_bytes, void* stream) {
+  MMG_CHECK_ARG(n_pairs >= 0 && n_pairs < (int64_t)INT32_MAX, "pair_select: n_pairs out of range");
+  MMG_CHECK_ARG(counts, "pair_select: counts is null");
+  hipStream_t st = (hipStream_t)stream;
+  if (n_pairs == 0) {
+    if (hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st) != hipSuccess) {
+      mmg_set_error("pair_select: memset failed");
+      return MMG_E_LAUNCH;
+    }
+    return MMG_OK;
+  }
+  MMG_CHECK_ARG(pi && deg && sel_low && sel_high, "pair_select: null buffer");
+  MMG_CHECK_ARG(ws && ws_bytes >= mmg_pair_select_ws_bytes(n_pairs), "pair_select: workspace too small");
+  const int nb = (int)((n_pairs + SEL_CH - 1) / SEL_CH);
+  int2* base = reinterpret_cast<int2*>(ws);                                  // 8-byte aligned: first in the workspace
+  unsigned* cnt = reinterpret_cast<unsigned*>(base + nb);
+  hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, n_pairs, cnt);
+  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, cnt, nb, base, counts);
+  hipLaunchKernelGGL(k_sel_write, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, n_pairs, base, sel_low,
+                     sel_high);
+  MMG_CHECK_LAUNCH("pair_select");
   return MMG_OK;
 }

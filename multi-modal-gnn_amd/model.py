@@ -189,10 +189,13 @@ class HeteroRGCN(nn.Module):
         return run.apply("predict", patient_indices, lab_indices)
 
     # pairs sorted by patient (cached: the split is static across epochs)
-    def _pairs(self, pi: torch.Tensor, li: torch.Tensor, n_rows: int, pair_ids: Optional[torch.Tensor] = None):
-        """(pi, li) sorted by patient -> (pi32, li32, perm, rng ids).  Cached per tensor OBJECT (the cache
-        holds the tensors, so their storage cannot be recycled under a stale entry)."""
-        key = (id(pi), id(li), pi._version, li._version, n_rows, id(pair_ids))
+    def _pairs(self, pi: torch.Tensor, li: torch.Tensor, n_rows: int, pair_ids: Optional[torch.Tensor] = None,
+               deg: Optional[torch.Tensor] = None, thr: int = 0):
+        """(pi, li) sorted by patient -> (pi32, li32, perm, rng ids, head lists).  Cached per tensor OBJECT (the
+        cache holds the tensors, so their storage cannot be recycled under a stale entry).  head lists = the
+        positions served by tabular_mlp / edge_predictor (deg[pi] < thr or not; static per pair set):
+        (sel_low, sel_high, counts_dev, n_low, n_high)."""
+        key = (id(pi), id(li), pi._version, li._version, n_rows, id(pair_ids), id(deg), int(thr))
         hit = self._pair_cache.get(key)
         if hit is not None:
             return hit[0]
@@ -204,10 +207,15 @@ class HeteroRGCN(nn.Module):
         perm64 = perm.to(torch.int64)
         pi_sorted = pi.to(torch.int32)[perm64].contiguous()
         ids = perm64 if pair_ids is None else pair_ids.to(torch.int64)[perm64].contiguous()
-        out = (pi_sorted, li_sorted, perm64, ids)
+        lists = None
+        if deg is not None:
+            sel_low, sel_high, counts = ops.pair_select(pi_sorted, deg, int(thr))
+            n_low, n_high = counts.tolist()             # one-off sync per pair set (sizes the launches)
+            lists = (sel_low[:max(n_low, 1)].clone(), sel_high[:max(n_high, 1)].clone(), counts, n_low, n_high)
+        out = (pi_sorted, li_sorted, perm64, ids, lists)
         if len(self._pair_cache) >= 6:
             self._pair_cache.clear()
-        self._pair_cache[key] = (out, pi, li, pair_ids)
+        self._pair_cache[key] = (out, pi, li, pair_ids, deg)
         return out
 
 
@@ -282,7 +290,8 @@ class _Run:
             if pi.device != self.dev or li.device != self.dev:
                 raise ops._lib.MmgError("patient_indices / lab_indices must live on the model's device")
             self.pairs = self.m._pairs(pi, li, self.plan.n_rows,
-                                       getattr(self.comm, "pair_ids", None) if self.comm else None)
+                                       getattr(self.comm, "pair_ids", None) if self.comm else None,
+                                       self.plan.lab_deg, int(self.m.degree_threshold))
             self.n_pairs = pi.numel()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params.values())
         self.need_grad = need_grad
@@ -594,13 +603,15 @@ class _Run:
         plan = self.plan
         if LAB_EDGE not in plan.rels:
             raise KeyError(f"graph has no {LAB_EDGE} relation (model.py:297)")
-        pi, li, perm, ids = self.pairs
+        pi, li, perm, ids, (sel_low, sel_high, counts, n_low, n_high) = self.pairs
         thr = int(self.m.degree_threshold)
-        pred_s = torch.zeros(pi.numel(), device=self.dev)
+        pred_s = torch.empty(pi.numel(), device=self.dev)        # every pair belongs to exactly one head list
         rec = dict(init=init, fin=fin)
         for which, src, want_low in (("edge_predictor", fin, False), ("tabular_mlp", init, True)):
             head, w1a, w1b = self.head_tensors(which, src[ROW_TYPE], src["lab"])
-            ops.pair_head_fwd(head, pi, li, plan.lab_deg, thr, want_low, self.p, self.seed, ids, pred_s, self.seed_dev)
+            sel, n_sel, nb = (sel_low, counts[0:1], n_low) if want_low else (sel_high, counts[1:2], n_high)
+            ops.pair_head_fwd(head, pi, li, plan.lab_deg, thr, want_low, self.p, self.seed, ids, pred_s, self.seed_dev,
+                              sel=sel, n_sel=n_sel, n_bound=nb)
             rec[which] = (head, w1a, w1b)
         pred = torch.empty_like(pred_s)
         pred[perm] = pred_s                      # back to the caller's pair order
@@ -608,16 +619,21 @@ class _Run:
 
     def heads_bwd(self, rec, dpred):
         plan, D = self.plan, self.D
-        pi, li, perm, ids = self.pairs
+        pi, li, perm, ids, (_, _, _, n_low, n_high) = self.pairs
         thr = int(self.m.degree_threshold)
         dps = dpred[perm].contiguous()
         n_lab = plan.num_nodes["lab"]
         gsets = {}
+        # pairs with a zero upstream gradient (everything outside the supervision subset, train.py:366-370) add
+        # exactly nothing: visit only the others, split by head
+        bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps)
         for which, src, want_low in (("edge_predictor", rec["fin"], False), ("tabular_mlp", rec["init"], True)):
             head, w1a, w1b = rec[which]
             g = ops.Head(torch.zeros_like(head.A), torch.zeros_like(head.B), torch.zeros_like(head.W2),
                          torch.zeros_like(head.b2), torch.zeros_like(head.W3), torch.zeros_like(head.b3))
-            ops.pair_head_bwd(head, g, pi, li, plan.lab_deg, thr, want_low, n_lab, self.p, self.seed, ids, dps, self.seed_dev)
+            sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
+            ops.pair_head_bwd(head, g, pi, li, plan.lab_deg, thr, want_low, n_lab, self.p, self.seed, ids, dps,
+                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb)
             self.allreduce(g.B)                  # lab-side partials from sharded pairs
             self.acc(f"{which}.mlp.3.weight", g.W2, partial=True)
             self.acc(f"{which}.mlp.3.bias", g.b2, partial=True)

@@ -386,28 +386,53 @@ class Head:
         return HeadT(_p(self.A), _p(self.B), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3))
 
 
-def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred, seed_dev=None):
+def pair_select(pi, deg, thr: int, dpred=None):
+    """Stable compaction of pair positions by head (mmg_pair_select) -> (sel_low, sel_high, counts[2] on device).
+    With `dpred`, positions whose upstream gradient is exactly 0 are dropped."""
     lib = _lib.load()
     n = pi.numel()
+    sel_low = torch.empty(max(n, 1), dtype=torch.int32, device=pi.device)
+    sel_high = torch.empty(max(n, 1), dtype=torch.int32, device=pi.device)
+    counts = torch.empty(2, dtype=torch.int32, device=pi.device)
+    ws = workspace(lib.mmg_pair_select_ws_bytes(n), pi.device)
+    _tok = _pb("pair_select")
+    check(lib.mmg_pair_select(_p(pi, torch.int32), _p(deg, torch.int32), thr, _p(dpred), n, _p(sel_low, torch.int32),
+                              _p(sel_high, torch.int32), _p(counts, torch.int32), _p(ws, torch.uint8), ws.numel(),
+                              _stream()), "mmg_pair_select")
+    _pe(_tok, "pair_select", n * 24)
+    return sel_low, sel_high, counts
+
+
+def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred, seed_dev=None,
+                  sel=None, n_sel=None, n_bound: Optional[int] = None):
+    """sel / n_sel: compacted positions (pair_select) and their device-resident count; n_bound >= that count."""
+    lib = _lib.load()
+    n = pi.numel() if sel is None else int(n_bound)
+    if n == 0:
+        return
     h = head.c()
     _tok = _pb("pair_head_fwd")
     check(lib.mmg_pair_head_fwd(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
                                 int(want_low), n, float(p), seed & 0xFFFFFFFFFFFFFFFF, _p(seed_dev, torch.int64),
-                                _p(pair_id, torch.int64), _p(pred), _stream()), "mmg_pair_head_fwd")
+                                _p(pair_id, torch.int64), _p(pred), _p(sel, torch.int32), _p(n_sel, torch.int32),
+                                _stream()), "mmg_pair_head_fwd")
     _pe(_tok, "pair_head_fwd", n * 12 + 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (64 * 32 + 32 + 64))
 
 
 def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool, n_labs: int, p: float, seed: int,
-                  pair_id, dpred, seed_dev=None):
+                  pair_id, dpred, seed_dev=None, sel=None, n_sel=None, n_bound: Optional[int] = None):
     """`grads` mirrors `head` (dA,dB,dW2,db2,dW3,db3), accumulated in place."""
     lib = _lib.load()
-    n = pi.numel()
+    n = pi.numel() if sel is None else int(n_bound)
+    if n == 0:
+        return
     h = head.c()
     g = HeadGradT(_p(grads.A), _p(grads.B), _p(grads.W2), _p(grads.b2), _p(grads.W3), _p(grads.b3))
     _tok = _pb("pair_head_bwd")
     check(lib.mmg_pair_head_bwd(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32),
                                 thr, int(want_low), n, n_labs, float(p), seed & 0xFFFFFFFFFFFFFFFF,
-                                _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _stream()),
+                                _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _p(sel, torch.int32),
+                                _p(n_sel, torch.int32), _stream()),
           "mmg_pair_head_bwd")
     _pe(_tok, "pair_head_bwd", n * 12 + 2 * 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (4 * 64 * 32))
 

@@ -359,6 +359,61 @@ def test_pair_head_fwd_bwd(ops, dev, p, sorted_pairs):
         for name, got, want in zip("A B W2 b2 W3 b3".split(), (g.A, g.B, g.W2, g.b2, g.W3, g.b3), leaf):
             assert rel(got, want.grad) <= 2e-5, (name, want_low)
 
+@pytest.mark.parametrize("n", [1, 2047, 2048, 70001])
+def test_pair_select_stable_two_way(ops, dev, n):
+    gen = torch.Generator().manual_seed(n)
+    P = 300
+    pi = torch.randint(0, P, (n,), generator=gen).sort().values
+    deg = torch.randint(0, 12, (P,), generator=gen)
+    dpred = torch.randn(n, generator=gen) * (torch.rand(n, generator=gen) < 0.2)
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    for dp in (None, dpred):
+        lo, hi, cnt = ops.pair_select(i32(pi), i32(deg), 6, None if dp is None else dp.to(dev))
+        live = torch.ones(n, dtype=torch.bool) if dp is None else dp != 0
+        want_lo = torch.nonzero(live & (deg[pi] < 6)).squeeze(1)
+        want_hi = torch.nonzero(live & (deg[pi] >= 6)).squeeze(1)
+        assert cnt.tolist() == [want_lo.numel(), want_hi.numel()]
+        assert torch.equal(lo[:want_lo.numel()].cpu().long(), want_lo)          # bit-exact, order kept
+        assert torch.equal(hi[:want_hi.numel()].cpu().long(), want_hi)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_pair_head_selected_lists_match_full_sweep(ops, dev, p):
+    """Heads driven by compacted lists (forward: per head; backward: per head and non-zero upstream gradient) give
+    what the predicated sweep over all pairs gives."""
+    gen = torch.Generator().manual_seed(5)
+    P, L, n = 500, 50, 9000
+    A, B = torch.randn(P, 64, generator=gen), torch.randn(L, 64, generator=gen)
+    W2, b2 = torch.randn(32, 64, generator=gen) / 8, torch.randn(32, generator=gen) * 0.1
+    W3, b3 = torch.randn(32, generator=gen) / 5, torch.randn(1, generator=gen)
+    pi = torch.randint(0, P, (n,), generator=gen).sort().values
+    li = torch.randint(0, L, (n,), generator=gen)
+    deg = torch.randint(0, 12, (P,), generator=gen)
+    pid = torch.randperm(n, generator=gen).to(dev)
+    dpred = (torch.randn(n, generator=gen) * (torch.rand(n, generator=gen) < 0.2)).to(dev)
+    head = ops.Head(*[t.to(dev) for t in (A, B, W2, b2, W3, b3)])
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    pi_d, li_d, deg_d = i32(pi), i32(li), i32(deg)
+    flo, fhi, fcnt = ops.pair_select(pi_d, deg_d, 6)
+    blo, bhi, bcnt = ops.pair_select(pi_d, deg_d, 6, dpred)
+    nf = fcnt.tolist()
+    full, listed = torch.zeros(n, device=dev), torch.full((n,), -7.0, device=dev)
+    for want_low in (False, True):
+        ops.pair_head_fwd(head, pi_d, li_d, deg_d, 6, want_low, p, 9, pid, full)
+        sel, k = (flo, 0) if want_low else (fhi, 1)
+        ops.pair_head_fwd(head, pi_d, li_d, deg_d, 6, want_low, p, 9, pid, listed, sel=sel, n_sel=fcnt[k:k + 1],
+                          n_bound=nf[k])
+    assert torch.equal(full, listed)                      # same arithmetic per pair: bitwise equal
+    for want_low in (False, True):
+        g0 = ops.Head(*[torch.zeros_like(t, device=dev) for t in (A, B, W2, b2, W3, b3)])
+        g1 = ops.Head(*[torch.zeros_like(t, device=dev) for t in (A, B, W2, b2, W3, b3)])
+        ops.pair_head_bwd(head, g0, pi_d, li_d, deg_d, 6, want_low, L, p, 9, pid, dpred)
+        sel, k = (blo, 0) if want_low else (bhi, 1)
+        ops.pair_head_bwd(head, g1, pi_d, li_d, deg_d, 6, want_low, L, p, 9, pid, dpred, sel=sel, n_sel=bcnt[k:k + 1],
+                          n_bound=nf[k])
+        for name in "A B W2 b2 W3 b3".split():
+            assert rel(getattr(g1, name), getattr(g0, name).double().cpu()) <= 2e-5, (name, want_low)
+
 
 @pytest.mark.parametrize("loss_type", ["mae", "mse"])
 def test_weighted_pair_loss(ops, dev, loss_type):
