@@ -76,8 +76,19 @@ typedef struct {
   int32_t n_cols;
   uint32_t flags;          /* MMG_REL_SIMPLE: no (row, col) pair occurs twice -- enables the 0/1 indicator
                               (bf16-split MFMA) kernels; multigraphs take the counting fp32 path */
+  const uint64_t* mask_t;  /* NULL, or the relation's adjacency as bit planes (mmg_rel_mask_build): word
+                              [row / 64][col][(row % 64 / 8) & 1] has bit 16 * (row % 64 / 16) + 4 + row % 8 set
+                              iff (row, col) is an edge (four 16-bit fields, one per 16 rows, each holding 8 row
+                              bits << 4); [ceil(n_rows / 64)][pad32(n_cols)][2] words.  Simple relations only. */
 } mmg_rel_t;
 #define MMG_REL_SIMPLE 1u
+
+/* One-off per static graph: the bit-plane form of a CSR-by-row relation (40 B per patient at the eICU vocab
+ * instead of 4 B per edge).  The scatter kernels expand indicator fragments for the matrix cores straight from
+ * these words.  mask_t must hold mmg_rel_mask_words(n_rows, n_cols) uint64; it is zeroed here. */
+size_t mmg_rel_mask_words(int64_t n_rows, int32_t n_cols);
+int mmg_rel_mask_build(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t n_cols,
+                       uint64_t* mask_t, void* stream);
 
 int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
                     float* out, int accumulate, void* stream);

@@ -18,6 +18,7 @@ struct RelDev {
   const int32_t* rowptr; const int32_t* col; const float* rowscale; const float* colscale;
   const float* table; float* out; int32_t n_cols; int32_t acc_off;   // acc_off: first accumulator row
   uint32_t flags;
+  const uint64_t* mask;      // bit planes (simple relations) or null
 };
 struct RelPack { RelDev r[MMG_MAX_REL]; int n; };
 
@@ -425,6 +426,7 @@ struct ScatterPlan {
   int n_split;
   int64_t rows_per_split;
   bool ok;
+  bool bf16;           // all relations simple and the tiles fit: the bf16-split matrix-core kernel
 };
 
 int pad32(int n) { return (n + 31) & ~31; }
@@ -450,6 +452,26 @@ ScatterPlan plan_scatter(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D
   p.rows_per_split = rps;
   p.n_split = (int)((n_rows + rps - 1) / rps);
   if (p.n_split < 1) p.n_split = 1;
+  // bf16-split kernel: one 512-thread workgroup per CU, stages of SB_SR rows dealt out evenly
+  static const int no_bf16 = [] { const char* e = getenv("MMG_SCATTER_FP32"); return e ? atoi(e) : 0; }();
+  bool simple = true;
+  for (int r = 0; r < n_rel; ++r)
+    simple &= ((rels[r].flags & MMG_REL_SIMPLE) != 0 && rels[r].mask_t != nullptr) || rels[r].n_cols == 0;
+  p.bf16 = p.ok && simple && !no_bf16 && p.nt <= 10 && n_rows >= 64;
+  bool has_rs = false;
+  for (int r = 0; r < n_rel; ++r) has_rs |= rels[r].rowscale != nullptr;
+  if (p.bf16 && has_rs) {
+    // the rowscale kernel needs a compile-time tile -> relation map: instances exist for the eICU vocabulary
+    // (50 / 114 / 100 items -> tiles 2 | 4 | 4) at 128 feature columns per workgroup; others count in fp32
+    p.bf16 = n_rel == 3 && p.nt == 10 && p.dc == 128 && pad32(rels[0].n_cols) == 64 && pad32(rels[1].n_cols) == 128 &&
+             pad32(rels[2].n_cols) == 128;
+  }
+  if (p.bf16) {
+    const int64_t nst = (n_rows + 63) / 64;
+    int64_t g = 256 / p.n_dchunks;
+    if (g > nst) g = nst;
+    p.n_split = (int)g;
+  }
   return p;
 }
 
@@ -540,6 +562,245 @@ __global__ __launch_bounds__(256, 2) void k_scatter_mfma(RelPack rp, int64_t n_r
     }
 }
 
+
+// ------------------------------------------------------------------------------ scatter on the bf16 matrix cores
+// Simple relations (MMG_REL_SIMPLE: no repeated (patient, item) pair -- the reference's frames are de-duplicated)
+// have a 0/1 indicator, exact in bf16, and an fp32 feature splits exactly into three bf16 pieces (8 significant
+// bits each).  Ind^T . x is then three v_mfma_f32_32x32x16_bf16 per 16 patients with EXACT products and fp32
+// accumulation: the fp32 result up to summation order at 16x the fp32 matrix rate (12.4 GFLOP of fp32 MFMA work,
+// 79 us at peak, becomes 15 us).
+// The indicator never exists in memory: the relation's adjacency is kept as bit planes (mmg_rel_mask_build; two
+// words per [64-row stage][item] = which of the 64 patients have the item, 80 B per patient instead of 180 B of
+// CSR), a lane holds the word of ITS item row and patient half, and the A fragment of a k-step (8 patients) is
+// one field of that word expanded through a 256-entry LDS table.  No index chasing, no tile build, no barrier: every wave streams x straight from
+// HBM into registers (lane = feature column, 8 patient rows per k-step, three k-steps of loads in flight), splits,
+// and feeds the matrix cores; accumulators stay in registers for the whole row range of the workgroup.
+// A rowscale (backward of the mean gather) multiplies x per relation before the split.
+// Measured on MI355X (x100 eICU shape, 183,400 rows x 128, 320 padded items): 46 us without / 57 us with rowscale
+// (the fp32-MFMA indicator kernel above: 192 / 216 us).  Ablations: no x loads 45 us, no split and no LUT reads
+// 42 us -- the kernel runs at the pace of its 1.38 M matrix instructions (37 GFLOP of bf16 MFMA at the ~1.3 PF/s
+// the chip sustains on random data), not of HBM (94 MB, 2.0 TB/s).
+constexpr int SB_SR = 64;                    // patient rows per stage = bits per mask word (4 k-steps of 16)
+
+__device__ inline void split8(const float* v, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 a = (__bf16)v[j];
+    const float r1 = v[j] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    p0[j] = a; p1[j] = b; p2[j] = (__bf16)(r1 - (float)b);
+  }
+}
+
+// RS = 1: a rowscale per relation, relation r owning the item tiles [T(r), T(r+1)) with T = {0, T1, T2, NT} fixed at
+// compile time (the tile -> relation map must be static for the accumulators to stay in registers).
+template <int NT, int KT, int RS, int T1, int T2>
+__global__ __launch_bounds__(256) void k_scatter_bits(RelPack rp, int64_t n_rows, int n_stage_total, int D,
+                                                      const float* __restrict__ x, float* __restrict__ slab) {
+  // One wave per SIMD (the accumulators of ALL item tiles + an 8-deep operand ring need > 256 registers): latency
+  // is hidden by run-ahead, not by occupancy -- 6 k-steps x 2 KB x 4 waves = 48 KB of x in flight per CU -- and the
+  // operands of k-step q+1 (bf16 split, indicator fragments) are produced in the shadow of the MFMAs of k-step q.
+  constexpr int NTOT = NT * 32, NSPLIT = 4 / KT, NTW = (NT + NSPLIT - 1) / NSPLIT;
+  constexpr int KS = 8, RING = 8, AHEAD = 6, NREL = RS ? 3 : 1;
+  static_assert(!RS || KT == 4, "static tile -> relation map needs every wave to own all item tiles");
+  __shared__ __attribute__((aligned(16))) unsigned lut[256][4];            // byte -> 8 bf16 in {0, 1}
+  __shared__ __attribute__((aligned(16))) float rss[RS ? 2 : 1][RS ? 4 : 1][3][2 * SB_SR];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int kt = wid % KT, nt0 = (wid / KT) * NTW;
+  const int d0 = blockIdx.y * (KT * 32);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
+  __syncthreads();
+  const int s_beg = (int)((int64_t)blockIdx.x * n_stage_total / gridDim.x);
+  const int s_end = (int)((int64_t)(blockIdx.x + 1) * n_stage_total / gridDim.x);
+  const int ns = s_end - s_beg;
+  const int64_t r_beg = (int64_t)s_beg * SB_SR;
+
+  // this wave's tiles: mask pointer (lane = item row of the tile and patient half), words per stage.
+  // Padding tiles (no relation) read some valid word and select the all-zero LUT entry.
+  const uint64_t* mb[NTW];
+  int ms[NTW];
+  bool live[NTW];
+  const uint64_t* any_mask = nullptr;
+#pragma unroll
+  for (int r = 0; r < MMG_MAX_REL; ++r)
+    if (r < rp.n && rp.r[r].mask && !any_mask) any_mask = rp.r[r].mask;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    mb[t] = any_mask; ms[t] = 0; live[t] = false;
+    const int c0 = (nt0 + t) * 32;
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      if (r >= rp.n) continue;
+      const int padc = (rp.r[r].n_cols + 31) & ~31;
+      if (rp.r[r].mask && c0 >= rp.r[r].acc_off && c0 < rp.r[r].acc_off + padc) {
+        mb[t] = rp.r[r].mask + ((size_t)s_beg * padc + (c0 - rp.r[r].acc_off) + l31) * 2 + h;
+        ms[t] = 2 * padc; live[t] = true;
+      }
+    }
+  }
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // x goes through a buffer descriptor that covers exactly this workgroup's rows: the range check returns 0 for
+  // rows past the end and for the run-ahead past the last k-step (no clamps, no exec-masked regions in the loop),
+  // and an address is  descriptor base + one 32-bit lane offset + a scalar row offset  (one VALU add per k-step).
+  const int64_t rows_here = (n_rows - r_beg) < (int64_t)ns * SB_SR ? (n_rows - r_beg) : (int64_t)ns * SB_SR;
+  const float* xw = x + (size_t)r_beg * D + d0;
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xw), 0, (int)((rows_here * D - d0) * 4), 0x00020000);
+  const unsigned voff0 = (unsigned)((8 * h * D + kt * 32 + l31) * 4);
+  const unsigned row_bytes = (unsigned)D * 4u;
+  float xq[RING][8];                                 // ring of k-step operands: slot = k-step & 7
+  auto loadx = [&](int kg, float* dst) {
+    const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, j * row_bytes, 0));
+  };
+  auto loadm = [&](int s, uint64_t* dst) {           // past the end: re-read the last stage (its x reads as 0)
+    const int sc = s < ns ? s : ns - 1;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) dst[t] = mb[t][(size_t)sc * ms[t]];
+  };
+  auto loadrs = [&](int s, float* dst) {             // lane = patient of the stage
+    int64_t lr = (int64_t)(s < ns ? s : ns - 1) * SB_SR + lane;
+    if (lr > rows_here - 1) lr = rows_here - 1;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dst[r] = (r < rp.n && rp.r[r].rowscale) ? rp.r[r].rowscale[r_beg + lr] : 1.f;
+  };
+  // operands of one k-step.  kq = k-step inside its 64-row stage (0..3): field kq of the mask word is
+  // (8 patient bits) << 4 = the byte offset of the LUT entry that expands them.
+  auto make_af = [&](const uint64_t* mw, int kq, bf16x8* af) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const unsigned w = (kq & 2) ? (unsigned)(mw[t] >> 32) : (unsigned)mw[t];
+      unsigned off = __builtin_amdgcn_ubfe(w, 16u * (kq & 1), 12u);
+      if (!live[t]) off = 0;
+      af[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
+    }
+  };
+  auto make_b = [&](const float* xs, int par, int k8, bf16x8 (*b)[3]) {      // k8 = k-step inside the 128-row pair
+    if (!RS) {
+      split8(xs, b[0][0], b[0][1], b[0][2]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const f32x4s s0 = *reinterpret_cast<const f32x4s*>(&rss[par][wid][r][k8 * 16 + 8 * h]);
+        const f32x4s s1 = *reinterpret_cast<const f32x4s*>(&rss[par][wid][r][k8 * 16 + 8 * h + 4]);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = xs[j] * s0[j]; v[4 + j] = xs[4 + j] * s1[j]; }
+        split8(v, b[r][0], b[r][1], b[r][2]);
+      }
+    }
+  };
+  uint64_t mc[NTW], mn[NTW];
+  float rsn[2][3];
+  loadm(0, mc);
+  if (RS) {
+    loadrs(0, rsn[0]); loadrs(1, rsn[1]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { rss[0][wid][r][lane] = rsn[0][r]; rss[0][wid][r][SB_SR + lane] = rsn[1][r]; }
+    loadrs(2, rsn[0]); loadrs(3, rsn[1]);
+  }
+  // drain before the ring is primed: the loop is then entered with exactly the loads its back edge carries, so
+  // the wait counts inside stay exact (otherwise every iteration starts by draining the whole ring)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+#pragma unroll
+  for (int q = 0; q < AHEAD; ++q) loadx(q, xq[q]);
+  bf16x8 afc[NTW], bc[NREL][3];
+  make_af(mc, 0, afc);
+  make_b(xq[0], 0, 0, bc);
+
+  const int n2 = (ns + 1) / 2;
+  for (int u = 0; u < n2; ++u) {
+    if (RS) {                                         // scales of the NEXT pair of stages -> the other LDS buffer
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {                   // private to this wave: no barrier
+        rss[(u + 1) & 1][wid][r][lane] = rsn[0][r]; rss[(u + 1) & 1][wid][r][SB_SR + lane] = rsn[1][r];
+      }
+      loadrs(2 * u + 4, rsn[0]); loadrs(2 * u + 5, rsn[1]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if ((ks & 3) == 0) loadm(2 * u + (ks >> 2) + 1, mn);             // words of the next stage
+      loadx(u * KS + ks + AHEAD, xq[(ks + AHEAD) & (RING - 1)]);       // into a slot consumed two k-steps ago
+      __builtin_amdgcn_sched_barrier(0);             // keep the run-ahead: the scheduler would sink these loads
+      bf16x8 afn[NTW], bn[NREL][3];
+      make_af((ks & 3) == 3 ? mn : mc, (ks + 1) & 3, afn);
+      make_b(xq[(ks + 1) & (RING - 1)], ks == KS - 1 ? (u + 1) & 1 : u & 1, (ks + 1) & (KS - 1), bn);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int r = RS ? (t < T1 ? 0 : (t < T2 ? 1 : 2)) : 0;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[r][0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[r][1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[r][2], acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) afc[t] = afn[t];
+#pragma unroll
+      for (int r = 0; r < NREL; ++r) { bc[r][0] = bn[r][0]; bc[r][1] = bn[r][1]; bc[r][2] = bn[r][2]; }
+      if ((ks & 3) == 3) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) mc[t] = mn[t];
+      }
+    }
+  }
+  float* dst = slab + (size_t)blockIdx.x * NTOT * D;
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    if (nt0 + t >= NT) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int v = (nt0 + t) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      dst[(size_t)v * D + d0 + kt * 32 + l31] = acc[t][i];
+    }
+  }
+}
+
+// tile -> relation layouts with a static instance of the rowscale kernel: {T1, T2} for NT tiles
+inline bool scatter_bits_rs_layout(const RelPack& rp, int nt, int* t1, int* t2) {
+  if (rp.n != 3) return false;
+  *t1 = rp.r[1].acc_off / 32; *t2 = rp.r[2].acc_off / 32;
+  return nt == 10 && *t1 == 2 && *t2 == 6;         // 50 / 114 / 100 items (the eICU vocabulary)
+}
+
+template <int NT>
+void launch_scatter_bits(const ScatterPlan& p, const RelPack& rp, int64_t n_rows, int D, const float* x, float* slab,
+                         hipStream_t st) {
+  dim3 grid((unsigned)p.n_split, (unsigned)p.n_dchunks);
+  bool has_rs = false;
+  for (int r = 0; r < rp.n; ++r) has_rs |= rp.r[r].rowscale != nullptr;
+  const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
+  if (has_rs) {                                      // plan_scatter only picks this kernel for a static layout
+    if (NT == 10) hipLaunchKernelGGL((k_scatter_bits<10, 4, 1, 2, 6>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
+  } else if (p.dc == 128) {
+    hipLaunchKernelGGL((k_scatter_bits<NT, 4, 0, 0, 0>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
+  } else {
+    hipLaunchKernelGGL((k_scatter_bits<NT, 2, 0, 0, 0>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
+  }
+}
+
+// bit planes of a CSR-by-row relation.  Word [row / 64][col][half] (half = bit 3 of the row inside its 64-row
+// stage) carries four 16-bit fields, one per k-step of 16 rows: field ks = (8 patient bits of rows
+// 16 ks + 8 half + 0..7) << 4, i.e. the byte offset of the LUT entry that expands them.
+__global__ __launch_bounds__(256) void k_mask_build(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                    int64_t n_rows, int padc, unsigned long long* __restrict__ mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (row >= n_rows) return;
+  const int b = rowptr[row], e = rowptr[row + 1];
+  const int p = (int)(row & 63);
+  unsigned long long* mrow = mask + ((size_t)(row >> 6) * padc) * 2 + ((p >> 3) & 1);
+  const unsigned long long bit = 1ull << (16 * (p >> 4) + 4 + (p & 7));
+  for (int k = b + lane; k < e; k += 64) atomicOr(mrow + (size_t)col[k] * 2, bit);
+}
+
 // epilogue of the slab sum: padded accumulator row -> (relation, vocab row), times colscale
 struct EpiScatter {
   RelPack rp; int D;
@@ -605,7 +866,7 @@ int pack(const mmg_rel_t* rels, int n_rel, RelPack* rp, bool need_table, bool ne
     MMG_CHECK_ARG(!need_table || rels[r].table, "aggregate: relation %d has null table", r);
     MMG_CHECK_ARG(!need_out || rels[r].out, "aggregate: relation %d has null out", r);
     rp->r[r] = RelDev{rels[r].rowptr, rels[r].col, rels[r].rowscale, rels[r].colscale, rels[r].table,
-                      rels[r].out, rels[r].n_cols, off, rels[r].flags};
+                      rels[r].out, rels[r].n_cols, off, rels[r].flags, rels[r].mask_t};
     off += pad_cols ? ((rels[r].n_cols + 31) & ~31) : rels[r].n_cols;
   }
   return MMG_OK;
@@ -718,6 +979,15 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     return MMG_E_WS;
   }
   float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  if (p.bf16) {
+    switch (p.nt) {
+      case 2: launch_scatter_bits<2>(p, rp, n_rows, D, x, slab, st); break;
+      case 4: launch_scatter_bits<4>(p, rp, n_rows, D, x, slab, st); break;
+      case 6: launch_scatter_bits<6>(p, rp, n_rows, D, x, slab, st); break;
+      case 8: launch_scatter_bits<8>(p, rp, n_rows, D, x, slab, st); break;
+      default: launch_scatter_bits<10>(p, rp, n_rows, D, x, slab, st); break;
+    }
+  } else
   switch (p.nt) {
     case 2: launch_scatter_mfma<2>(p, rp, n_rows, D, x, slab, st); break;
     case 4: launch_scatter_mfma<4>(p, rp, n_rows, D, x, slab, st); break;
@@ -731,5 +1001,27 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
   hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiScatter>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4,
                      p.n_split, EpiScatter{rp, D});
   MMG_CHECK_LAUNCH("scatter_rows");
+  return MMG_OK;
+}
+
+extern "C" size_t mmg_rel_mask_words(int64_t n_rows, int32_t n_cols) {
+  if (n_rows <= 0 || n_cols <= 0) return 0;
+  return (size_t)((n_rows + 63) / 64) * (size_t)((n_cols + 31) & ~31) * 2;
+}
+
+extern "C" int mmg_rel_mask_build(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t n_cols,
+                                  uint64_t* mask_t, void* stream) {
+  MMG_CHECK_ARG(n_rows >= 0 && n_rows < 2147483647LL / 64 && n_cols >= 0, "rel_mask_build: size out of range");
+  const size_t words = mmg_rel_mask_words(n_rows, n_cols);
+  if (words == 0) return MMG_OK;
+  MMG_CHECK_ARG(rowptr && mask_t, "rel_mask_build: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(mask_t, 0, words * sizeof(uint64_t), st) != hipSuccess) {
+    mmg_set_error("rel_mask_build: memset failed");
+    return MMG_E_LAUNCH;
+  }
+  hipLaunchKernelGGL(k_mask_build, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rowptr, col, n_rows,
+                     (n_cols + 31) & ~31, reinterpret_cast<unsigned long long*>(mask_t));
+  MMG_CHECK_LAUNCH("rel_mask_build");
   return MMG_OK;
 }

@@ -496,7 +496,7 @@ class _Run:
             for r in rout:
                 agg = buf[off:off + r.n_cols]
                 off += r.n_cols
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg, simple=r.simple))
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg, simple=r.simple, mask_t=r.mask_t))
                 aggs.append(agg)
             ops.scatter_rows(rels, P, D, xP)
             self.allreduce(buf)                          # partial sums over patient shards
@@ -555,7 +555,7 @@ class _Run:
             for r in rec["rin"]:
                 dT = buf[off:off + r.n_cols]
                 off += r.n_cols
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=dT, simple=r.simple))
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=dT, simple=r.simple, mask_t=r.mask_t))
                 dTs.append(dT)
             ops.scatter_rows(rels, P, D, dyP)
             self.allreduce(buf)

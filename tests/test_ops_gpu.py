@@ -170,7 +170,14 @@ def test_aggregates_simple_graph_paths(ops, dev, D, n_rows):
         grels.append(ops.Rel(rp, col, nc, rowscale=inv, colscale=cinv, table=tab.to(dev), simple=True))
         gref += scatter_mean((tab.double() * cinv.cpu().double()[:, None]), ei.flip(0), n_rows)
         out = torch.full((nc, D), -3.0, device=dev)
-        srels.append(ops.Rel(rp, col, nc, colscale=cinv, out=out, simple=True))
+        mask = ops.rel_mask_build(rp, col, nc)
+        padc = (nc + 31) // 32 * 32
+        want = torch.zeros((n_rows + 63) // 64, padc, 2, dtype=torch.int64)      # bit planes, bit-exact
+        p64 = ei[0] % 64
+        want.view(-1).index_add_(0, ((ei[0] // 64) * padc + ei[1]) * 2 + ((p64 // 8) & 1),
+                                 torch.ones(ei.shape[1], dtype=torch.int64) << (16 * (p64 // 16) + 4 + p64 % 8))
+        assert torch.equal(mask.cpu().view(-1, padc, 2), want)
+        srels.append(ops.Rel(rp, col, nc, colscale=cinv, out=out, simple=True, mask_t=mask))
         srefs.append(scatter_mean(x.double(), ei, nc))
     base = torch.randn(n_rows, D, generator=gen)
     o = base.to(dev).clone()
