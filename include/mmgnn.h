@@ -80,15 +80,19 @@ typedef struct {
                               [row / 64][col][(row % 64 / 8) & 1] has bit 16 * (row % 64 / 16) + 4 + row % 8 set
                               iff (row, col) is an edge (four 16-bit fields, one per 16 rows, each holding 8 row
                               bits << 4); [ceil(n_rows / 64)][pad32(n_cols)][2] words.  Simple relations only. */
+  const uint16_t* mask_r;  /* NULL, or the same adjacency row-major for the gather: field
+                              [row][(col % 16 / 8) & 1][col / 16] = (8 item bits of cols 16 (col/16) + 8 half + 0..7)
+                              << 4; [n_rows][2][pad32(n_cols) / 16] uint16. */
 } mmg_rel_t;
 #define MMG_REL_SIMPLE 1u
 
 /* One-off per static graph: the bit-plane form of a CSR-by-row relation (40 B per patient at the eICU vocab
  * instead of 4 B per edge).  The scatter kernels expand indicator fragments for the matrix cores straight from
- * these words.  mask_t must hold mmg_rel_mask_words(n_rows, n_cols) uint64; it is zeroed here. */
+ * these words.  mask_t and mask_r must each hold mmg_rel_mask_words(n_rows, n_cols) uint64 (8-byte units for both);
+ * they are zeroed here.  Either may be NULL (not built). */
 size_t mmg_rel_mask_words(int64_t n_rows, int32_t n_cols);
 int mmg_rel_mask_build(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t n_cols,
-                       uint64_t* mask_t, void* stream);
+                       uint64_t* mask_t, uint16_t* mask_r, void* stream);
 
 int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
                     float* out, int accumulate, void* stream);

@@ -21,7 +21,8 @@ class MmgError(RuntimeError):
 class RelT(C.Structure):
     _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("rowscale", C.c_void_p),
                 ("colscale", C.c_void_p), ("table", C.c_void_p), ("out", C.c_void_p),
-                ("n_cols", C.c_int32), ("flags", C.c_uint32), ("mask_t", C.c_void_p)]
+                ("n_cols", C.c_int32), ("flags", C.c_uint32), ("mask_t", C.c_void_p),
+                ("mask_r", C.c_void_p)]
 
 
 class PrologueT(C.Structure):
@@ -52,7 +53,7 @@ SIGNATURES = {
     "mmg_row_degree": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "mmg_col_degree": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "mmg_rel_mask_words": (_sz, [_i64, C.c_int32]),
-    "mmg_rel_mask_build": (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp, _vp]),
+    "mmg_rel_mask_build": (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp, _vp, _vp]),
     "mmg_gather_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _i32, _vp]),
     "mmg_scatter_rows_ws_bytes": (_sz, [_P(RelT), _i32, _i64, _i32]),
     "mmg_scatter_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _vp, _sz, _vp]),

@@ -19,6 +19,7 @@ struct RelDev {
   const float* table; float* out; int32_t n_cols; int32_t acc_off;   // acc_off: first accumulator row
   uint32_t flags;
   const uint64_t* mask;      // bit planes (simple relations) or null
+  const uint16_t* mask_r;    // row-major fields (gather side) or null
 };
 struct RelPack { RelDev r[MMG_MAX_REL]; int n; };
 
@@ -403,6 +404,7 @@ void launch_gather_bf16(const RelPack& rb, int64_t n_rows, int D, float* out, in
   if (D == 64) hipLaunchKernelGGL((k_gather_bf16<NKS, 2>), dim3((unsigned)nblk), dim3(128), 0, st, rb, n_rows, rows_per_blk, D, out, accumulate, dbg);
   else hipLaunchKernelGGL((k_gather_bf16<NKS, 4>), dim3((unsigned)nblk, (unsigned)(D / 128)), dim3(256), 0, st, rb, n_rows, rows_per_blk, D, out, accumulate, dbg);
 }
+
 
 // ------------------------------------------------------------------------------ scatter
 // out[v, :] = sum_rows Ind[row, v] * x[row, :]  is a tall-skinny product  Ind^T [V x P] . x [P x D].
@@ -801,6 +803,188 @@ __global__ __launch_bounds__(256) void k_mask_build(const int32_t* __restrict__ 
   for (int k = b + lane; k < e; k += 64) atomicOr(mrow + (size_t)col[k] * 2, bit);
 }
 
+// ------------------------------------------------------------------------------ gather on the bf16 matrix cores
+// out[i, :] (+)= sum_r rs_r[i] * sum_v Ind_r[i, v] * (cs_r[v] T_r[v, :])  as  Ind [32 patients x items] . T' pieces.
+// Mirror image of k_scatter_bits: the 0/1 indicator fragment of a k-step (16 items) is one 12-bit field of the
+// patient's row-major bit planes expanded through the 256-entry LDS table, and the (tiny) item tables are split
+// ONCE per workgroup into three exact bf16 pieces that stay in registers for every patient tile.  Eight waves:
+// wave (ft, kh) owns feature tile ft and HALF of the k-steps (10 x 3 pieces x 4 VGPRs per lane, so two waves per
+// SIMD fit); each relation accumulates separately so that its mean scale applies exactly; the kh = 1 waves hand
+// their scaled partial sums to their kh = 0 partner through a double-buffered LDS tile (one barrier per patient
+// tile), which adds, accumulates and stores.  The loop body is LUT reads + MFMAs; the masks / scales / previous
+// output of the next tile are prefetched, and out goes through a buffer descriptor (no exec-masked tails).
+// Relation r owns the k-steps [K(r), K(r+1)), K = {0, K1, K2, NK} at compile time.
+template <int NK, int K1, int K2, bool ACCUM, int KH>
+__device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_rows, int n_tile_total, int D,
+                                                 float* __restrict__ out, const unsigned (*lut)[4],
+                                                 float (*rss)[3][32], float (*xch)[4][16][64]) {
+  constexpr int KB = KH * (NK / 2), KE = KB + NK / 2;               // this wave's k-steps
+  constexpr bool USE0 = KB < K1, USE1 = KB < K2 && KE > K1, USE2 = KE > K2;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31, ft = wid & 3;
+  const int dcol = blockIdx.y * 128 + ft * 32 + l31;
+  // ---- table pieces: B[k = item 16 ks + 8 h + j][n = this lane's feature column]
+  bf16x8 tb[NK / 2][3];
+#pragma unroll
+  for (int q = 0; q < NK / 2; ++q) {
+    const int ks = KB + q;
+    const int r = ks < K1 ? 0 : (ks < K2 ? 1 : 2);
+    const int kr = ks - (r == 0 ? 0 : (r == 1 ? K1 : K2));
+    const RelDev& R = rp.r[r];
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int item = kr * 16 + 8 * h + j;
+      float t = 0.f;
+      if (item < R.n_cols) {
+        t = R.table[(size_t)item * D + dcol];
+        if (R.colscale) t *= R.colscale[item];
+      }
+      v[j] = t;
+    }
+    split8(v, tb[q][0], tb[q][1], tb[q][2]);
+  }
+  constexpr int NF0 = K1, NF1 = K2 - K1, NF2 = NK - K2;             // 16-bit fields per (row, half)
+  static_assert(NF0 % 2 == 0 && NF1 % 2 == 0 && NF2 % 2 == 0 && K1 % 2 == 0 && K2 % 2 == 0 && NK % 4 == 0,
+                "fields are loaded as dwords");
+  const int t_beg = (int)((int64_t)blockIdx.x * n_tile_total / gridDim.x);
+  const int t_end = (int)((int64_t)(blockIdx.x + 1) * n_tile_total / gridDim.x);
+  const int64_t last_row = n_rows - 1;
+  const int64_t wg_row0 = (int64_t)t_beg * 32;
+  const int64_t wg_rows = ((int64_t)t_end * 32 < n_rows ? (int64_t)t_end * 32 : n_rows) - wg_row0;
+  const __amdgpu_buffer_rsrc_t osrc =
+      __builtin_amdgcn_make_buffer_rsrc(out + (size_t)wg_row0 * D, 0, (int)(wg_rows * D * 4), 0x00020000);
+  const unsigned row_bytes = (unsigned)D * 4u;
+  unsigned mcur[NK / 4], mnxt[NK / 4];                              // fields KB..KE-1 as dwords
+  float rsn[3], prev[16];
+  auto loadm = [&](int tile, unsigned* dst) {                       // this lane's patient and item half
+    int64_t row = (int64_t)tile * 32 + l31;
+    if (row > last_row) row = last_row;
+#pragma unroll
+    for (int i = 0; i < NK / 4; ++i) {
+      const int ks = KB + 2 * i;                                    // static: relation and offset inside it
+      const int r = ks < K1 ? 0 : (ks < K2 ? 1 : 2);
+      const int kr = ks - (r == 0 ? 0 : (r == 1 ? K1 : K2));
+      const int nf = r == 0 ? NF0 : (r == 1 ? NF1 : NF2);
+      dst[i] = reinterpret_cast<const unsigned*>(rp.r[r].mask_r)[((size_t)row * 2 + h) * (nf / 2) + kr / 2];
+    }
+  };
+  auto loadrs = [&](int tile, float* dst) {
+    int64_t row = (int64_t)tile * 32 + l31;
+    if (row > last_row) row = last_row;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) dst[r] = (r < rp.n && rp.r[r].rowscale) ? rp.r[r].rowscale[row] : 1.f;
+  };
+  auto loadprev = [&](int tile, float* dst) {
+    const unsigned vo = (unsigned)(((tile - t_beg) * 32 + 4 * h) * D + dcol) * 4u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0));
+  };
+  if (t_beg < t_end) {
+    loadm(t_beg, mcur); loadrs(t_beg, rsn);
+    if (ACCUM && KH == 0) loadprev(t_beg, prev);
+  }
+
+  for (int tile = t_beg; tile < t_end; ++tile) {
+    const int tn = tile + 1 < t_end ? tile + 1 : tile;
+    loadm(tn, mnxt);
+    if (h == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) rss[wid][r][l31] = rsn[r];        // private to this wave
+    }
+    loadrs(tn, rsn);
+    float pc[16];
+    if (ACCUM && KH == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pc[i] = prev[i];
+      loadprev(tn, prev);                                           // consumed one tile later
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NK / 2; ++q) {
+      const int ks = KB + q;
+      const int r = ks < K1 ? 0 : (ks < K2 ? 1 : 2);
+      const unsigned off = __builtin_amdgcn_ubfe(mcur[q >> 1], 16u * (q & 1), 12u);
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
+      acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][0], acc[r], 0, 0, 0);
+      acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][1], acc[r], 0, 0, 0);
+      acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][2], acc[r], 0, 0, 0);
+    }
+    // scaled partial in the C layout: register i <-> patient row (i & 3) + 8 (i >> 2) + 4 h, lane <-> feature column
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4s s0, s1, s2;
+      if (USE0) s0 = *reinterpret_cast<const f32x4s*>(&rss[wid][0][8 * q + 4 * h]);
+      if (USE1) s1 = *reinterpret_cast<const f32x4s*>(&rss[wid][1][8 * q + 4 * h]);
+      if (USE2) s2 = *reinterpret_cast<const f32x4s*>(&rss[wid][2][8 * q + 4 * h]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * q + e;
+        float t = 0.f;
+        if (USE0) t = s0[e] * acc[0][i];
+        if (USE1) t = fmaf(s1[e], acc[1][i], t);
+        if (USE2) t = fmaf(s2[e], acc[2][i], t);
+        v[i] = t;
+      }
+    }
+    float (*xb)[64] = xch[tile & 1][ft];
+    if (KH == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xb[i][lane] = v[i];
+    }
+    __syncthreads();
+    if (KH == 0) {
+      const unsigned vo = (unsigned)(((tile - t_beg) * 32 + 4 * h) * D + dcol) * 4u;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float t = v[i] + xb[i][lane];
+        if (ACCUM) t += pc[i];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NK / 4; ++i) mcur[i] = mnxt[i];
+  }
+}
+
+template <int NK, int K1, int K2, bool ACCUM>
+__global__ __launch_bounds__(512) void k_gather_bits(RelPack rp, int64_t n_rows, int n_tile_total, int D,
+                                                     float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned lut[256][4];
+  __shared__ __attribute__((aligned(16))) float rss[8][3][32];
+  __shared__ __attribute__((aligned(16))) float xch[2][4][16][64];
+  const int tid = threadIdx.x;
+  if (tid < 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
+  }
+  __syncthreads();
+  if ((tid >> 8) == 0) gather_bits_body<NK, K1, K2, ACCUM, 0>(rp, n_rows, n_tile_total, D, out, lut, rss, xch);
+  else gather_bits_body<NK, K1, K2, ACCUM, 1>(rp, n_rows, n_tile_total, D, out, lut, rss, xch);
+}
+
+// row-major bit planes: field [row][half][col / 16] (uint16) |= 1 << (4 + col % 8), half = (col % 16) / 8
+__global__ __launch_bounds__(256) void k_mask_build_rows(const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col, int64_t n_rows, int nf,
+                                                         unsigned* __restrict__ mask) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (row >= n_rows) return;
+  const int b = rowptr[row], e = rowptr[row + 1];
+  for (int k = b + lane; k < e; k += 64) {
+    const int c = col[k];
+    const size_t f = ((size_t)row * 2 + ((c >> 3) & 1)) * nf + (c >> 4);       // uint16 index
+    atomicOr(mask + (f >> 1), 1u << (4 + (c & 7) + 16 * (int)(f & 1)));
+  }
+}
+
 // epilogue of the slab sum: padded accumulator row -> (relation, vocab row), times colscale
 struct EpiScatter {
   RelPack rp; int D;
@@ -866,7 +1050,7 @@ int pack(const mmg_rel_t* rels, int n_rel, RelPack* rp, bool need_table, bool ne
     MMG_CHECK_ARG(!need_table || rels[r].table, "aggregate: relation %d has null table", r);
     MMG_CHECK_ARG(!need_out || rels[r].out, "aggregate: relation %d has null out", r);
     rp->r[r] = RelDev{rels[r].rowptr, rels[r].col, rels[r].rowscale, rels[r].colscale, rels[r].table,
-                      rels[r].out, rels[r].n_cols, off, rels[r].flags, rels[r].mask_t};
+                      rels[r].out, rels[r].n_cols, off, rels[r].flags, rels[r].mask_t, rels[r].mask_r};
     off += pad_cols ? ((rels[r].n_cols + 31) & ~31) : rels[r].n_cols;
   }
   return MMG_OK;
@@ -904,6 +1088,37 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
       if (vp <= 12 * 16) launch_gather_bf16<12>(rb, n_rows, D, out, accumulate, st);
       else launch_gather_bf16<20>(rb, n_rows, D, out, accumulate, st);
       MMG_CHECK_LAUNCH("gather_rows(bf16)");
+      return MMG_OK;
+    }
+  }
+  // bit-plane matrix-core kernel: simple relations in a layout with a static instance -- the eICU vocabulary
+  // (64 | 128 | 128 padded items) or its first relation alone (the last layer's backward only reaches the labs)
+  {
+    static const int no_bits = [] { const char* e = getenv("MMG_GATHER_LDS"); return e ? atoi(e) : 0; }();
+    bool okb = !no_bits && (n_rel == 3 || n_rel == 1) && D >= 128 && n_rows >= 32;
+    for (int r = 0; r < n_rel && okb; ++r) okb = (rels[r].flags & MMG_REL_SIMPLE) != 0 && rels[r].mask_r != nullptr;
+    okb = okb && ((rels[0].n_cols + 31) & ~31) == 64;
+    if (n_rel == 3) okb = okb && ((rels[1].n_cols + 31) & ~31) == 128 && ((rels[2].n_cols + 31) & ~31) == 128;
+    if (okb && n_rel == 1) {
+      const int n_tiles = (int)((n_rows + 31) / 32);
+      const int n_dchunks = D / 128;
+      int g = 256 / n_dchunks;
+      if (g > n_tiles) g = n_tiles;
+      dim3 grid((unsigned)g, (unsigned)n_dchunks);
+      if (accumulate) hipLaunchKernelGGL((k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out);
+      else hipLaunchKernelGGL((k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out);
+      MMG_CHECK_LAUNCH("gather_rows(bits)");
+      return MMG_OK;
+    }
+    if (okb) {
+      const int n_tiles = (int)((n_rows + 31) / 32);
+      const int n_dchunks = D / 128;
+      int g = 256 / n_dchunks;
+      if (g > n_tiles) g = n_tiles;
+      dim3 grid((unsigned)g, (unsigned)n_dchunks);
+      if (accumulate) hipLaunchKernelGGL((k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out);
+      else hipLaunchKernelGGL((k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out);
+      MMG_CHECK_LAUNCH("gather_rows(bits)");
       return MMG_OK;
     }
   }
@@ -1010,18 +1225,29 @@ extern "C" size_t mmg_rel_mask_words(int64_t n_rows, int32_t n_cols) {
 }
 
 extern "C" int mmg_rel_mask_build(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t n_cols,
-                                  uint64_t* mask_t, void* stream) {
+                                  uint64_t* mask_t, uint16_t* mask_r, void* stream) {
   MMG_CHECK_ARG(n_rows >= 0 && n_rows < 2147483647LL / 64 && n_cols >= 0, "rel_mask_build: size out of range");
   const size_t words = mmg_rel_mask_words(n_rows, n_cols);
   if (words == 0) return MMG_OK;
-  MMG_CHECK_ARG(rowptr && mask_t, "rel_mask_build: null buffer");
+  MMG_CHECK_ARG(rowptr && (mask_t || mask_r), "rel_mask_build: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(mask_t, 0, words * sizeof(uint64_t), st) != hipSuccess) {
-    mmg_set_error("rel_mask_build: memset failed");
-    return MMG_E_LAUNCH;
+  const int padc = (n_cols + 31) & ~31;
+  if (mask_t) {
+    if (hipMemsetAsync(mask_t, 0, words * sizeof(uint64_t), st) != hipSuccess) {
+      mmg_set_error("rel_mask_build: memset failed");
+      return MMG_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_mask_build, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rowptr, col, n_rows, padc,
+                       reinterpret_cast<unsigned long long*>(mask_t));
   }
-  hipLaunchKernelGGL(k_mask_build, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rowptr, col, n_rows,
-                     (n_cols + 31) & ~31, reinterpret_cast<unsigned long long*>(mask_t));
+  if (mask_r) {
+    if (hipMemsetAsync(mask_r, 0, words * sizeof(uint64_t), st) != hipSuccess) {
+      mmg_set_error("rel_mask_build: memset failed");
+      return MMG_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_mask_build_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rowptr, col, n_rows,
+                       padc / 16, reinterpret_cast<unsigned*>(mask_r));
+  }
   MMG_CHECK_LAUNCH("rel_mask_build");
   return MMG_OK;
 }

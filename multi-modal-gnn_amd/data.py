@@ -117,7 +117,8 @@ class RelCSR:
     col_cnt: torch.Tensor           # int32 [n_cols] LOCAL in-degree (summed across shards for inv_col)
     n_edges: int = 0
     simple: bool = False            # no (patient, item) pair occurs twice (true for the reference's frames)
-    mask_t: Optional[torch.Tensor] = None    # bit planes [ceil(P/64)][pad32(n_cols)] of a simple relation
+    mask_t: Optional[torch.Tensor] = None    # bit planes [ceil(P/64)][pad32(n_cols)][2] of a simple relation
+    mask_r: Optional[torch.Tensor] = None    # the same row-major: uint16 fields [P][2][pad32(n_cols)/16]
 
 
 @dataclass
@@ -199,7 +200,7 @@ def build_plan(data, device=None, validate: bool = True, use_cache: bool = True)
             t_ei, t_rel = twin
             if t_ei.shape == ei.shape and torch.equal(t_ei.flip(0), ei):
                 rel = RelCSR(et, other, patient_is_dst, t_rel.n_cols, t_rel.rowptr, t_rel.col, t_rel.perm,
-                             t_rel.inv_row, t_rel.inv_col, t_rel.col_cnt, E, t_rel.simple, t_rel.mask_t)
+                             t_rel.inv_row, t_rel.inv_col, t_rel.col_cnt, E, t_rel.simple, t_rel.mask_t, t_rel.mask_r)
         if rel is None:
             rowptr, col, perm = ops.csr_build(ei, P, sort_row)
             _, inv_row = ops.row_degree(rowptr)
@@ -207,9 +208,9 @@ def build_plan(data, device=None, validate: bool = True, use_cache: bool = True)
             prow = ei[1] if patient_is_dst else ei[0]
             ocol = ei[0] if patient_is_dst else ei[1]
             simple = E == 0 or int(torch.unique(prow * num_nodes[other] + ocol).numel()) == E     # one-off check
-            mask_t = ops.rel_mask_build(rowptr, col, num_nodes[other]) if simple and P > 0 else None
+            mask_t, mask_r = ops.rel_mask_build(rowptr, col, num_nodes[other]) if simple and P > 0 else (None, None)
             rel = RelCSR(et, other, patient_is_dst, num_nodes[other], rowptr, col, perm, inv_row, inv_col, cnt, E,
-                         simple, mask_t)
+                         simple, mask_t, mask_r)
             shared[(other, "src" if not patient_is_dst else "dst")] = (ei, rel)
         plan.rels[et] = rel
     if LAB_EDGE in plan.rels:

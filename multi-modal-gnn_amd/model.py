@@ -485,7 +485,7 @@ class _Run:
             rels = []
             for r, nme in zip(rin, names):
                 Tv = ops.linear_fwd(x[r.other], self.W(nme + ".lin_l.weight"))
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv, simple=r.simple))
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv, simple=r.simple, mask_r=r.mask_r))
             ops.gather_rows(rels, P, D, yP, accumulate=True)
             y[ROW_TYPE] = yP
             rec["Wsum"] = Wsum
@@ -578,7 +578,7 @@ class _Run:
                 self.acc(nme + ".lin_r.weight", ops.linear_wgrad(dyv, x[r.other]))
                 add(r.other, ops.linear_fwd(dyv, self.W(nme + ".lin_r.weight").t().contiguous()))
                 dagg = ops.linear_fwd(dyv, self.W(nme + ".lin_l.weight").t().contiguous())
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=dagg, simple=r.simple))
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=dagg, simple=r.simple, mask_r=r.mask_r))
             if rels:
                 if g_in[ROW_TYPE] is None:
                     g_in[ROW_TYPE] = torch.empty(P, D, device=self.dev)

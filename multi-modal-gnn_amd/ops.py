@@ -168,6 +168,7 @@ class Rel:
     out: Optional[torch.Tensor] = None
     simple: bool = False          # no duplicate (row, col) pair (MMG_REL_SIMPLE)
     mask_t: Optional[torch.Tensor] = None     # bit planes of the adjacency (rel_mask_build), simple relations only
+    mask_r: Optional[torch.Tensor] = None     # the same, row-major (gather side)
 
 
 def _agg_bytes(rels, n_rows, D, accumulate):
@@ -194,19 +195,23 @@ def _rels(rels: Sequence[Rel], D: int, need_table=False, need_out=False):
             raise ValueError(f"relation {i}: out must be [{r.n_cols},{D}]")
         arr[i] = RelT(_p(r.rowptr, torch.int32), _p(r.col, torch.int32), _p(r.rowscale), _p(r.colscale),
                       _p(r.table), _p(r.out), r.n_cols, 1 if r.simple else 0,
-                      _p(r.mask_t, torch.int64) if r.simple else None)
+                      _p(r.mask_t, torch.int64) if r.simple else None,
+                      _p(r.mask_r, torch.int64) if r.simple else None)
     return arr
 
 
-def rel_mask_build(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int) -> torch.Tensor:
-    """Bit planes of a SIMPLE CSR relation: int64 [ceil(n_rows/64) * pad32(n_cols)] (mmg_rel_mask_build)."""
+def rel_mask_build(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int):
+    """Bit planes of a SIMPLE CSR relation (mmg_rel_mask_build) -> (mask_t, mask_r), int64 storage each:
+    mask_t [ceil(n_rows/64)][pad32(n_cols)][2] words (scatter side), mask_r [n_rows][2][pad32(n_cols)/16] uint16
+    fields (gather side)."""
     lib = _lib.load()
     n_rows = rowptr.numel() - 1
     words = lib.mmg_rel_mask_words(n_rows, n_cols)
-    mask = torch.empty(max(words, 1), dtype=torch.int64, device=rowptr.device)
-    check(lib.mmg_rel_mask_build(_p(rowptr, torch.int32), _p(col, torch.int32), n_rows, n_cols, _p(mask, torch.int64),
-                                 _stream()), "mmg_rel_mask_build")
-    return mask
+    mask_t = torch.empty(max(words, 1), dtype=torch.int64, device=rowptr.device)
+    mask_r = torch.empty(max(words, 1), dtype=torch.int64, device=rowptr.device)
+    check(lib.mmg_rel_mask_build(_p(rowptr, torch.int32), _p(col, torch.int32), n_rows, n_cols, _p(mask_t, torch.int64),
+                                 _p(mask_r, torch.int64), _stream()), "mmg_rel_mask_build")
+    return mask_t, mask_r
 
 
 def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, accumulate: bool):

@@ -169,9 +169,18 @@ def test_aggregates_simple_graph_paths(ops, dev, D, n_rows):
         cnt, cinv = ops.col_degree(col, nc)
         grels.append(ops.Rel(rp, col, nc, rowscale=inv, colscale=cinv, table=tab.to(dev), simple=True))
         gref += scatter_mean((tab.double() * cinv.cpu().double()[:, None]), ei.flip(0), n_rows)
+        if len(grels) == 1:
+            gref0 = gref.clone()
         out = torch.full((nc, D), -3.0, device=dev)
-        mask = ops.rel_mask_build(rp, col, nc)
+        mask, mask_r = ops.rel_mask_build(rp, col, nc)
         padc = (nc + 31) // 32 * 32
+        nf = padc // 16
+        want_r = torch.zeros(n_rows * 2 * nf, dtype=torch.int64)                 # row-major fields, bit-exact
+        want_r.index_add_(0, (ei[0] * 2 + ((ei[1] % 16) // 8)) * nf + ei[1] // 16,
+                          torch.ones(ei.shape[1], dtype=torch.int64) << (4 + ei[1] % 8))
+        got_r = mask_r.cpu().view(torch.int16).to(torch.int64)[:n_rows * 2 * nf] & 0xFFFF
+        assert torch.equal(got_r, want_r)
+        grels[-1].mask_r = mask_r
         want = torch.zeros((n_rows + 63) // 64, padc, 2, dtype=torch.int64)      # bit planes, bit-exact
         p64 = ei[0] % 64
         want.view(-1).index_add_(0, ((ei[0] // 64) * padc + ei[1]) * 2 + ((p64 // 8) & 1),
@@ -186,6 +195,9 @@ def test_aggregates_simple_graph_paths(ops, dev, D, n_rows):
     o2 = torch.empty(n_rows, D, device=dev)
     ops.gather_rows(grels, n_rows, D, o2, accumulate=False)
     assert rel(o2, gref) <= 1e-6
+    o3 = torch.empty(n_rows, D, device=dev)                 # first relation alone (last layer's backward)
+    ops.gather_rows(grels[:1], n_rows, D, o3, accumulate=False)
+    assert rel(o3, gref0) <= 1e-6
     ops.scatter_rows(srels, n_rows, D, x.to(dev))
     for r, ref in zip(srels, srefs):
         assert rel(r.out, ref) <= 1e-6
