@@ -110,8 +110,9 @@ def build_workload(args, world, rank, dev):
     y = g[LAB].edge_attr[tr].squeeze(-1).contiguous()
     sup = torch.rand(tr.numel(), generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev) < 0.2
     wlab = torch.ones(int(g["lab"].num_nodes), device=dev)
+    # F5: embeddings are not in the optimizer.  fused = one multi-tensor kernel for all ~60 parameter tensors
     opt = torch.optim.Adam([p for n, p in model.named_parameters() if not n.startswith("embeddings.")],
-                           lr=1e-3, weight_decay=1e-5, capturable=True)   # F5: embeddings are not in the optimizer
+                           lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
     n_sup_global = torch.tensor([float(sup.sum())], device=dev)
     if comm is not None:
         torch.distributed.all_reduce(n_sup_global)

@@ -114,7 +114,9 @@ class Trainer:
     def _build_optimizer(self, oc: Dict) -> optim.Optimizer:
         kind = oc.get("type", "adam").lower()
         if kind == "adam":
-            return optim.Adam(self.model.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"])
+            params = list(self.model.parameters())
+            fused = bool(params) and all(p.is_cuda for p in params)        # one multi-tensor kernel per step
+            return optim.Adam(params, lr=oc["lr"], weight_decay=oc["weight_decay"], fused=fused)
         if kind == "sgd":
             return optim.SGD(self.model.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"],
                              momentum=oc.get("momentum", 0.9))
