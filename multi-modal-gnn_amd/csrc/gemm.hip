@@ -131,6 +131,158 @@ __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------- fp32 GEMM on the bf16 matrix cores
+// An fp32 value is EXACTLY hi + mid + lo with three bf16 pieces (8 significant bits each), so
+//     x . w = x1 w1 + (x1 w2 + x2 w1) + (x2 w2 + x1 w3 + x3 w1) + O(2^-24 |x||w|)
+// Six v_mfma_f32_32x32x16_bf16 products (each exact, accumulated in fp32) reproduce the fp32 product to within
+// its own rounding error at 6/16 of the fp32 matrix time: the dropped terms x2 w3 + x3 w2 + x3 w3 are below
+// 3 * 2^-25 |x||w| -- less than the rounding of the fp32 FMA chain they replace.
+// Layout: the three W pieces stay in registers for the whole kernel (lane (n = l&31, h = l>>5) holds
+// W[n][16 ks + 8 h + 0..7]); every 64-row X tile is prologue'd AND split once while it is staged to LDS (three
+// bf16 planes, double-buffered: tile t+1 is staged while tile t is multiplied, one barrier per tile), and an A
+// fragment is one conflict-free ds_read_b128 per piece.
+typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xbf16x4 __attribute__((ext_vector_type(4)));
+
+template <int K, int WN>          // WN waves along N (32 columns each), 2 along M: 128 * WN threads
+__global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restrict__ X, ProDev pr,
+                                                            const float* __restrict__ W, const float* __restrict__ bias,
+                                                            float* __restrict__ Y, int64_t M, int N, int accumulate) {
+  pr.resolve();
+  constexpr int LDP = K + 8;            // plane row stride in bf16 (K*2 + 16 bytes: fragment reads hit 64 distinct banks)
+  constexpr int BN = 32 * WN, NK = K / 16, NTHR = 128 * WN;
+  extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int col = blockIdx.x * BN + wn * 32 + l31;
+
+  xbf16x8 wb[NK][3];
+  {
+    const float* wp = W + (size_t)col * K + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + ks * 16), w1 = *reinterpret_cast<const f32x4*>(wp + ks * 16 + 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = j < 4 ? w0[j] : w1[j - 4];
+        const __bf16 a = (__bf16)v;
+        const float r1 = v - (float)a;
+        const __bf16 b = (__bf16)r1;
+        wb[ks][0][j] = a; wb[ks][1][j] = b; wb[ks][2][j] = (__bf16)(r1 - (float)b);
+      }
+    }
+  }
+  const float bv = bias ? bias[col] : 0.f;
+
+  constexpr int K4 = K / 4;
+  const int kc4 = tid % K4;                 // float4 column: this thread always touches the same 4 k's
+  constexpr int ROWS_PER_PASS = NTHR / K4;
+  constexpr int NP = BM / ROWS_PER_PASS;    // 16-B loads per thread per tile
+  const int prow = tid / K4;
+  const int64_t n_tiles = (M + BM - 1) / BM;
+  f32x4 nx[NP];
+  auto fetch = [&](int64_t tile) {
+    const int64_t row0 = tile * BM;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      int64_t gr = row0 + p * ROWS_PER_PASS + prow;
+      if (gr > M - 1) gr = M - 1;           // clamp (no exec-masked loads); such rows are never stored
+      nx[p] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + kc4 * 4);
+    }
+  };
+  auto stage = [&](int64_t tile, int buf) {  // prologue + split + three plane writes
+    const int64_t row0 = tile * BM;
+    __bf16* pb = planes + (size_t)buf * 3 * BM * LDP;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    const bool has_pro = pr.scale || pr.relu || pr.p > 0.f;
+    if (pr.scale) {
+      sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
+      sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = p * ROWS_PER_PASS + prow;
+      const int64_t gr = row0 + r < M ? row0 + r : M - 1;
+      f32x4 v = nx[p];
+      if (has_pro) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mmg_pro_apply(pr, v[j], sc[j], sh[j], gr, kc4 * 4 + j, K);
+      }
+      xbf16x4 q0, q1, q2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        const float r1 = v[j] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        q0[j] = a; q1[j] = b; q2[j] = (__bf16)(r1 - (float)b);
+      }
+      *reinterpret_cast<xbf16x4*>(pb + (0 * BM + r) * LDP + kc4 * 4) = q0;
+      *reinterpret_cast<xbf16x4*>(pb + (1 * BM + r) * LDP + kc4 * 4) = q1;
+      *reinterpret_cast<xbf16x4*>(pb + (2 * BM + r) * LDP + kc4 * 4) = q2;
+    }
+  };
+  int64_t t = blockIdx.y;
+  if (t >= n_tiles) return;
+  fetch(t);
+  stage(t, 0);
+  if (t + gridDim.y < n_tiles) fetch(t + gridDim.y);
+  __syncthreads();
+  int buf = 0;
+  for (; t < n_tiles; t += gridDim.y) {
+    const int64_t tn = t + gridDim.y;
+    if (tn < n_tiles) {
+      stage(tn, buf ^ 1);                    // the other buffer: its readers passed the barrier of the last tile
+      if (tn + gridDim.y < n_tiles) fetch(tn + gridDim.y);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + (wm * 32 + l31) * LDP + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const xbf16x8 a1 = *reinterpret_cast<const xbf16x8*>(ap + ks * 16);
+      const xbf16x8 a2 = *reinterpret_cast<const xbf16x8*>(ap + BM * LDP + ks * 16);
+      const xbf16x8 a3 = *reinterpret_cast<const xbf16x8*>(ap + 2 * BM * LDP + ks * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wb[ks][0], acc, 0, 0, 0);   // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wb[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wb[ks][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][0], acc, 0, 0, 0);
+    }
+    const int64_t row0 = t * BM;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t gr = row0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (gr < M) {
+        float* dst = Y + (size_t)gr * N + col;
+        float v = acc[i] + bv;
+        if (accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+    __syncthreads();                         // buf fully read, buf^1 fully written
+    buf ^= 1;
+  }
+}
+
+template <int K, int WN>
+int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                  int accumulate, hipStream_t st) {
+  constexpr int BN = 32 * WN;
+  const int n_slices = N / BN;
+  const int64_t n_tiles = (M + BM - 1) / BM;
+  int64_t gy = 256 / n_slices;               // one persistent workgroup per CU
+  if (gy < 1) gy = 1;
+  if (gy > n_tiles) gy = n_tiles;
+  const size_t lds = (size_t)2 * 3 * BM * (K + 8) * 2;
+  (void)hipFuncSetAttribute((const void*)k_linear_fwd_x6<K, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_linear_fwd_x6<K, WN>), dim3((unsigned)n_slices, (unsigned)gy), dim3(128 * WN), lds, st, X, pr, W,
+                     bias, Y, M, N, accumulate);
+  return 0;
+}
+
 // Small M (the vocab-side tables: 50..200 rows): one wave per 32x32 output tile, both operands
 // straight from L2 into registers -- no LDS, no barrier, M/32 x N/32 independent waves.
 template <int K>
@@ -319,6 +471,11 @@ int launch_fwd(const float* X, const ProDev& pr, const float* W, const float* bi
   return 0;
 }
 
+inline bool fp32_mfma() {
+  static const int v = [] { const char* e = getenv("MMG_LINEAR_FP32"); return e ? atoi(e) : 0; }();
+  return v != 0;
+}
+
 template <int K>
 int launch_small(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                  int accumulate, hipStream_t st) {
@@ -343,6 +500,15 @@ extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const f
     if (K == 64) launch_small<64>(X, pr, W, bias, Y, M, N, accumulate, st);
     else if (K == 128) launch_small<128>(X, pr, W, bias, Y, M, N, accumulate, st);
     else launch_small<256>(X, pr, W, bias, Y, M, N, accumulate, st);
+  } else if (K <= 128 && !fp32_mfma()) {
+    // exact-product 6-term bf16 split on the bf16 matrix cores (MMG_LINEAR_FP32=1: the fp32-MFMA kernels below)
+    if (K == 64) {
+      if (N % 128 == 0) launch_fwd_x6<64, 4>(X, pr, W, bias, Y, M, N, accumulate, st);
+      else launch_fwd_x6<64, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
+    } else {
+      if (N % 128 == 0) launch_fwd_x6<128, 4>(X, pr, W, bias, Y, M, N, accumulate, st);
+      else launch_fwd_x6<128, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
+    }
   } else if (K == 64) {
     if (N % 128 == 0) launch_fwd<64, 2, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
     else launch_fwd<64, 1, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
