@@ -428,6 +428,177 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
       }
 }
 
+// wgrad on the bf16 matrix cores: dW[n, k] = sum_m dY[m, n] * pro(X)[m, k] with the same exact 6-term split.  Both
+// operands are contracted over their ROW index, so the fragments are column slices of the row-major tiles: the
+// three bf16 planes of dY and X are staged row-major (coalesced 16-B loads, one split per element) and read back
+// through the gfx950 transposing LDS read (ds_read_b64_tr_b16: a 16-lane group fetches 4 rows x 16 columns and
+// each lane receives 4 consecutive rows of ITS column).  Row stride = tile bytes + 64: the 4 rows of a group then
+// sit on 4 disjoint 16-bank spans (conflict-free).  32-row stages, double-buffered, one barrier per stage.
+typedef short xs16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ xbf16x8 tr_frag(const __bf16* p, int row_stride) {   // rows +0..3 and +4..7 of this lane's column
+  const xs16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) xs16x4*)p);
+  const xs16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) xs16x4*)(p + 4 * row_stride));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(xbf16x8, v);
+}
+
+template <int TN, int TK, int WNN, int WNK>      // WNN x WNK waves over the [TN, TK] output tile
+__global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float* __restrict__ dY, const float* __restrict__ X,
+                                                         ProDev pr, float* __restrict__ slab, int64_t M, int N, int K,
+                                                         int64_t rows_per_split, int direct_accumulate) {
+  pr.resolve();
+  constexpr int NTHR = 64 * WNN * WNK;
+  constexpr int MT = TN / (32 * WNN), KT = TK / (32 * WNK);      // 32x32 tiles per wave along n and k
+  static_assert(MT >= 1 && KT >= 1, "tile too small for the wave grid");
+  constexpr int SY = TN + 32, SX = TK + 32;      // plane row strides in bf16 (+64 B)
+  constexpr int PY = 3 * WG_ROWS * SY, PX = 3 * WG_ROWS * SX;
+  extern __shared__ __attribute__((aligned(16))) __bf16 wplanes[];   // [2][ dY: 3 x 32 x SY | X: 3 x 32 x SX ]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid / WNK, wk = wid % WNK;
+  const int tiles_k = K / TK;
+  const int tn0 = (blockIdx.x / tiles_k) * TN, tk0 = (blockIdx.x % tiles_k) * TK;
+  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t r_end = min(M, r_beg + rows_per_split);
+
+  f32x16 acc[MT][KT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  constexpr int NY = WG_ROWS * (TN / 4) / NTHR, NX = WG_ROWS * (TK / 4) / NTHR;   // 16-B loads per thread per stage
+  static_assert(NY >= 1 && NX >= 1, "stage smaller than the workgroup");
+  f32x4 ny[NY], nxr[NX];
+  auto fetch = [&](int64_t r0) {                 // rows past the end are clamped and zeroed when staged
+#pragma unroll
+    for (int u = 0; u < NY; ++u) {
+      const int i = tid + u * NTHR, r = i / (TN / 4), c4 = i - r * (TN / 4);
+      const int64_t gr = r0 + r < r_end ? r0 + r : r_end - 1;
+      ny[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * N + tn0 + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int i = tid + u * NTHR, r = i / (TK / 4), c4 = i - r * (TK / 4);
+      const int64_t gr = r0 + r < r_end ? r0 + r : r_end - 1;
+      nxr[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + tk0 + c4 * 4);
+    }
+  };
+  auto split_store = [&](f32x4 v, __bf16* plane0, int plane_elems, int off) {
+    xbf16x4 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const __bf16 a = (__bf16)v[j];
+      const float r1 = v[j] - (float)a;
+      const __bf16 b = (__bf16)r1;
+      q0[j] = a; q1[j] = b; q2[j] = (__bf16)(r1 - (float)b);
+    }
+    *reinterpret_cast<xbf16x4*>(plane0 + off) = q0;
+    *reinterpret_cast<xbf16x4*>(plane0 + plane_elems + off) = q1;
+    *reinterpret_cast<xbf16x4*>(plane0 + 2 * plane_elems + off) = q2;
+  };
+  auto stage = [&](int64_t r0, int buf) {
+    __bf16* yb = wplanes + (size_t)buf * (PY + PX);
+    __bf16* xb = yb + PY;
+    const bool has_pro = pr.scale || pr.relu || pr.p > 0.f;
+#pragma unroll
+    for (int u = 0; u < NY; ++u) {
+      const int i = tid + u * NTHR, r = i / (TN / 4), c4 = i - r * (TN / 4);
+      f32x4 v = ny[u];
+      if (r0 + r >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      split_store(v, yb, WG_ROWS * SY, r * SY + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int i = tid + u * NTHR, r = i / (TK / 4), c4 = i - r * (TK / 4);
+      f32x4 v = nxr[u];
+      const int64_t gr = r0 + r;
+      if (gr < r_end && has_pro) {
+        const int k = tk0 + c4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sc = pr.scale ? pr.scale[k + j] : 1.f, sh = pr.scale ? pr.shift[k + j] : 0.f;
+          v[j] = mmg_pro_apply(pr, v[j], sc, sh, gr, k + j, K);
+        }
+      }
+      if (gr >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      split_store(v, xb, WG_ROWS * SX, r * SX + c4 * 4);
+    }
+  };
+  // transposing-read lane roles: group g = lane >> 4 fetches rows 8 (g >> 1) + q, columns 16 (g & 1) + 4 p
+  const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const int tr_row = 8 * (g >> 1) + q, tr_col = 16 * (g & 1) + 4 * p4;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  if (r_beg < r_end) {
+    fetch(r_beg);
+    stage(r_beg, 0);
+    if (r_beg + WG_ROWS < r_end) fetch(r_beg + WG_ROWS);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t r0 = r_beg; r0 < r_end; r0 += WG_ROWS) {
+    if (r0 + WG_ROWS < r_end) {
+      stage(r0 + WG_ROWS, buf ^ 1);
+      if (r0 + 2 * WG_ROWS < r_end) fetch(r0 + 2 * WG_ROWS);
+    }
+    const __bf16* yb = wplanes + (size_t)buf * (PY + PX) + tr_row * SY + wn * (TN / WNN) + tr_col;
+    const __bf16* xb = wplanes + (size_t)buf * (PY + PX) + PY + tr_row * SX + wk * (TK / WNK) + tr_col;
+#pragma unroll
+    for (int ks = 0; ks < WG_ROWS / 16; ++ks) {
+      xbf16x8 a[MT][3], b[KT][3];
+#pragma unroll
+      for (int x = 0; x < MT; ++x)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) a[x][pc] = tr_frag(yb + pc * WG_ROWS * SY + ks * 16 * SY + x * 32, SY);
+#pragma unroll
+      for (int x = 0; x < KT; ++x)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) b[x][pc] = tr_frag(xb + pc * WG_ROWS * SX + ks * 16 * SX + x * 32, SX);
+#pragma unroll
+      for (int x = 0; x < MT; ++x)
+#pragma unroll
+        for (int y = 0; y < KT; ++y) {
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][2], b[y][0], acc[x][y], 0, 0, 0);   // small terms first
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][2], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][1], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][1], b[y][0], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][1], acc[x][y], 0, 0, 0);
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][0], b[y][0], acc[x][y], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  // slab[split][N][K]; with a single split `slab` is dW itself (direct_accumulate: 1 = overwrite, 2 = add)
+  float* dst = slab + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < KT; ++y)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = tn0 + wn * (TN / WNN) + x * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const int k = tk0 + wk * (TK / WNK) + y * 32 + l31;
+        float v = acc[x][y][i];
+        if (direct_accumulate == 2) v += dst[(size_t)n * K + k];
+        dst[(size_t)n * K + k] = v;
+      }
+}
+
+template <int TN, int TK, int WNN, int WNK>
+void launch_wgrad_x6(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
+                     int N, int K, int64_t rps, int direct) {
+  const size_t lds = (size_t)2 * 3 * WG_ROWS * ((TN + 32) + (TK + 32)) * 2;
+  (void)hipFuncSetAttribute((const void*)k_linear_wgrad_x6<TN, TK, WNN, WNK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((k_linear_wgrad_x6<TN, TK, WNN, WNK>), grid, dim3(64 * WNN * WNK), lds, st, dY, X, pr, target, M, N, K,
+                     rps, direct);
+}
+
 struct EpiStore {
   float* out; int accumulate;
   __device__ void operator()(int64_t i4, mmg_f4 v) const {
@@ -554,7 +725,13 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
   dim3 grid((unsigned)p.n_tiles, (unsigned)p.n_split);
   const int direct = p.n_split == 1 ? (accumulate ? 2 : 1) : 0;     // small M: no slab, no reduce launch
   float* target = direct ? dW : slab;
-  if (p.TN == 128 && p.TK == 128)
+  if (!fp32_mfma()) {
+    // eight waves (two per SIMD: one stages while the other multiplies) wherever the tile has 8 sub-tiles
+    if (p.TN == 128 && p.TK == 128) launch_wgrad_x6<128, 128, 4, 2>(grid, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
+    else if (p.TN == 128) launch_wgrad_x6<128, 64, 4, 2>(grid, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
+    else if (p.TK == 128) launch_wgrad_x6<64, 128, 2, 4>(grid, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
+    else launch_wgrad_x6<64, 64, 2, 2>(grid, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
+  } else if (p.TN == 128 && p.TK == 128)
     hipLaunchKernelGGL((k_linear_wgrad<128, 128>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
   else if (p.TN == 128)
     hipLaunchKernelGGL((k_linear_wgrad<128, 64>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
