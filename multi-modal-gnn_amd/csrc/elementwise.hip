@@ -7,14 +7,18 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int CR_MAX_BLOCKS = 2048;
+// Big inputs: one 1024-thread workgroup per CU (16 waves keep 128 KB of loads in flight per CU) so that only 256
+// partial rows are left for the second pass; small inputs: 256-thread workgroups of 64 rows.
+constexpr int CR_BIG_ROWS = 32768, CR_BIG_BLOCKS = 256, CR_MAX_BLOCKS = 2048;
 
-struct ColGeom { int cg, rl; int nblk; int64_t rows_per_blk; };
+struct ColGeom { int cg, rl; int nblk; int64_t rows_per_blk; int nthr; };
 inline bool col_geom(int64_t M, int N, ColGeom* g) {
   if (N % 4 || N / 4 > 256 || 256 % (N / 4)) return false;
-  g->cg = N / 4; g->rl = 256 / g->cg;
+  g->nthr = M >= CR_BIG_ROWS ? 1024 : 256;
+  g->cg = N / 4; g->rl = g->nthr / g->cg;
   int64_t nb = (M + 63) / 64;
-  if (nb > CR_MAX_BLOCKS) nb = CR_MAX_BLOCKS;
+  const int64_t cap = M >= CR_BIG_ROWS ? CR_BIG_BLOCKS : CR_MAX_BLOCKS;
+  if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   g->nblk = (int)nb;
   g->rows_per_blk = (M + nb - 1) / nb;
@@ -23,14 +27,14 @@ inline bool col_geom(int64_t M, int N, ColGeom* g) {
 
 // MODE 0: a = A, b = B (or A if B null)       -> (sum a, sum a*b)
 // MODE 1: BN backward stats: a = g_out(G,Y), b = xhat(Y)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ A, const float* __restrict__ B,
-                                                    ProDev pr, const float* __restrict__ mean,
-                                                    const float* __restrict__ rstd, double* __restrict__ partial,
-                                                    int64_t M, int N, int64_t rows_per_blk) {
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, const float* __restrict__ B,
+                                                   ProDev pr, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, double* __restrict__ partial,
+                                                   int64_t M, int N, int64_t rows_per_blk) {
   pr.resolve();
-  __shared__ double red[2 * 1024];   // [rl][2][N] with rl*N == 1024
-  const int cg = N / 4, rl = 256 / cg;
+  __shared__ double red[8 * NT];     // [rl][2][N] with rl*N == 4*NT
+  const int cg = N / 4, rl = NT / cg;
   const int c4 = threadIdx.x % cg, rr = threadIdx.x / cg;
   double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f};
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void k_col_reduce(const float* __restrict__ A,
     red[(rr * 2 + 1) * N + c4 * 4 + j] = s1[j];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+  for (int i = threadIdx.x; i < 2 * N; i += NT) {
     double s = 0;
     for (int q = 0; q < rl; ++q) s += red[q * 2 * N + i];
     partial[(size_t)blockIdx.x * 2 * N + i] = s;
@@ -287,11 +291,15 @@ int run_col_reduce(const float* A, const float* B, const ProDev& pr, const float
   if (ws_bytes < need) { mmg_set_error("%s: workspace %zu < %zu", what, ws_bytes, need); return MMG_E_WS; }
   double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   if (g.nblk == 1) {      // small tables (vocab side): the single workgroup's result IS the answer
-    hipLaunchKernelGGL(k_col_reduce<MODE>, dim3(1), dim3(256), 0, st, A, B, pr, mean, rstd, out, M, N, g.rows_per_blk);
+    hipLaunchKernelGGL((k_col_reduce<MODE, 256>), dim3(1), dim3(256), 0, st, A, B, pr, mean, rstd, out, M, N, g.rows_per_blk);
     return MMG_OK;
   }
-  hipLaunchKernelGGL(k_col_reduce<MODE>, dim3(g.nblk), dim3(256), 0, st, A, B, pr, mean, rstd, partial, M, N,
-                     g.rows_per_blk);
+  if (g.nthr == 1024)
+    hipLaunchKernelGGL((k_col_reduce<MODE, 1024>), dim3(g.nblk), dim3(1024), 0, st, A, B, pr, mean, rstd, partial, M, N,
+                       g.rows_per_blk);
+  else
+    hipLaunchKernelGGL((k_col_reduce<MODE, 256>), dim3(g.nblk), dim3(256), 0, st, A, B, pr, mean, rstd, partial, M, N,
+                       g.rows_per_blk);
   hipLaunchKernelGGL(k_partial_sum, dim3((2 * N + 3) / 4), dim3(256), 0, st, partial, out, 2 * N, g.nblk);
   return MMG_OK;
 }

@@ -49,11 +49,16 @@ class OpProfiler:
         torch.cuda.synchronize()
         out = {}
         for name, e0, e1, nbytes, flops in self.rows:
-            d = out.setdefault(name, dict(calls=0, ms=0.0, bytes=0, flops=0))
+            d = out.setdefault(name, dict(calls=0, ms=0.0, bytes=0, flops=0, shapes={}))
+            ms = e0.elapsed_time(e1)
             d["calls"] += 1
-            d["ms"] += e0.elapsed_time(e1)
+            d["ms"] += ms
             d["bytes"] += nbytes
             d["flops"] += flops
+            # launches of one op with the same algorithmic size are one kernel shape
+            sh = d["shapes"].setdefault((nbytes, flops), dict(calls=0, ms=0.0, bytes=nbytes, flops=flops))
+            sh["calls"] += 1
+            sh["ms"] += ms
         return out
 
 
