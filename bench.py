@@ -129,7 +129,7 @@ def build_workload(args, world, rank, dev):
 def train_step(w):
     model, opt = w["model"], w["opt"]
     model.train()
-    opt.zero_grad(set_to_none=True)
+    model.zero_grad(set_to_none=True)    # all parameters (the frozen embedding tables too): .grad adopted, not accumulated
     pred = model.predict_lab_values(w["plan"], w["pi"], w["li"])
     # weighted MAE over the supervision subset (train.py:366-386), global mean over all shards: one fused pass
     loss = ops.weighted_pair_loss(pred, w["y"], w["wpair"], w["supf"], 1.0 / w["n_sup"], "mae")

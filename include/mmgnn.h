@@ -121,9 +121,13 @@ typedef struct {
                               (lets a captured hipGraph draw fresh masks on every replay) */
 } mmg_prologue_t;
 
-/* Y[M,N] = prologue(X)[M,K] . W[N,K]^T (+ bias[N]) (+ Y if accumulate)            */
+/* Y[M,N] = prologue(X)[M,K] . W[N,K]^T (+ bias[N]) (+ Y if MMG_LIN_ACCUMULATE).
+ * MMG_LIN_W_KN: W is stored [K,N] (Y = X . W) -- the data-gradient GEMMs of the backward pass read the forward
+ * weight in place instead of a transposed copy. */
+#define MMG_LIN_ACCUMULATE 1
+#define MMG_LIN_W_KN 2
 int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
-                   float* Y, int64_t M, int N, int K, int accumulate, void* stream);
+                   float* Y, int64_t M, int N, int K, int flags, void* stream);
 
 /* dW[N,K] (+)= dY[M,N]^T . prologue(X)[M,K]   (reduction over the M rows)          */
 size_t mmg_linear_wgrad_ws_bytes(int64_t M, int N, int K);

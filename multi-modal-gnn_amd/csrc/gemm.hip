@@ -27,8 +27,9 @@ constexpr int BM = 64;
 template <int K, int NTW, int OCC, int PF>
 __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict__ X, ProDev pr,
                                                        const float* __restrict__ W, const float* __restrict__ bias,
-                                                       float* __restrict__ Y, int64_t M, int N, int accumulate) {
+                                                       float* __restrict__ Y, int64_t M, int N, int flags) {
   pr.resolve();
+  const int accumulate = flags & MMG_LIN_ACCUMULATE;
   constexpr int LDK = K + 4;            // row stride (floats): shifts rows by one 16-B slot
   constexpr int BN = 64 * NTW;
   __shared__ __attribute__((aligned(16))) float Xs[BM * LDK];
@@ -42,11 +43,17 @@ __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict
   float wr[NTW][K / 2];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
-    const float* wp = W + (size_t)(n0 + nt * 32 + l31) * K + h * (K / 2);
+    if (flags & MMG_LIN_W_KN) {
+      const float* wp = W + (size_t)(h * (K / 2)) * N + n0 + nt * 32 + l31;
 #pragma unroll
-    for (int q = 0; q < K / 8; ++q) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wp + q * 4);
-      wr[nt][q * 4 + 0] = w[0]; wr[nt][q * 4 + 1] = w[1]; wr[nt][q * 4 + 2] = w[2]; wr[nt][q * 4 + 3] = w[3];
+      for (int s = 0; s < K / 2; ++s) wr[nt][s] = wp[(size_t)s * N];
+    } else {
+      const float* wp = W + (size_t)(n0 + nt * 32 + l31) * K + h * (K / 2);
+#pragma unroll
+      for (int q = 0; q < K / 8; ++q) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + q * 4);
+        wr[nt][q * 4 + 0] = w[0]; wr[nt][q * 4 + 1] = w[1]; wr[nt][q * 4 + 2] = w[2]; wr[nt][q * 4 + 3] = w[3];
+      }
     }
   }
   float bv[NTW];
@@ -147,8 +154,9 @@ typedef __bf16 xbf16x4 __attribute__((ext_vector_type(4)));
 template <int K, int WN>          // WN waves along N (32 columns each), 2 along M: 128 * WN threads
 __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restrict__ X, ProDev pr,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
-                                                            float* __restrict__ Y, int64_t M, int N, int accumulate) {
+                                                            float* __restrict__ Y, int64_t M, int N, int flags) {
   pr.resolve();
+  const int accumulate = flags & MMG_LIN_ACCUMULATE;
   constexpr int LDP = K + 8;            // plane row stride in bf16 (K*2 + 16 bytes: fragment reads hit 64 distinct banks)
   constexpr int BN = 32 * WN, NK = K / 16, NTHR = 128 * WN;
   extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
@@ -159,10 +167,17 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
 
   xbf16x8 wb[NK][3];
   {
-    const float* wp = W + (size_t)col * K + 8 * h;
+    const bool wkn = (flags & MMG_LIN_W_KN) != 0;
+    const float* wp = wkn ? W + (size_t)(8 * h) * N + col : W + (size_t)col * K + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + ks * 16), w1 = *reinterpret_cast<const f32x4*>(wp + ks * 16 + 4);
+      f32x4 w0, w1;
+      if (wkn) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w0[j] = wp[(size_t)(ks * 16 + j) * N]; w1[j] = wp[(size_t)(ks * 16 + 4 + j) * N]; }
+      } else {
+        w0 = *reinterpret_cast<const f32x4*>(wp + ks * 16); w1 = *reinterpret_cast<const f32x4*>(wp + ks * 16 + 4);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float v = j < 4 ? w0[j] : w1[j - 4];
@@ -288,21 +303,29 @@ int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float*
 template <int K>
 __global__ __launch_bounds__(64) void k_linear_small(const float* __restrict__ X, ProDev pr,
                                                      const float* __restrict__ W, const float* __restrict__ bias,
-                                                     float* __restrict__ Y, int64_t M, int N, int accumulate) {
+                                                     float* __restrict__ Y, int64_t M, int N, int flags) {
   pr.resolve();
+  const int accumulate = flags & MMG_LIN_ACCUMULATE;
+  const bool wkn = (flags & MMG_LIN_W_KN) != 0;
   const int lane = threadIdx.x, h = lane >> 5, l31 = lane & 31;
   const int n0 = blockIdx.x * 32;
   const int64_t row0 = (int64_t)blockIdx.y * 32;
   const int64_t ar = row0 + l31;
   const float* xp = X + (size_t)(ar < M ? ar : 0) * K + h * (K / 2);
-  const float* wp = W + (size_t)(n0 + l31) * K + h * (K / 2);
+  const float* wp = wkn ? W + (size_t)(h * (K / 2)) * N + n0 + l31 : W + (size_t)(n0 + l31) * K + h * (K / 2);
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll 4
   for (int q = 0; q < K / 8; ++q) {
     f32x4 a = *reinterpret_cast<const f32x4*>(xp + q * 4);
-    const f32x4 w = *reinterpret_cast<const f32x4*>(wp + q * 4);
+    f32x4 w;
+    if (wkn) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = wp[(size_t)(q * 4 + j) * N];
+    } else {
+      w = *reinterpret_cast<const f32x4*>(wp + q * 4);
+    }
     if (pr.scale || pr.relu || pr.p > 0.f) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -658,8 +681,10 @@ int launch_small(const float* X, const ProDev& pr, const float* W, const float* 
 }  // namespace
 
 extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias, float* Y,
-                              int64_t M, int N, int K, int accumulate, void* stream) {
+                              int64_t M, int N, int K, int flags, void* stream) {
+  const int accumulate = flags;           // the launchers forward the whole flag word
   MMG_CHECK_ARG(M >= 0, "linear_fwd: M < 0");
+  MMG_CHECK_ARG((flags & ~(MMG_LIN_ACCUMULATE | MMG_LIN_W_KN)) == 0, "linear_fwd: unknown flag bits");
   MMG_CHECK_ARG(K == 64 || K == 128 || K == 256, "linear_fwd: K=%d unsupported (64|128|256)", K);
   MMG_CHECK_ARG(N > 0 && N % 64 == 0 && N <= 4096, "linear_fwd: N=%d must be a multiple of 64", N);
   if (M == 0) return MMG_OK;

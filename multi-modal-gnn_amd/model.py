@@ -374,7 +374,7 @@ class _Run:
             self.comm.all_reduce_list([self.grads[n] for n in sorted(self.partial)])
         out = []
         for n in self.names:
-            g = self.grads.get(n)
+            g = self.grads.pop(n, None)       # drop our reference: autograd can then adopt the tensor as .grad (no clone)
             if g is not None and g.shape != self.params[n].shape:
                 g = g.reshape(self.params[n].shape)
             out.append(g)
@@ -438,7 +438,7 @@ class _Run:
         if bname is not None:
             self.acc(bname, ops.col_reduce2(dy)[0].float(), partial)
         if need_dx:
-            return ops.linear_fwd(dy, self.W(wname).t().contiguous())
+            return ops.linear_fwd(dy, self.W(wname), w_kn=True)          # dX = dY . W, W read in place
         return None
 
     def enc_bwd(self, enc, g_x0):
@@ -543,13 +543,20 @@ class _Run:
         def add(t, v):
             g_in[t] = v if g_in[t] is None else g_in[t].add_(v)
 
+        def add_dgrad(t, dy_, W_):
+            """g_in[t] += dy_ . W_  (W_ is the forward weight [N,K], read in place; accumulated by the GEMM itself)."""
+            if g_in[t] is None:
+                g_in[t] = ops.linear_fwd(dy_, W_, w_kn=True)
+            else:
+                ops.linear_fwd(dy_, W_, w_kn=True, out=g_in[t], accumulate=True)
+
         # ---- patient destination
         dyP = dy.get(ROW_TYPE)
         if dyP is not None and rec["rin"]:
             xP = x[ROW_TYPE]
             dWsum = ops.linear_wgrad(dyP, xP)
             dbsum = ops.col_reduce2(dyP)[0].float()
-            add(ROW_TYPE, ops.linear_fwd(dyP, rec["Wsum"].t().contiguous()))
+            add_dgrad(ROW_TYPE, dyP, rec["Wsum"])
             rels, dTs, off = [], [], 0
             buf = torch.empty(sum(r.n_cols for r in rec["rin"]), D, device=self.dev)
             for r in rec["rin"]:
@@ -564,7 +571,7 @@ class _Run:
                 self.acc(nme + ".lin_r.weight", dWsum, partial=True)
                 self.acc(nme + ".lin_l.bias", dbsum, partial=True)
                 self.acc(nme + ".lin_l.weight", ops.linear_wgrad(dT, x[r.other]))
-                add(r.other, ops.linear_fwd(dT, self.W(nme + ".lin_l.weight").t().contiguous()))
+                add_dgrad(r.other, dT, self.W(nme + ".lin_l.weight"))
         # ---- vocab destinations
         if rec["rout"]:
             rels = []
@@ -576,8 +583,8 @@ class _Run:
                 self.acc(nme + ".lin_l.weight", ops.linear_wgrad(dyv, agg))
                 self.acc(nme + ".lin_l.bias", ops.col_reduce2(dyv)[0].float())
                 self.acc(nme + ".lin_r.weight", ops.linear_wgrad(dyv, x[r.other]))
-                add(r.other, ops.linear_fwd(dyv, self.W(nme + ".lin_r.weight").t().contiguous()))
-                dagg = ops.linear_fwd(dyv, self.W(nme + ".lin_l.weight").t().contiguous())
+                add_dgrad(r.other, dyv, self.W(nme + ".lin_r.weight"))
+                dagg = ops.linear_fwd(dyv, self.W(nme + ".lin_l.weight"), w_kn=True)
                 rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=dagg, simple=r.simple, mask_r=r.mask_r))
             if rels:
                 if g_in[ROW_TYPE] is None:
@@ -646,8 +653,8 @@ class _Run:
                 self.allreduce(dW1a)             # so that the concatenated weight grad is uniformly "full"
             self.acc(f"{which}.mlp.0.weight", torch.cat([dW1a, dW1b], dim=1))
             self.acc(f"{which}.mlp.0.bias", ops.col_reduce2(g.B)[0].float())
-            gP = ops.linear_fwd(g.A, w1a.t().contiguous())
-            glab = ops.linear_fwd(g.B, w1b.t().contiguous())
+            gP = ops.linear_fwd(g.A, w1a, w_kn=True)
+            glab = ops.linear_fwd(g.B, w1b, w_kn=True)
             gsets[which] = {ROW_TYPE: gP, "lab": glab}
         return gsets["tabular_mlp"], gsets["edge_predictor"]
 

@@ -252,12 +252,12 @@ def scatter_rows(rels: Sequence[Rel], n_rows: int, D: int, x: torch.Tensor):
 
 # ------------------------------------------------------------------------------------------ dense
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, pro: Optional[Pro] = None,
-               out: Optional[torch.Tensor] = None, accumulate: bool = False):
-    """out[M,N] (+)= pro(x)[M,K] @ W[N,K]^T + bias."""
+               out: Optional[torch.Tensor] = None, accumulate: bool = False, w_kn: bool = False):
+    """out[M,N] (+)= pro(x)[M,K] @ W[N,K]^T + bias;  w_kn: W is stored [K,N] (out = x @ W), read in place."""
     lib = _lib.load()
     M, K = x.shape
-    N = W.shape[0]
-    if W.shape[1] != K:
+    N = W.shape[1] if w_kn else W.shape[0]
+    if (W.shape[0] if w_kn else W.shape[1]) != K:
         raise ValueError(f"linear_fwd: W {tuple(W.shape)} vs x {tuple(x.shape)}")
     if out is None:
         if accumulate:
@@ -267,7 +267,7 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
         raise ValueError("linear_fwd: out shape")
     _tok = _pb("linear_fwd")
     check(lib.mmg_linear_fwd(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"), _p(out, name="out"),
-                             M, N, K, int(accumulate), _stream()), "mmg_linear_fwd")
+                             M, N, K, int(accumulate) | (2 if w_kn else 0), _stream()), "mmg_linear_fwd")
     _pe(_tok, "linear_fwd", 4 * (M * K + N * K + M * N * (2 if accumulate else 1)), 2 * M * N * K)
     return out
 

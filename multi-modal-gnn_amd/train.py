@@ -268,7 +268,8 @@ class GraphedTrainStep:
 
     def _body(self):
         from . import ops
-        self.opt.zero_grad(set_to_none=True)
+        # every parameter, the (frozen, F5) embedding tables included: their .grad is then adopted, not accumulated
+        self.model.zero_grad(set_to_none=True)
         pred = self.model.predict_lab_values(self.data, self.pi, self.li)
         if self.n_sup_global is None:
             inv_den = 1.0 / max(float(self._n_sup), 1.0)

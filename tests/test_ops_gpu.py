@@ -226,6 +226,10 @@ def test_linear_fwd(ops, dev, M, N, K):
     assert rel(y, ref) <= 1e-5
     y2 = ops.linear_fwd(x.to(dev), W.to(dev), None, out=y.clone(), accumulate=True)
     assert rel(y2, 2 * ref - b.double()) <= 1e-5
+    # the weight stored [K, N] (data-gradient GEMMs read the forward weight in place): same arithmetic, same bits
+    y3 = ops.linear_fwd(x.to(dev), W.t().contiguous().to(dev), b.to(dev), w_kn=True)
+    assert torch.equal(y3, y)
+    assert rel(y, ref) <= 2e-6                     # the 6-term bf16 split keeps fp32 accuracy
 
 
 def _host_pro(ops, dev, x, scale, shift, relu, p, seed, site, row_offset=0):
