@@ -38,22 +38,33 @@ __host__ __device__ static inline uint32_t mmg_mix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   return h;
 }
-__host__ __device__ static inline uint32_t mmg_rng_u32(uint64_t seed, uint32_t site, uint64_t elem) {
+// kernel-invariant part: (seed, site) -> 32-bit key (the compiler hoists it out of every loop)
+__host__ __device__ static inline uint32_t mmg_rng_key(uint64_t seed, uint32_t site) {
   uint32_t h = mmg_mix32((uint32_t)seed ^ 0x9e3779b9u);
-  h = mmg_mix32(h ^ (uint32_t)(seed >> 32) ^ (site * 0x632be5abu));
-  h = mmg_mix32(h ^ (uint32_t)elem);
-  h = mmg_mix32(h + (uint32_t)(elem >> 32) * 0x27d4eb2fu + 0x165667b1u);
-  return h;
+  return mmg_mix32(h ^ (uint32_t)(seed >> 32) ^ (site * 0x632be5abu));
 }
+// 64 random bits for one aligned GROUP of four consecutive elements (grp = elem >> 2): one full mix for the first
+// word, one multiply-xorshift step for the second (3 integer multiplies per 4 elements -- v_mul_lo_u32 is a
+// quarter-rate instruction and was the bottleneck of the pair-head kernels).
+__host__ __device__ static inline void mmg_rng_group(uint32_t key, uint64_t grp, uint32_t* w0, uint32_t* w1) {
+  const uint32_t hi = (uint32_t)(grp >> 32);
+  const uint32_t h = mmg_mix32(key ^ (uint32_t)grp ^ ((hi << 16) | (hi >> 16)) ^ hi);
+  uint32_t t = (h ^ (h >> 15)) * 0x2c1b3c6du;
+  t ^= t >> 13;
+  *w0 = h; *w1 = t;
+}
+// 16 random bits of element `sub` (0..3) of a group
+__host__ __device__ static inline uint32_t mmg_rng_field(uint32_t w0, uint32_t w1, uint32_t sub) {
+  const uint32_t word = (sub & 2u) ? w1 : w0;
+  return (word >> ((sub & 1u) * 16u)) & 0xFFFFu;
+}
+__host__ __device__ static inline uint32_t mmg_keep_threshold(float p) { return (uint32_t)(p * 65536.0f); }
 // keep with probability 1-p.  One hash serves FOUR consecutive elements (16 random bits each, p quantised
 // to 1/65536): callers walk elements in aligned groups of 4, so the compiler shares the hash across the group.
 __host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, uint64_t elem, float p) {
-  const uint32_t h1 = mmg_rng_u32(seed, site, elem >> 2);
-  const uint32_t h2 = mmg_mix32(h1 ^ 0x68bc21ebu);
-  const uint32_t sub = (uint32_t)elem & 3u;
-  const uint32_t word = (sub & 2u) ? h2 : h1;
-  const uint32_t bits = (word >> ((sub & 1u) * 16u)) & 0xFFFFu;
-  return bits >= (uint32_t)(p * 65536.0f);
+  uint32_t w0, w1;
+  mmg_rng_group(mmg_rng_key(seed, site), elem >> 2, &w0, &w1);
+  return mmg_rng_field(w0, w1, (uint32_t)elem & 3u) >= mmg_keep_threshold(p);
 }
 
 // folded prologue: dropout(relu(x*scale+shift)); returns the transformed value

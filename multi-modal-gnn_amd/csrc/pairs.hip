@@ -213,6 +213,39 @@ constexpr int WAVE_LDS = TP * LDH + TP * LDD + 4 * TP + 2 * TP;   // floats per 
 
 __device__ inline int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// Layer-2 dropout keeps in the MFMA C layout (lane = unit u, register r = pair row crow(r, h)): the element
+// (pair id, u) belongs to the RNG group (pair id * 8 + u / 4), shared by the four lanes of a quad.  Instead of every
+// lane hashing all 16 of its rows (4 lanes computing the same 64 bits), quad lane j hashes the rows with r % 4 == j
+// (4 hashes) and the words are broadcast inside the quad by DPP.  keep[r] = the 16-bit field of this lane's unit.
+template <int R>
+__device__ __forceinline__ uint32_t quad_bcast_field(const uint32_t* hw0, const uint32_t* hw1, uint32_t sub) {
+  constexpr int j = R & 3, i = R >> 2;
+  constexpr int ctrl = j | (j << 2) | (j << 4) | (j << 6);          // quad_perm: every lane reads quad lane j
+  const uint32_t w0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)hw0[i], ctrl, 0xF, 0xF, true);
+  const uint32_t w1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)hw1[i], ctrl, 0xF, 0xF, true);
+  return mmg_rng_field(w0, w1, sub);
+}
+__device__ __forceinline__ void layer2_fields(uint32_t key, const unsigned* PLo, const unsigned* PHi, int h, int l31,
+                                              uint32_t* bits /*[16]*/) {
+  uint32_t hw0[4], hw1[4];
+  const int j = l31 & 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = j + 8 * i + 4 * h;                              // = crow(j + 4 i, h)
+    const uint64_t pd = ((uint64_t)PHi[row] << 32) | PLo[row];
+    mmg_rng_group(key, pd * 8ull + (uint64_t)(l31 >> 2), &hw0[i], &hw1[i]);
+  }
+  const uint32_t sub = (uint32_t)l31 & 3u;
+  bits[0] = quad_bcast_field<0>(hw0, hw1, sub);   bits[1] = quad_bcast_field<1>(hw0, hw1, sub);
+  bits[2] = quad_bcast_field<2>(hw0, hw1, sub);   bits[3] = quad_bcast_field<3>(hw0, hw1, sub);
+  bits[4] = quad_bcast_field<4>(hw0, hw1, sub);   bits[5] = quad_bcast_field<5>(hw0, hw1, sub);
+  bits[6] = quad_bcast_field<6>(hw0, hw1, sub);   bits[7] = quad_bcast_field<7>(hw0, hw1, sub);
+  bits[8] = quad_bcast_field<8>(hw0, hw1, sub);   bits[9] = quad_bcast_field<9>(hw0, hw1, sub);
+  bits[10] = quad_bcast_field<10>(hw0, hw1, sub); bits[11] = quad_bcast_field<11>(hw0, hw1, sub);
+  bits[12] = quad_bcast_field<12>(hw0, hw1, sub); bits[13] = quad_bcast_field<13>(hw0, hw1, sub);
+  bits[14] = quad_bcast_field<14>(hw0, hw1, sub); bits[15] = quad_bcast_field<15>(hw0, hw1, sub);
+}
+
 template <int LT>
 __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                        const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
@@ -323,6 +356,8 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
     }
     // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
     float d2c[16];
+    uint32_t kb[16];
+    if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PLo, PHi, h, l31, kb);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = crow(r, h);
@@ -330,8 +365,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
       float m = pre > 0.f ? 1.f : 0.f;
       float post = fmaxf(pre, 0.f);
       if (drop_p > 0.f) {
-        const uint64_t pd = ((uint64_t)PHi[row] << 32) | PLo[row];
-        const bool kp = mmg_keep(seed, SITE_H2, pd * 32ull + l31, drop_p);
+        const bool kp = kb[r] >= mmg_keep_threshold(drop_p);
         m = kp ? m * inv_keep : 0.f;
         post = kp ? post * inv_keep : 0.f;
       }
@@ -532,14 +566,12 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
       }
     // C layout: lane = unit u (l31), reg r = pair row crow(r,h).  v[r] = W3[u] * dropout(relu(pre))
     float v[16];
+    uint32_t kb[16];
+    if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PL[wid], PH[wid], h, l31, kb);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float post = fmaxf(acc[r] + b2v, 0.f);
-      if (drop_p > 0.f) {
-        const int row = crow(r, h);
-        const uint64_t pd = ((uint64_t)PH[wid][row] << 32) | PL[wid][row];
-        post = mmg_keep(seed, SITE_H2, pd * 32ull + l31, drop_p) ? post * inv_keep : 0.f;
-      }
+      if (drop_p > 0.f) post = kb[r] >= mmg_keep_threshold(drop_p) ? post * inv_keep : 0.f;
       v[r] = w3v * post;
     }
     // butterfly over the 32 unit lanes: after the 5 steps lane l31 holds the full sum of reg r = l31 >> 1
