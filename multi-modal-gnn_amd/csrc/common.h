@@ -61,6 +61,13 @@ __host__ __device__ static inline uint32_t mmg_rng_field(uint32_t w0, uint32_t w
 __host__ __device__ static inline uint32_t mmg_keep_threshold(float p) { return (uint32_t)(p * 65536.0f); }
 // keep with probability 1-p.  One hash serves FOUR consecutive elements (16 random bits each, p quantised
 // to 1/65536): callers walk elements in aligned groups of 4, so the compiler shares the hash across the group.
+// keep bits of the 4 consecutive elements e0 .. e0+3 (e0 % 4 == 0): bit j set = element j kept.  ONE hash.
+__host__ __device__ static inline uint32_t mmg_keep4(uint32_t key, uint64_t e0, uint32_t thr) {
+  uint32_t w0, w1;
+  mmg_rng_group(key, e0 >> 2, &w0, &w1);
+  return ((w0 & 0xFFFFu) >= thr ? 1u : 0u) | ((w0 >> 16) >= thr ? 2u : 0u) | ((w1 & 0xFFFFu) >= thr ? 4u : 0u) |
+         ((w1 >> 16) >= thr ? 8u : 0u);
+}
 __host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, uint64_t elem, float p) {
   uint32_t w0, w1;
   mmg_rng_group(mmg_rng_key(seed, site), elem >> 2, &w0, &w1);
@@ -71,8 +78,13 @@ __host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, ui
 struct ProDev {
   const float* scale; const float* shift; int relu; float p; float inv_keep; uint64_t seed; uint32_t site;
   int64_t row_offset; const uint64_t* seed_ptr;
-  // resolve a device-resident seed (hipGraph replays); call once at kernel entry
-  __device__ inline void resolve() { if (seed_ptr) seed = *seed_ptr; }
+  uint32_t key, thr;       // derived at kernel entry: RNG key of (seed, site), keep threshold of p
+  // resolve a device-resident seed (hipGraph replays) and derive the RNG constants; call once at kernel entry
+  __device__ inline void resolve() {
+    if (seed_ptr) seed = *seed_ptr;
+    key = mmg_rng_key(seed, site);
+    thr = mmg_keep_threshold(p);
+  }
 };
 static inline ProDev mmg_pro_dev(const mmg_prologue_t* pro) {
   ProDev d;
@@ -84,7 +96,26 @@ static inline ProDev mmg_pro_dev(const mmg_prologue_t* pro) {
     d.scale = nullptr; d.shift = nullptr; d.relu = 0; d.p = 0.f; d.inv_keep = 1.f; d.seed = 0; d.site = 0;
     d.row_offset = 0; d.seed_ptr = nullptr;
   }
+  d.key = 0; d.thr = 0;
   return d;
+}
+// four consecutive columns k0 .. k0+3 (k0 % 4 == 0, K % 4 == 0) of one row: the dropout hash is computed once
+template <class V4>
+__device__ static inline void mmg_pro_apply4(const ProDev& pr, V4& v, const V4& sc, const V4& sh, int64_t row, int k0,
+                                             int K) {
+  if (pr.scale) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
+  }
+  if (pr.relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+  }
+  if (pr.p > 0.f) {
+    const uint32_t m = mmg_keep4(pr.key, (uint64_t)(pr.row_offset + row) * (uint64_t)K + (uint64_t)k0, pr.thr);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (m >> j) & 1u ? v[j] * pr.inv_keep : 0.f;
+  }
 }
 __device__ static inline float mmg_pro_apply(const ProDev& pr, float x, float sc, float sh, int64_t row,
                                              int k, int K) {

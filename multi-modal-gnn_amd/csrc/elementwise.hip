@@ -48,6 +48,9 @@ __global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, 
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
   auto body = [&](int64_t r, const f32x4& a, const f32x4& b) {
+    uint32_t km = 15u;
+    if (MODE == 1 && pr.p > 0.f)
+      km = mmg_keep4(pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)(c4 * 4), pr.thr);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float av = a[j], bv = b[j];
@@ -56,10 +59,7 @@ __global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, 
         const float o = pr.scale ? fmaf(bv, sc[j], sh[j]) : bv;
         float g = av;
         if (pr.relu && !(o > 0.f)) g = 0.f;
-        if (pr.p > 0.f) {
-          const uint64_t e = (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)(c4 * 4 + j);
-          g = mmg_keep(pr.seed, pr.site, e, pr.p) ? g * pr.inv_keep : 0.f;
-        }
+        if (pr.p > 0.f) g = (km >> j) & 1u ? g * pr.inv_keep : 0.f;
         av = g;
         bv = (bv - mu[j]) * rs[j];
       }
@@ -156,8 +156,7 @@ __global__ __launch_bounds__(256) void k_affine_act_drop(const float* __restrict
   for (; i < n4; i += stride) {
     const int64_t r = i / (N / 4);
     f32x4 v = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = mmg_pro_apply(pr, v[j], sc[j], sh[j], r, c + j, N);
+    mmg_pro_apply4(pr, v, sc, sh, r, c, N);
     *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
   }
 }
@@ -184,16 +183,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(G + (size_t)i * 4);
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
     f32x4 o;
+    uint32_t km = 15u;
+    if (pr.p > 0.f) km = mmg_keep4(pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)c, pr.thr);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int k = c + j;
       const float act = pr.scale ? fmaf(y4[j], sc[j], sh[j]) : y4[j];
       float g = g4[j];
       if (pr.relu && !(act > 0.f)) g = 0.f;
-      if (pr.p > 0.f) {
-        const uint64_t e = (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)k;
-        g = mmg_keep(pr.seed, pr.site, e, pr.p) ? g * pr.inv_keep : 0.f;
-      }
+      if (pr.p > 0.f) g = (km >> j) & 1u ? g * pr.inv_keep : 0.f;
       if (pr.scale) {
         const float xh = (y4[j] - mu[j]) * rs[j];
         g = sc[j] * (g - a0[j] - xh * a1[j]);

@@ -95,8 +95,7 @@ __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict
           sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
           sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = mmg_pro_apply(pr, v[j], sc[j], sh[j], gr, kc4 * 4 + j, K);
+        mmg_pro_apply4(pr, v, sc, sh, gr, kc4 * 4, K);
       }
       *reinterpret_cast<f32x4*>(Xs + r * LDK + kc4 * 4) = v;
     }
@@ -221,8 +220,7 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
       const int64_t gr = row0 + r < M ? row0 + r : M - 1;
       f32x4 v = nx[p];
       if (has_pro) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = mmg_pro_apply(pr, v[j], sc[j], sh[j], gr, kc4 * 4 + j, K);
+        mmg_pro_apply4(pr, v, sc, sh, gr, kc4 * 4, K);
       }
       xbf16x4 q0, q1, q2;
 #pragma unroll
@@ -327,12 +325,10 @@ __global__ __launch_bounds__(64) void k_linear_small(const float* __restrict__ X
       w = *reinterpret_cast<const f32x4*>(wp + q * 4);
     }
     if (pr.scale || pr.relu || pr.p > 0.f) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = h * (K / 2) + q * 4 + j;
-        const float s = pr.scale ? pr.scale[k] : 1.f, sh = pr.scale ? pr.shift[k] : 0.f;
-        a[j] = mmg_pro_apply(pr, a[j], s, sh, ar, k, K);
-      }
+      const int k0 = h * (K / 2) + q * 4;
+      f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+      if (pr.scale) { s4 = *reinterpret_cast<const f32x4*>(pr.scale + k0); sh4 = *reinterpret_cast<const f32x4*>(pr.shift + k0); }
+      mmg_pro_apply4(pr, a, s4, sh4, ar, k0, K);
     }
     if (ar >= M) a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -410,11 +406,9 @@ __global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ 
       const int64_t gr = r0 + r;
       if (gr < r_end && (pr.scale || pr.relu || pr.p > 0.f)) {
         const int k = tk0 + c4 * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float sc = pr.scale ? pr.scale[k + j] : 1.f, sh = pr.scale ? pr.shift[k + j] : 0.f;
-          v[j] = mmg_pro_apply(pr, v[j], sc, sh, gr, k + j, K);
-        }
+        f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+        if (pr.scale) { s4 = *reinterpret_cast<const f32x4*>(pr.scale + k); sh4 = *reinterpret_cast<const f32x4*>(pr.shift + k); }
+        mmg_pro_apply4(pr, v, s4, sh4, gr, k, K);
       }
       *reinterpret_cast<f32x4*>(&Xs[r][c4 * 4]) = v;
     }
@@ -541,11 +535,9 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
       const int64_t gr = r0 + r;
       if (gr < r_end && has_pro) {
         const int k = tk0 + c4 * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float sc = pr.scale ? pr.scale[k + j] : 1.f, sh = pr.scale ? pr.shift[k + j] : 0.f;
-          v[j] = mmg_pro_apply(pr, v[j], sc, sh, gr, k + j, K);
-        }
+        f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+        if (pr.scale) { s4 = *reinterpret_cast<const f32x4*>(pr.scale + k); sh4 = *reinterpret_cast<const f32x4*>(pr.shift + k); }
+        mmg_pro_apply4(pr, v, s4, sh4, gr, k, K);
       }
       if (gr >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
       split_store(v, xb, WG_ROWS * SX, r * SX + c4 * 4);

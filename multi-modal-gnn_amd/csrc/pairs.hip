@@ -332,13 +332,19 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
     }
     // ---- (b) h1[pair=l31][k=32h+s]: gather-add, relu, dropout; kept in registers AND written to LDS
     float h1a[32];
+    uint32_t km1[8];                                 // keep bits of the 8 aligned groups of 4 (one hash each)
+    if (drop_p > 0.f) {
+      const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) km1[q] = mmg_keep4(key1, pid * 64ull + (uint64_t)(32 * h + q * 4), thr1);
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = fmaxf(ca[q][j] + cb[q][j], 0.f);
-        if (drop_p > 0.f) x = mmg_keep(seed, SITE_H1, pid * 64ull + (32 * h + q * 4 + j), drop_p) ? x * inv_keep : 0.f;
+        if (drop_p > 0.f) x = (km1[q] >> j) & 1u ? x * inv_keep : 0.f;
         v[j] = x;
         h1a[q * 4 + j] = x;
       }
@@ -556,12 +562,18 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    uint32_t km1[8];                                 // keep bits of the 8 aligned groups of 4 (one hash each)
+    if (drop_p > 0.f) {
+      const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) km1[q] = mmg_keep4(key1, mc.pid * 64ull + (uint64_t)(32 * h + q * 4), thr1);
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float x = fmaxf(ca[q][j] + cb[q][j], 0.f);
-        if (drop_p > 0.f) x = mmg_keep(seed, SITE_H1, mc.pid * 64ull + (32 * h + q * 4 + j), drop_p) ? x * inv_keep : 0.f;
+        if (drop_p > 0.f) x = (km1[q] >> j) & 1u ? x * inv_keep : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, w2b[q * 4 + j], acc, 0, 0, 0);
       }
     // C layout: lane = unit u (l31), reg r = pair row crow(r,h).  v[r] = W3[u] * dropout(relu(pre))
