@@ -215,6 +215,21 @@ def main():
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             w["model"]._seed_dev = None
             gstep = None
+    elif world > 1 and not args.no_graph:
+        # sharded: a chain of hipGraph segments with the all-reduces between them (nothing RCCL-specific is captured)
+        ok = torch.ones(1, device=dev)
+        try:
+            from mmgnn.train import PiecewiseGraphedTrainStep
+            gstep = PiecewiseGraphedTrainStep(w["model"], w["plan"], w["pi"], w["li"], w["y"], w["wlab"], w["opt"], w["sup"],
+                                              w["comm"], n_sup_global=w["n_sup"], warmup=1)
+        except Exception as e:
+            print(f"[bench] rank {rank}: piecewise capture unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+            ok.zero_()
+            gstep = None
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)     # all ranks or none
+        if float(ok) == 0.0:
+            w["model"]._seed_dev = None
+            gstep = None
     step_fn = (lambda: gstep.step()) if gstep is not None else (lambda: train_step(w))
     for _ in range(max(args.warmup, 1)):
         step_fn()
@@ -298,7 +313,9 @@ def main():
                        "patients_per_gpu": P_loc, "has_lab_edges_total": int(total_edges),
                        "train_pairs_rank0": int(w["pi"].numel()), "hidden_dim": args.dim,
                        "parallelism": f"patient-shard x{world}" if world > 1 else "single GPU",
-                       "launch": "hipGraph replay" if gstep is not None else "eager"},
+                       "launch": ("eager" if gstep is None else "hipGraph replay" if world == 1 else
+                                  f"{sum(1 for k, _ in gstep.items if k == 'graph')} hipGraph segments + "
+                                  f"{sum(1 for k, _ in gstep.items if k == 'all_reduce')} all-reduces per step")},
             "roofline": roof,
             "loss": loss_value,
         }

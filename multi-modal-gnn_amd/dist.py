@@ -35,9 +35,17 @@ class ShardComm:
         self.pair_ids = pair_ids          # global pair ids of this rank's pairs (keys the head dropout RNG)
         self.n_calls = 0
         self.n_bytes = 0
+        self.on_collective = None         # set while a step is being captured piecewise (train.PiecewiseGraphedTrainStep)
+
+    def raw_all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
 
     def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self.on_collective is not None:
+            self.on_collective(t)         # ends the current graph segment, runs the collective eagerly, starts the next
+        else:
+            self.raw_all_reduce(t)
         self.n_calls += 1
         self.n_bytes += t.numel() * t.element_size()
         return t

@@ -289,3 +289,105 @@ class GraphedTrainStep:
         self.model._seed_dev.random_(0, 2 ** 62)     # fresh dropout masks for this replay
         self.graph.replay()
         return self.loss
+
+
+class PiecewiseGraphedTrainStep:
+    """The sharded training step as a CHAIN of hipGraphs with the RCCL all-reduces between them.
+
+    A patient-sharded step has ~14 tiny all-reduces (Sync-BN statistics, vocab-side partial sums, the gradient bucket;
+    dist.py) between its ~330 kernel launches.  Collectives are not captured: every ``ShardComm.all_reduce`` met while
+    the step is recorded closes the current graph segment, runs eagerly, and opens the next segment, so a replay is
+    ``segment, all_reduce, segment, ...`` -- ~15 graph launches and ~14 collectives of host work instead of one Python
+    dispatch per kernel, and nothing that a stock RCCL cannot do.  All segments share one memory pool (static
+    addresses), are recorded on one thread -- forward, loss and backward are driven by hand (``_Run.run_forward`` /
+    ``run_backward``), not through the autograd engine -- and replay in recording order.
+    """
+
+    def __init__(self, model, plan, pi, li, y, lab_weights, optimizer, sup_mask, comm, loss_fn: str = "mae",
+                 n_sup_global: Optional[float] = None, warmup: int = 2):
+        from . import ops
+        from .model import _Run
+        if loss_fn not in ("mae", "mse"):
+            raise ValueError(f"PiecewiseGraphedTrainStep supports 'mae'/'mse', got {loss_fn}")
+        self.model, self.plan, self.opt, self.comm = model, plan, optimizer, comm
+        self.pi, self.li, self.y = pi, li, y
+        self.wl = lab_weights[li].contiguous()
+        self.sup = sup_mask.to(torch.float32).contiguous()
+        self.inv_den = 1.0 / (float(n_sup_global) if n_sup_global is not None else max(float(self.sup.sum()), 1.0))
+        self.loss_fn = loss_fn
+        self._ops, self._Run = ops, _Run
+        dev = pi.device
+        model._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.loss = torch.zeros((), device=dev)
+        self.params = [p for p in model.parameters()]
+        model.train()
+        self.items = []
+        self._cur = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._body()
+            torch.cuda.synchronize()
+            self._pool = torch.cuda.graph_pool_handle()
+            self._begin()
+            if comm is not None:
+                comm.on_collective = self._collective
+            try:
+                self._body()
+            finally:
+                if comm is not None:
+                    comm.on_collective = None
+                self._end()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+    # ---- recording
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self._pool)
+        self._cur = g
+
+    def _end(self):
+        self._cur.capture_end()
+        self.items.append(("graph", self._cur))
+        self._cur = None
+
+    def _collective(self, t):
+        self._end()
+        self.comm.raw_all_reduce(t)
+        self.items.append(("all_reduce", t))
+        self._begin()
+
+    def _body(self):
+        ops, model = self._ops, self.model
+        with torch.no_grad():
+            for p in self.params:
+                p.grad = None
+            run = self._Run(model, self.plan)
+            run.pairs = model._pairs(self.pi, self.li, self.plan.n_rows,
+                                     getattr(self.comm, "pair_ids", None) if self.comm else None,
+                                     self.plan.lab_deg, int(model.degree_threshold))
+            run.n_pairs = self.pi.numel()
+            run.need_grad = True
+            (pred,) = run.run_forward("predict")
+            loss, dpred = ops.pair_loss(pred, self.y, self.wl, self.sup, self.inv_den, self.loss_fn)
+            grads = run.run_backward((dpred,))
+            for p, g in zip(self.params, grads):
+                if g is not None:
+                    p.grad = g
+            self.opt.step()
+            self.loss.copy_(loss.float())
+
+    # ---- replay
+    def set_mask(self, sup_mask):
+        self.sup.copy_(sup_mask.to(torch.float32))
+
+    def step(self) -> torch.Tensor:
+        self.model._seed_dev.random_(0, 2 ** 62)
+        for kind, x in self.items:
+            if kind == "graph":
+                x.replay()
+            else:
+                self.comm.raw_all_reduce(x)
+        return self.loss
