@@ -195,8 +195,8 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
   constexpr int NP = BM / ROWS_PER_PASS;    // 16-B loads per thread per tile
   const int prow = tid / K4;
   const int64_t n_tiles = (M + BM - 1) / BM;
-  f32x4 nx[NP];
-  auto fetch = [&](int64_t tile) {
+  f32x4 nxa[NP], nxb[NP];                   // two tiles of X in flight (64 KB per CU): tiles alternate between them
+  auto fetch = [&](int64_t tile, f32x4* nx) {
     const int64_t row0 = tile * BM;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
       nx[p] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + kc4 * 4);
     }
   };
-  auto stage = [&](int64_t tile, int buf) {  // prologue + split + three plane writes
+  auto stage = [&](int64_t tile, int buf, const f32x4* nx) {  // prologue + split + three plane writes
     const int64_t row0 = tile * BM;
     __bf16* pb = planes + (size_t)buf * 3 * BM * LDP;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -235,18 +235,20 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
       *reinterpret_cast<xbf16x4*>(pb + (2 * BM + r) * LDP + kc4 * 4) = q2;
     }
   };
+  const int64_t G = gridDim.y;
   int64_t t = blockIdx.y;
   if (t >= n_tiles) return;
-  fetch(t);
-  stage(t, 0);
-  if (t + gridDim.y < n_tiles) fetch(t + gridDim.y);
+  fetch(t, nxa);
+  stage(t, 0, nxa);
+  fetch(t + G < n_tiles ? t + G : t, nxa);          // tile t+G  (clamped re-reads past the end are never staged)
+  fetch(t + 2 * G < n_tiles ? t + 2 * G : t, nxb);  // tile t+2G
   __syncthreads();
-  int buf = 0;
-  for (; t < n_tiles; t += gridDim.y) {
-    const int64_t tn = t + gridDim.y;
+  auto tile_body = [&](int64_t tt, int buf, f32x4* nx) {
+    // nx holds tile tt+G (fetched two tiles ago); after staging it, the registers take tile tt+3G
+    const int64_t tn = tt + G;
     if (tn < n_tiles) {
-      stage(tn, buf ^ 1);                    // the other buffer: its readers passed the barrier of the last tile
-      if (tn + gridDim.y < n_tiles) fetch(tn + gridDim.y);
+      stage(tn, buf ^ 1, nx);                // the other buffer: its readers passed the barrier of the last tile
+      fetch(tn + 2 * G < n_tiles ? tn + 2 * G : tn, nx);
     }
     f32x16 acc;
 #pragma unroll
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][0], acc, 0, 0, 0);
     }
-    const int64_t row0 = t * BM;
+    const int64_t row0 = tt * BM;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int64_t gr = row0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -276,7 +278,10 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
       }
     }
     __syncthreads();                         // buf fully read, buf^1 fully written
-    buf ^= 1;
+  };
+  for (; t < n_tiles; t += 2 * G) {
+    tile_body(t, 0, nxa);
+    if (t + G < n_tiles) tile_body(t + G, 1, nxb);
   }
 }
 
