@@ -157,13 +157,15 @@ int mmg_affine_act_drop(const float* Y, const mmg_prologue_t* pro, float* out, i
  *   g_out = g * keepmask/(1-p) * [y*scale+shift > 0]
  * pass 1 (stats):  sums[0,:] = sum g_out ; sums[1,:] = sum g_out * xhat,  xhat = (y-mean)*rstd
  * pass 2 (apply):  dy = scale * (g_out - c0[k] - xhat*c1[k]),  c0 = sums0/count, c1 = sums1/count
- *                  (eval mode: c0 = c1 = 0) */
+ *                  (eval mode: sums = NULL, c0 = c1 = 0).  `sums` is the (all-reduced, when sharded) output of pass 1
+ *                  and inv_count = 1/count; dbeta / dgamma (nullable, [N] float) receive sums0 / sums1, the gradients
+ *                  of the BatchNorm bias / weight. */
 int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
                      const float* rstd, double* sums, int64_t M, int N, void* ws, size_t ws_bytes,
                      void* stream);
 int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
-                     const float* rstd, const float* c0, const float* c1, float* dY, int64_t M, int N,
-                     void* stream);
+                     const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
+                     float* dY, int64_t M, int N, void* stream);
 
 /* Row L2 normalisation, F.normalize(p=2, dim=1, eps): out = z / max(||z||, eps); rnorm = 1/max(..) */
 int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, float eps, void* stream);
@@ -216,6 +218,9 @@ typedef struct {
  * pair_id (nullable) = original position of each pair, used only to key the dropout RNG so that
  * a permuted (patient-sorted) pair list draws the same masks.  seed_ptr (nullable, device): overrides
  * `seed` at run time (hipGraph replays).
+ * io_perm (nullable, device): the kernels work on a patient-SORTED pair list; io_perm[k] is the position of sorted
+ * pair k in the caller's order -- pred is written to pred[io_perm[k]] and dpred read from dpred[io_perm[k]], so no
+ * separate permutation pass over the predictions / their gradient is needed.
  * sel / n_sel (both nullable, device): a compacted list of pair positions built by mmg_pair_select -- only
  * sel[0 .. *n_sel) are visited (in list order) and `n_pairs` is then an upper bound of *n_sel that sizes the
  * launch.  Forward: the per-head lists (static per pair set) replace the predicated sweep over all pairs.
@@ -224,19 +229,20 @@ typedef struct {
 int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li,
                       const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs,
                       float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
-                      float* pred, const int32_t* sel, const int32_t* n_sel, void* stream);
+                      float* pred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream);
 int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,
                       const int32_t* pi, const int32_t* li, const int32_t* deg, int degree_threshold,
                       int want_low, int64_t n_pairs, int n_labs, float drop_p, uint64_t seed,
                       const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred,
-                      const int32_t* sel, const int32_t* n_sel, void* stream);
+                      const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream);
 
 /* Stable two-way compaction of pair positions by head: position k goes to sel_low if deg[pi[k]] < threshold,
  * else to sel_high -- and only if dpred is NULL or dpred[k] != 0.  Order inside a list = pair order (pairs sorted
  * by patient stay sorted).  counts[0], counts[1] (device) = list lengths.  sel_low / sel_high: capacity n each. */
 size_t mmg_pair_select_ws_bytes(int64_t n_pairs);
-int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold, const float* dpred, int64_t n_pairs,
-                    int32_t* sel_low, int32_t* sel_high, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold, const float* dpred,
+                    const int64_t* io_perm, int64_t n_pairs, int32_t* sel_low, int32_t* sel_high, int32_t* counts,
+                    void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

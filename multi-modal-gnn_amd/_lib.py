@@ -66,18 +66,18 @@ SIGNATURES = {
                                   _i32, _vp]),
     "mmg_affine_act_drop": (C.c_int, [_vp, _P(PrologueT), _vp, _i64, _i32, _vp]),
     "mmg_bn_bwd_stats": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
-    "mmg_bn_bwd_apply": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "mmg_bn_bwd_apply": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _i64, _i32, _vp]),
     "mmg_l2norm_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmg_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmg_pair_loss_ws_bytes": (_sz, [_i64]),
     "mmg_pair_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_double, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmg_dropout_mask": (C.c_int, [_u64, _vp, _u32, _i64, _i64, _f32, _vp, _vp]),
     "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _f32, _u64, _vp, _vp, _vp, _vp, _vp,
-                                    _vp]),
+                                    _vp, _vp]),
     "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64,
-                                    _vp, _vp, _vp, _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmg_pair_select_ws_bytes": (_sz, [_i64]),
-    "mmg_pair_select": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmg_pair_select": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

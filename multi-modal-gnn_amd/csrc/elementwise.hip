@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void k_affine_act_drop(const float* __restrict
 
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ Y, ProDev pr,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      const float* __restrict__ c0, const float* __restrict__ c1,
+                                                      const double* __restrict__ sums, double inv_count,
+                                                      float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                       float* __restrict__ dY, int64_t M, int N) {
   pr.resolve();
   const int64_t n4 = M * (int64_t)(N / 4);
@@ -175,8 +176,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   if (pr.scale) {
     sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c);
     mu = *reinterpret_cast<const f32x4*>(mean + c); rs = *reinterpret_cast<const f32x4*>(rstd + c);
-    if (c0) a0 = *reinterpret_cast<const f32x4*>(c0 + c);
-    if (c1) a1 = *reinterpret_cast<const f32x4*>(c1 + c);
+    if (sums) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] = (float)(sums[c + j] * inv_count);
+        a1[j] = (float)(sums[N + c + j] * inv_count);
+      }
+    }
+  }
+  if (sums && blockIdx.x == 0 && threadIdx.x < N / 4) {       // d beta / d gamma ride along (one thread per 4 columns)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (dbeta) dbeta[c + j] = (float)sums[c + j];
+      if (dgamma) dgamma[c + j] = (float)sums[N + c + j];
+    }
   }
   for (; i < n4; i += stride) {
     const int64_t r = i / (N / 4);
@@ -357,14 +370,14 @@ extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prolog
 }
 
 extern "C" int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
-                                const float* rstd, const float* c0, const float* c1, float* dY, int64_t M, int N,
-                                void* stream) {
+                                const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
+                                float* dY, int64_t M, int N, void* stream) {
   MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0 && 256 % (N / 4) == 0, "bn_bwd_apply: N=%d must be 4*2^k <= 1024", N);
   if (M == 0) return MMG_OK;
   MMG_CHECK_ARG(G && Y && dY, "bn_bwd_apply: null buffer");
   MMG_CHECK_ARG(!pro || !pro->scale || (mean && rstd), "bn_bwd_apply: affine prologue needs mean/rstd");
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, G, Y, mmg_pro_dev(pro),
-                     mean, rstd, c0, c1, dY, M, N);
+                     mean, rstd, sums, inv_count, dbeta, dgamma, dY, M, N);
   MMG_CHECK_LAUNCH("bn_bwd_apply");
   return MMG_OK;
 }

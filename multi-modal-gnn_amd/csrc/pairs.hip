@@ -76,7 +76,7 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
                                                  uint64_t seed, const uint64_t* __restrict__ seed_ptr,
                                                  const int64_t* __restrict__ pair_id,
                                                  const float* __restrict__ dpred, const int32_t* __restrict__ sel,
-                                                 const int32_t* __restrict__ n_sel) {
+                                                 const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) n = *n_sel;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
     const bool active = p_i >= 0;
     // inactive lanes run the same code on row 0 with dout = 0: every contribution is then zero
     const uint64_t pid = active ? (pair_id ? (uint64_t)pair_id[k] : (uint64_t)k) : 0ull;
-    const float dout = active ? dpred[k] : 0.f;
+    const float dout = active ? dpred[io ? io[k] : k] : 0.f;
     float h1[64], dh1[64];
     head_layer1(H, active ? p_i : 0, l_i, pid, drop_p, inv_keep, seed, h1);
 #pragma unroll
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
                                                        uint64_t seed, const uint64_t* __restrict__ seed_ptr,
                                                        const int64_t* __restrict__ pair_id,
                                                        const float* __restrict__ dpred, const int32_t* __restrict__ sel,
-                                                       const int32_t* __restrict__ n_sel) {
+                                                       const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) n = *n_sel;                   // compacted pair list (device-resident length): see mmg_pair_select
   __shared__ __attribute__((aligned(16))) float sm[4 * WAVE_LDS];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
       const int pp = pi[k];
       if (((int)(deg[pp] < thr)) == want_low) {
         m.p_i = pp; m.l_i = li[k];
-        m.dout = dpred[k];
+        m.dout = dpred[io ? io[k] : k];
         m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
       }
     }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
                                                           const uint64_t* __restrict__ seed_ptr,
                                                           const int64_t* __restrict__ pair_id, float* __restrict__ pred,
                                                           const int32_t* __restrict__ sel,
-                                                          const int32_t* __restrict__ n_sel) {
+                                                          const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) n = *n_sel;
   __shared__ unsigned PL[4][TP], PH[4][TP];
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
     const int row = crow(r, h);
     const int owner = __shfl(mc.p_i, row, 64);          // lane `row` (half 0) holds that pair's metadata
     const int ok = __shfl(mc.k, row, 64);
-    if ((l31 & 1) == 0 && owner >= 0) pred[ok] = w1 + b3;
+    if ((l31 & 1) == 0 && owner >= 0) pred[io ? io[ok] : ok] = w1 + b3;
   }
 }
 
@@ -622,12 +622,13 @@ constexpr int SEL_PER = 8, SEL_CH = 256 * SEL_PER;      // pairs per thread / pe
 
 // packed per-thread counts: low list in bits 0..15, high list in bits 16..31 (a chunk holds 2048 pairs)
 __device__ inline unsigned sel_flags(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg, int thr,
-                                     const float* __restrict__ dpred, int64_t n, int64_t k0, unsigned* bits) {
+                                     const float* __restrict__ dpred, const int64_t* __restrict__ io, int64_t n,
+                                     int64_t k0, unsigned* bits) {
   unsigned cnt = 0, lowbits = 0, anybits = 0;
 #pragma unroll
   for (int j = 0; j < SEL_PER; ++j) {
     const int64_t k = k0 + j;
-    if (k < n && (!dpred || dpred[k] != 0.f)) {
+    if (k < n && (!dpred || dpred[io ? io[k] : k] != 0.f)) {
       const bool low = deg[pi[k]] < thr;
       anybits |= 1u << j;
       if (low) { lowbits |= 1u << j; cnt += 1u; } else cnt += 1u << 16;
@@ -655,11 +656,12 @@ __device__ inline unsigned block_excl_scan(unsigned v, unsigned* total, unsigned
 }
 
 __global__ __launch_bounds__(256) void k_sel_count(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg,
-                                                   int thr, const float* __restrict__ dpred, int64_t n,
+                                                   int thr, const float* __restrict__ dpred,
+                                                   const int64_t* __restrict__ io, int64_t n,
                                                    unsigned* __restrict__ cnt) {
   __shared__ unsigned sm[4];
   unsigned bits, tot;
-  const unsigned c = sel_flags(pi, deg, thr, dpred, n, (int64_t)blockIdx.x * SEL_CH + threadIdx.x * SEL_PER, &bits);
+  const unsigned c = sel_flags(pi, deg, thr, dpred, io, n, (int64_t)blockIdx.x * SEL_CH + threadIdx.x * SEL_PER, &bits);
   block_excl_scan(c, &tot, sm);
   if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
 }
@@ -698,13 +700,14 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const unsigned* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_sel_write(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg,
-                                                   int thr, const float* __restrict__ dpred, int64_t n,
+                                                   int thr, const float* __restrict__ dpred,
+                                                   const int64_t* __restrict__ io, int64_t n,
                                                    const int2* __restrict__ base, int32_t* __restrict__ sel_low,
                                                    int32_t* __restrict__ sel_high) {
   __shared__ unsigned sm[4];
   unsigned bits, tot;
   const int64_t k0 = (int64_t)blockIdx.x * SEL_CH + threadIdx.x * SEL_PER;
-  const unsigned c = sel_flags(pi, deg, thr, dpred, n, k0, &bits);
+  const unsigned c = sel_flags(pi, deg, thr, dpred, io, n, k0, &bits);
   const unsigned off = block_excl_scan(c, &tot, sm);
   const int2 b = base[blockIdx.x];
   int ol = b.x + (int)(off & 0xFFFFu), oh = b.y + (int)(off >> 16);
@@ -734,7 +737,7 @@ int check_head(const mmg_head_t* h, const char* what) {
 extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
                                  int degree_threshold, int want_low, int64_t n_pairs, float drop_p, uint64_t seed,
                                  const uint64_t* seed_ptr, const int64_t* pair_id, float* pred, const int32_t* sel,
-                                 const int32_t* n_sel, void* stream) {
+                                 const int32_t* n_sel, const int64_t* io_perm, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0, "pair_head_fwd: n_pairs < 0");
   MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_fwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
@@ -747,7 +750,7 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   hipLaunchKernelGGL(k_pair_fwd_mfma, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, H, pi, li, deg,
-                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel);
+                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel, io_perm);
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;
 }
@@ -755,7 +758,8 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
 extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi, const int32_t* li,
                                  const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
                                  float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
-                                 const float* dpred, const int32_t* sel, const int32_t* n_sel, void* stream) {
+                                 const float* dpred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
+                                 void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0 && n_labs >= 0, "pair_head_bwd: negative size");
   MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_bwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
@@ -775,7 +779,7 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     if (g < 1) g = 1;
 #define MMG_LAUNCH_PBWD(LT_)                                                                                          \
   hipLaunchKernelGGL((k_pair_bwd_mfma<LT_>), dim3((unsigned)g), dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, \
-                     want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel)
+                     want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel, io_perm)
     if (n_labs <= 64) MMG_LAUNCH_PBWD(2);
     else MMG_LAUNCH_PBWD(4);
 #undef MMG_LAUNCH_PBWD
@@ -791,7 +795,7 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     int64_t g = (n_pairs + PT - 1) / PT;
     if (g > 512) g = 512;
     hipLaunchKernelGGL(k_pair_bwd, dim3((unsigned)g), dim3(PT), lds, st, H, G, pi, li, deg, degree_threshold,
-                       want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel);
+                       want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel, io_perm);
   }
   MMG_CHECK_LAUNCH("pair_head_bwd");
   return MMG_OK;
@@ -803,8 +807,8 @@ extern "C" size_t mmg_pair_select_ws_bytes(int64_t n_pairs) {
 }
 
 extern "C" int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold, const float* dpred,
-                               int64_t n_pairs, int32_t* sel_low, int32_t* sel_high, int32_t* counts, void* ws,
-                               size_t ws_bytes, void* stream) {
+                               const int64_t* io_perm, int64_t n_pairs, int32_t* sel_low, int32_t* sel_high,
+                               int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0 && n_pairs < (int64_t)INT32_MAX, "pair_select: n_pairs out of range");
   MMG_CHECK_ARG(counts, "pair_select: counts is null");
   hipStream_t st = (hipStream_t)stream;
@@ -820,10 +824,10 @@ extern "C" int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree
   const int nb = (int)((n_pairs + SEL_CH - 1) / SEL_CH);
   int2* base = reinterpret_cast<int2*>(ws);                                  // 8-byte aligned: first in the workspace
   unsigned* cnt = reinterpret_cast<unsigned*>(base + nb);
-  hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, n_pairs, cnt);
+  hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, io_perm, n_pairs, cnt);
   hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, cnt, nb, base, counts);
-  hipLaunchKernelGGL(k_sel_write, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, n_pairs, base, sel_low,
-                     sel_high);
+  hipLaunchKernelGGL(k_sel_write, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, io_perm, n_pairs, base,
+                     sel_low, sel_high);
   MMG_CHECK_LAUNCH("pair_select");
   return MMG_OK;
 }

@@ -421,16 +421,20 @@ class _Run:
     def bn_bwd(self, g, y, pro: Pro, fold: Optional[ops.BNFold], bn_prefix: Optional[str], sharded: bool):
         """grad wrt the pre-BN tensor y of  x' = dropout(relu(BN(y)));  accumulates d gamma / d beta."""
         if fold is None:        # no batch norm: relu/dropout only
-            return ops.bn_bwd_apply(g, y, pro, None, None, None)
+            return ops.bn_bwd_apply(g, y, pro, None)
         sums = ops.bn_bwd_stats(g, y, pro, fold)
         if sharded and self.comm is not None:
             self.allreduce(sums)
-        self.acc(bn_prefix + ".bias", sums[0].float())
-        self.acc(bn_prefix + ".weight", sums[1].float())
+        N = y.shape[1]
+        dbg = torch.empty(2, N, device=y.device)       # d beta | d gamma, written by the apply kernel
         if fold.training:
-            c = (sums / float(fold.count)).float()
-            return ops.bn_bwd_apply(g, y, pro, fold, c[0].contiguous(), c[1].contiguous())
-        return ops.bn_bwd_apply(g, y, pro, fold, None, None)
+            dy = ops.bn_bwd_apply(g, y, pro, fold, sums, fold.count, dbg[0], dbg[1])
+        else:
+            dbg.copy_(sums)
+            dy = ops.bn_bwd_apply(g, y, pro, fold)
+        self.acc(bn_prefix + ".bias", dbg[0])
+        self.acc(bn_prefix + ".weight", dbg[1])
+        return dy
 
     def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False):
         """grads of  y = pro(x) W^T + b."""
@@ -612,35 +616,33 @@ class _Run:
             raise KeyError(f"graph has no {LAB_EDGE} relation (model.py:297)")
         pi, li, perm, ids, (sel_low, sel_high, counts, n_low, n_high) = self.pairs
         thr = int(self.m.degree_threshold)
-        pred_s = torch.empty(pi.numel(), device=self.dev)        # every pair belongs to exactly one head list
+        pred = torch.empty(pi.numel(), device=self.dev)          # every pair belongs to exactly one head list
         rec = dict(init=init, fin=fin)
         for which, src, want_low in (("edge_predictor", fin, False), ("tabular_mlp", init, True)):
             head, w1a, w1b = self.head_tensors(which, src[ROW_TYPE], src["lab"])
             sel, n_sel, nb = (sel_low, counts[0:1], n_low) if want_low else (sel_high, counts[1:2], n_high)
-            ops.pair_head_fwd(head, pi, li, plan.lab_deg, thr, want_low, self.p, self.seed, ids, pred_s, self.seed_dev,
-                              sel=sel, n_sel=n_sel, n_bound=nb)
+            ops.pair_head_fwd(head, pi, li, plan.lab_deg, thr, want_low, self.p, self.seed, ids, pred, self.seed_dev,
+                              sel=sel, n_sel=n_sel, n_bound=nb, io_perm=perm)      # written in the caller's pair order
             rec[which] = (head, w1a, w1b)
-        pred = torch.empty_like(pred_s)
-        pred[perm] = pred_s                      # back to the caller's pair order
         return pred, rec
 
     def heads_bwd(self, rec, dpred):
         plan, D = self.plan, self.D
         pi, li, perm, ids, (_, _, _, n_low, n_high) = self.pairs
         thr = int(self.m.degree_threshold)
-        dps = dpred[perm].contiguous()
+        dps = dpred.contiguous()                 # caller's pair order: the kernels read it through perm
         n_lab = plan.num_nodes["lab"]
         gsets = {}
         # pairs with a zero upstream gradient (everything outside the supervision subset, train.py:366-370) add
         # exactly nothing: visit only the others, split by head
-        bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps)
+        bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps, io_perm=perm)
         for which, src, want_low in (("edge_predictor", rec["fin"], False), ("tabular_mlp", rec["init"], True)):
             head, w1a, w1b = rec[which]
             g = ops.Head(torch.zeros_like(head.A), torch.zeros_like(head.B), torch.zeros_like(head.W2),
                          torch.zeros_like(head.b2), torch.zeros_like(head.W3), torch.zeros_like(head.b3))
             sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
             ops.pair_head_bwd(head, g, pi, li, plan.lab_deg, thr, want_low, n_lab, self.p, self.seed, ids, dps,
-                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb)
+                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb, io_perm=perm)
             self.allreduce(g.B)                  # lab-side partials from sharded pairs
             self.acc(f"{which}.mlp.3.weight", g.W2, partial=True)
             self.acc(f"{which}.mlp.3.bias", g.b2, partial=True)

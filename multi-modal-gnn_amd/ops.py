@@ -351,14 +351,16 @@ def bn_bwd_stats(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold):
     return out
 
 
-def bn_bwd_apply(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFold], c0, c1,
-                 out: Optional[torch.Tensor] = None):
+def bn_bwd_apply(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFold], sums=None, count: float = 1.0,
+                 dbeta=None, dgamma=None, out: Optional[torch.Tensor] = None):
+    """sums: the fp64 [2,N] output of bn_bwd_stats (None in eval mode); dbeta / dgamma ([N] float) receive its rows."""
     lib = _lib.load()
     M, N = y.shape
     out = torch.empty_like(y) if out is None else out
     _tok = _pb("bn_bwd_apply")
     check(lib.mmg_bn_bwd_apply(_p(g), _p(y), _pro(pro), _p(fold.mean) if fold else None,
-                               _p(fold.rstd) if fold else None, _p(c0), _p(c1), _p(out), M, N, _stream()),
+                               _p(fold.rstd) if fold else None, _p(sums, torch.float64), 1.0 / float(count),
+                               _p(dbeta), _p(dgamma), _p(out), M, N, _stream()),
           "mmg_bn_bwd_apply")
     _pe(_tok, "bn_bwd_apply", 12 * M * N, 0)
     return out
@@ -409,9 +411,9 @@ class Head:
         return HeadT(_p(self.A), _p(self.B), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3))
 
 
-def pair_select(pi, deg, thr: int, dpred=None):
+def pair_select(pi, deg, thr: int, dpred=None, io_perm=None):
     """Stable compaction of pair positions by head (mmg_pair_select) -> (sel_low, sel_high, counts[2] on device).
-    With `dpred`, positions whose upstream gradient is exactly 0 are dropped."""
+    With `dpred`, positions whose upstream gradient is exactly 0 are dropped (dpred is read through io_perm)."""
     lib = _lib.load()
     n = pi.numel()
     sel_low = torch.empty(max(n, 1), dtype=torch.int32, device=pi.device)
@@ -419,7 +421,8 @@ def pair_select(pi, deg, thr: int, dpred=None):
     counts = torch.empty(2, dtype=torch.int32, device=pi.device)
     ws = workspace(lib.mmg_pair_select_ws_bytes(n), pi.device)
     _tok = _pb("pair_select")
-    check(lib.mmg_pair_select(_p(pi, torch.int32), _p(deg, torch.int32), thr, _p(dpred), n, _p(sel_low, torch.int32),
+    check(lib.mmg_pair_select(_p(pi, torch.int32), _p(deg, torch.int32), thr, _p(dpred), _p(io_perm, torch.int64), n,
+                              _p(sel_low, torch.int32),
                               _p(sel_high, torch.int32), _p(counts, torch.int32), _p(ws, torch.uint8), ws.numel(),
                               _stream()), "mmg_pair_select")
     _pe(_tok, "pair_select", n * 24)
@@ -427,8 +430,9 @@ def pair_select(pi, deg, thr: int, dpred=None):
 
 
 def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred, seed_dev=None,
-                  sel=None, n_sel=None, n_bound: Optional[int] = None):
-    """sel / n_sel: compacted positions (pair_select) and their device-resident count; n_bound >= that count."""
+                  sel=None, n_sel=None, n_bound: Optional[int] = None, io_perm=None):
+    """sel / n_sel: compacted positions (pair_select) and their device-resident count; n_bound >= that count.
+    io_perm: pred is written to pred[io_perm[k]] (the caller's pair order)."""
     lib = _lib.load()
     n = pi.numel() if sel is None else int(n_bound)
     if n == 0:
@@ -438,12 +442,12 @@ def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, s
     check(lib.mmg_pair_head_fwd(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
                                 int(want_low), n, float(p), seed & 0xFFFFFFFFFFFFFFFF, _p(seed_dev, torch.int64),
                                 _p(pair_id, torch.int64), _p(pred), _p(sel, torch.int32), _p(n_sel, torch.int32),
-                                _stream()), "mmg_pair_head_fwd")
+                                _p(io_perm, torch.int64), _stream()), "mmg_pair_head_fwd")
     _pe(_tok, "pair_head_fwd", n * 12 + 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (64 * 32 + 32 + 64))
 
 
 def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool, n_labs: int, p: float, seed: int,
-                  pair_id, dpred, seed_dev=None, sel=None, n_sel=None, n_bound: Optional[int] = None):
+                  pair_id, dpred, seed_dev=None, sel=None, n_sel=None, n_bound: Optional[int] = None, io_perm=None):
     """`grads` mirrors `head` (dA,dB,dW2,db2,dW3,db3), accumulated in place."""
     lib = _lib.load()
     n = pi.numel() if sel is None else int(n_bound)
@@ -455,7 +459,7 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
     check(lib.mmg_pair_head_bwd(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32),
                                 thr, int(want_low), n, n_labs, float(p), seed & 0xFFFFFFFFFFFFFFFF,
                                 _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _p(sel, torch.int32),
-                                _p(n_sel, torch.int32), _stream()),
+                                _p(n_sel, torch.int32), _p(io_perm, torch.int64), _stream()),
           "mmg_pair_head_bwd")
     _pe(_tok, "pair_head_bwd", n * 12 + 2 * 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (4 * 64 * 32))
 

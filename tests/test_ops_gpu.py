@@ -319,9 +319,10 @@ def test_bn_relu_dropout_backward(ops, dev, p):
     out.backward(g.double())
     sums = ops.bn_bwd_stats(g.to(dev), y.to(dev), pro, fold)
     assert rel(sums[0], bd.grad) <= 1e-6 and rel(sums[1], gd.grad) <= 1e-5
-    c = (sums / M).float()
-    dy = ops.bn_bwd_apply(g.to(dev), y.to(dev), pro, fold, c[0].contiguous(), c[1].contiguous())
+    dbg = torch.empty(2, N, device=dev)
+    dy = ops.bn_bwd_apply(g.to(dev), y.to(dev), pro, fold, sums, M, dbg[0], dbg[1])
     assert rel(dy, yd.grad) <= 2e-5
+    assert torch.equal(dbg.double(), sums.float().double())        # d beta / d gamma ride along
 
 
 @pytest.mark.parametrize("N", [64, 128, 256])

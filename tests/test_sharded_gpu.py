@@ -233,4 +233,5 @@ def test_piecewise_graph_chain_matches_eager_steps():
         # a bias in front of a BatchNorm has a zero gradient up to rounding noise, which Adam turns into +-lr steps
         feeds_bn = n in ("patient_transform.0.bias", "patient_transform.4.bias") or n.endswith("lin_l.bias")
         if not n.startswith("embeddings.") and not feeds_bn:
-            assert float((p1 - p2).abs().max()) <= 2e-4 * float(p1.abs().max()) + 1e-6, n
+            # (Adam normalises tiny gradients: atomics-order noise shows up at a few 1e-5; a structural error is O(lr))
+            assert float((p1 - p2).abs().max()) <= 1e-3 * float(p1.abs().max()) + 1e-5, n
