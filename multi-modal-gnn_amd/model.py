@@ -211,7 +211,14 @@ class HeteroRGCN(nn.Module):
         if deg is not None:
             sel_low, sel_high, counts = ops.pair_select(pi_sorted, deg, int(thr))
             n_low, n_high = counts.tolist()             # one-off sync per pair set (sizes the launches)
-            lists = (sel_low[:max(n_low, 1)].clone(), sel_high[:max(n_high, 1)].clone(), counts, n_low, n_high)
+            # the tabular head only ever sees the low-degree patients (~1.5 %): it works on their compacted rows
+            low_rows = torch.nonzero(deg < int(thr)).squeeze(1)
+            low_pos = torch.full((n_rows,), -1, dtype=torch.int32, device=pi.device)
+            low_pos[low_rows] = torch.arange(low_rows.numel(), dtype=torch.int32, device=pi.device)
+            pi_low = low_pos[pi_sorted.to(torch.int64)].contiguous() if n else pi_sorted
+            deg_low = torch.zeros(max(int(low_rows.numel()), 1), dtype=torch.int32, device=pi.device)
+            lists = (sel_low[:max(n_low, 1)].clone(), sel_high[:max(n_high, 1)].clone(), counts, n_low, n_high,
+                     low_rows, pi_low, deg_low)
         out = (pi_sorted, li_sorted, perm64, ids, lists)
         if len(self._pair_cache) >= 6:
             self._pair_cache.clear()
@@ -357,14 +364,25 @@ class _Run:
             dpred = gouts[0].contiguous()
             g_init, g_fin = self.heads_bwd(hrec, dpred)
             g = self.layers_bwd(layers, g_fin)
+            gi = g_init.get(ROW_TYPE)            # tabular head: (row ids, gradient rows) of the low-degree patients
+
+            def dense(rows_grads):
+                if rows_grads is None:
+                    return None
+                d = torch.zeros(self.plan.n_rows, D, device=self.dev)
+                d[rows_grads[0]] = rows_grads[1]
+                return d
+
             if enc0 is enc1:
                 gp = g.get(ROW_TYPE)
-                gi = g_init.get(ROW_TYPE)
-                tot = gp if gi is None else (gi if gp is None else gp.add_(gi))
+                if gp is None:
+                    tot = dense(gi)
+                else:
+                    tot = gp if gi is None else gp.index_add_(0, gi[0], gi[1])
                 self.enc_bwd(enc0, tot)
             else:
                 self.enc_bwd(enc1, g.get(ROW_TYPE))
-                self.enc_bwd(enc0, g_init.get(ROW_TYPE))
+                self.enc_bwd(enc0, dense(gi))
             for t, gt in g.items():
                 if t != ROW_TYPE and gt is not None:
                     self.acc(f"embeddings.{t}.weight", gt)
@@ -600,11 +618,12 @@ class _Run:
 
     # ======================================================================== heads
     def head_tensors(self, which, xP, xlab):
+        """xP: the patient rows this head can see (all of them, or the compacted low-degree rows)."""
         mod = getattr(self.m, which)
         D = self.D
         w1 = mod.mlp[0].weight.detach()
         w1a, w1b = w1[:, :D].contiguous(), w1[:, D:].contiguous()
-        A = ops.linear_fwd(xP, w1a)
+        A = ops.linear_fwd(xP, w1a) if xP.shape[0] else torch.zeros(1, w1a.shape[0], device=self.dev)
         B = ops.linear_fwd(xlab, w1b, mod.mlp[0].bias.detach())
         head = ops.Head(A, B, mod.mlp[3].weight.detach(), mod.mlp[3].bias.detach(),
                         mod.mlp[6].weight.detach().reshape(-1).contiguous(), mod.mlp[6].bias.detach())
@@ -614,21 +633,24 @@ class _Run:
         plan = self.plan
         if LAB_EDGE not in plan.rels:
             raise KeyError(f"graph has no {LAB_EDGE} relation (model.py:297)")
-        pi, li, perm, ids, (sel_low, sel_high, counts, n_low, n_high) = self.pairs
+        pi, li, perm, ids, (sel_low, sel_high, counts, n_low, n_high, low_rows, pi_low, deg_low) = self.pairs
         thr = int(self.m.degree_threshold)
         pred = torch.empty(pi.numel(), device=self.dev)          # every pair belongs to exactly one head list
         rec = dict(init=init, fin=fin)
         for which, src, want_low in (("edge_predictor", fin, False), ("tabular_mlp", init, True)):
-            head, w1a, w1b = self.head_tensors(which, src[ROW_TYPE], src["lab"])
+            # tabular_mlp: patient rows, ids and gate of the compacted low-degree patients (gate: all of them are low)
+            xP = src[ROW_TYPE].index_select(0, low_rows) if want_low else src[ROW_TYPE]
+            head, w1a, w1b = self.head_tensors(which, xP, src["lab"])
             sel, n_sel, nb = (sel_low, counts[0:1], n_low) if want_low else (sel_high, counts[1:2], n_high)
-            ops.pair_head_fwd(head, pi, li, plan.lab_deg, thr, want_low, self.p, self.seed, ids, pred, self.seed_dev,
+            ops.pair_head_fwd(head, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr, want_low,
+                              self.p, self.seed, ids, pred, self.seed_dev,
                               sel=sel, n_sel=n_sel, n_bound=nb, io_perm=perm)      # written in the caller's pair order
-            rec[which] = (head, w1a, w1b)
+            rec[which] = (head, w1a, w1b, xP)
         return pred, rec
 
     def heads_bwd(self, rec, dpred):
         plan, D = self.plan, self.D
-        pi, li, perm, ids, (_, _, _, n_low, n_high) = self.pairs
+        pi, li, perm, ids, (_, _, _, n_low, n_high, low_rows, pi_low, deg_low) = self.pairs
         thr = int(self.m.degree_threshold)
         dps = dpred.contiguous()                 # caller's pair order: the kernels read it through perm
         n_lab = plan.num_nodes["lab"]
@@ -637,26 +659,33 @@ class _Run:
         # exactly nothing: visit only the others, split by head
         bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps, io_perm=perm)
         for which, src, want_low in (("edge_predictor", rec["fin"], False), ("tabular_mlp", rec["init"], True)):
-            head, w1a, w1b = rec[which]
+            head, w1a, w1b, xP = rec[which]
             g = ops.Head(torch.zeros_like(head.A), torch.zeros_like(head.B), torch.zeros_like(head.W2),
                          torch.zeros_like(head.b2), torch.zeros_like(head.W3), torch.zeros_like(head.b3))
             sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
-            ops.pair_head_bwd(head, g, pi, li, plan.lab_deg, thr, want_low, n_lab, self.p, self.seed, ids, dps,
+            ops.pair_head_bwd(head, g, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr,
+                              want_low, n_lab, self.p, self.seed, ids, dps,
                               self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb, io_perm=perm)
             self.allreduce(g.B)                  # lab-side partials from sharded pairs
             self.acc(f"{which}.mlp.3.weight", g.W2, partial=True)
             self.acc(f"{which}.mlp.3.bias", g.b2, partial=True)
             self.acc(f"{which}.mlp.6.weight", g.W3.reshape(1, -1), partial=True)
             self.acc(f"{which}.mlp.6.bias", g.b3, partial=True)
-            xP, xlab = src[ROW_TYPE], src["lab"]
-            dW1a = ops.linear_wgrad(g.A, xP)
+            xlab = src["lab"]
+            if xP.shape[0]:
+                dW1a = ops.linear_wgrad(g.A, xP)
+            else:
+                dW1a = torch.zeros(w1a.shape, device=self.dev)
             dW1b = ops.linear_wgrad(g.B, xlab)
             if self.comm is not None:
                 self.allreduce(dW1a)             # so that the concatenated weight grad is uniformly "full"
             self.acc(f"{which}.mlp.0.weight", torch.cat([dW1a, dW1b], dim=1))
             self.acc(f"{which}.mlp.0.bias", ops.col_reduce2(g.B)[0].float())
-            gP = ops.linear_fwd(g.A, w1a, w_kn=True)
             glab = ops.linear_fwd(g.B, w1b, w_kn=True)
+            if want_low:                         # gradient rows of the low-degree patients only: (row ids, rows)
+                gP = (low_rows, ops.linear_fwd(g.A, w1a, w_kn=True)) if xP.shape[0] else None
+            else:
+                gP = ops.linear_fwd(g.A, w1a, w_kn=True)
             gsets[which] = {ROW_TYPE: gP, "lab": glab}
         return gsets["tabular_mlp"], gsets["edge_predictor"]
 
