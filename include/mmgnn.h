@@ -227,7 +227,7 @@ typedef struct {
  * Backward: pairs whose upstream gradient is exactly 0 (the ~80 % of train pairs outside the supervision
  * subset, src/train.py:366-370) contribute exactly 0 to every gradient and are skipped. */
 int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li,
-                      const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs,
+                      const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
                       float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
                       float* pred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream);
 int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,

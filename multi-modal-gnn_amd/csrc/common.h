@@ -61,12 +61,17 @@ __host__ __device__ static inline uint32_t mmg_rng_field(uint32_t w0, uint32_t w
 __host__ __device__ static inline uint32_t mmg_keep_threshold(float p) { return (uint32_t)(p * 65536.0f); }
 // keep with probability 1-p.  One hash serves FOUR consecutive elements (16 random bits each, p quantised
 // to 1/65536): callers walk elements in aligned groups of 4, so the compiler shares the hash across the group.
-// keep bits of the 4 consecutive elements e0 .. e0+3 (e0 % 4 == 0): bit j set = element j kept.  ONE hash.
-__host__ __device__ static inline uint32_t mmg_keep4(uint32_t key, uint64_t e0, uint32_t thr) {
+// element j (compile-time 0..3) of a group kept?  Written so that each use is ONE 16-bit sub-dword compare.
+#define MMG_KEPT(w0, w1, j, thr) ((((j) & 2 ? (w1) : (w0)) >> (((j) & 1) * 16) & 0xFFFFu) >= (thr))
+// dropout of the 4 consecutive elements e0 .. e0+3 (e0 % 4 == 0) held in v[0..3]: ONE hash, 4 compares, 4 selects
+template <class V4>
+__host__ __device__ static inline void mmg_drop4(V4& v, uint32_t key, uint64_t e0, uint32_t thr, float inv_keep) {
   uint32_t w0, w1;
   mmg_rng_group(key, e0 >> 2, &w0, &w1);
-  return ((w0 & 0xFFFFu) >= thr ? 1u : 0u) | ((w0 >> 16) >= thr ? 2u : 0u) | ((w1 & 0xFFFFu) >= thr ? 4u : 0u) |
-         ((w1 >> 16) >= thr ? 8u : 0u);
+  v[0] = MMG_KEPT(w0, w1, 0, thr) ? v[0] * inv_keep : 0.f;
+  v[1] = MMG_KEPT(w0, w1, 1, thr) ? v[1] * inv_keep : 0.f;
+  v[2] = MMG_KEPT(w0, w1, 2, thr) ? v[2] * inv_keep : 0.f;
+  v[3] = MMG_KEPT(w0, w1, 3, thr) ? v[3] * inv_keep : 0.f;
 }
 __host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, uint64_t elem, float p) {
   uint32_t w0, w1;
@@ -111,11 +116,7 @@ __device__ static inline void mmg_pro_apply4(const ProDev& pr, V4& v, const V4& 
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
   }
-  if (pr.p > 0.f) {
-    const uint32_t m = mmg_keep4(pr.key, (uint64_t)(pr.row_offset + row) * (uint64_t)K + (uint64_t)k0, pr.thr);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (m >> j) & 1u ? v[j] * pr.inv_keep : 0.f;
-  }
+  if (pr.p > 0.f) mmg_drop4(v, pr.key, (uint64_t)(pr.row_offset + row) * (uint64_t)K + (uint64_t)k0, pr.thr, pr.inv_keep);
 }
 __device__ static inline float mmg_pro_apply(const ProDev& pr, float x, float sc, float sh, int64_t row,
                                              int k, int K) {

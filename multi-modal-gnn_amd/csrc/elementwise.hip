@@ -47,20 +47,23 @@ __global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, 
     rs = *reinterpret_cast<const f32x4*>(rstd + c4 * 4);
   }
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
-  auto body = [&](int64_t r, const f32x4& a, const f32x4& b) {
-    uint32_t km = 15u;
-    if (MODE == 1 && pr.p > 0.f)
-      km = mmg_keep4(pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)(c4 * 4), pr.thr);
+  auto body = [&](int64_t r, const f32x4& a_in, const f32x4& b) {
+    f32x4 a = a_in;
+    if (MODE == 1) {                 // a = upstream grad G, b = pre-BN activation Y: g through relu, then dropout
+      if (pr.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float o = pr.scale ? fmaf(b[j], sc[j], sh[j]) : b[j];
+          if (!(o > 0.f)) a[j] = 0.f;
+        }
+      }
+      if (pr.p > 0.f)
+        mmg_drop4(a, pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)(c4 * 4), pr.thr, pr.inv_keep);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float av = a[j], bv = b[j];
       if (MODE == 1) {
-        // a = upstream grad G, b = pre-BN activation Y
-        const float o = pr.scale ? fmaf(bv, sc[j], sh[j]) : bv;
-        float g = av;
-        if (pr.relu && !(o > 0.f)) g = 0.f;
-        if (pr.p > 0.f) g = (km >> j) & 1u ? g * pr.inv_keep : 0.f;
-        av = g;
         bv = (bv - mu[j]) * rs[j];
       }
       s0[j] += (double)av;
@@ -195,15 +198,18 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const int64_t r = i / (N / 4);
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(G + (size_t)i * 4);
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
-    f32x4 o;
-    uint32_t km = 15u;
-    if (pr.p > 0.f) km = mmg_keep4(pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)c, pr.thr);
+    f32x4 o, gm = g4;
+    if (pr.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float act = pr.scale ? fmaf(y4[j], sc[j], sh[j]) : y4[j];
+        if (!(act > 0.f)) gm[j] = 0.f;
+      }
+    }
+    if (pr.p > 0.f) mmg_drop4(gm, pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)c, pr.thr, pr.inv_keep);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float act = pr.scale ? fmaf(y4[j], sc[j], sh[j]) : y4[j];
-      float g = g4[j];
-      if (pr.relu && !(act > 0.f)) g = 0.f;
-      if (pr.p > 0.f) g = (km >> j) & 1u ? g * pr.inv_keep : 0.f;
+      float g = gm[j];
       if (pr.scale) {
         const float xh = (y4[j] - mu[j]) * rs[j];
         g = sc[j] * (g - a0[j] - xh * a1[j]);

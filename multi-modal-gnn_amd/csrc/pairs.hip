@@ -332,22 +332,15 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
     }
     // ---- (b) h1[pair=l31][k=32h+s]: gather-add, relu, dropout; kept in registers AND written to LDS
     float h1a[32];
-    uint32_t km1[8];                                 // keep bits of the 8 aligned groups of 4 (one hash each)
-    if (drop_p > 0.f) {
-      const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
+    const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) km1[q] = mmg_keep4(key1, pid * 64ull + (uint64_t)(32 * h + q * 4), thr1);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 8; ++q) {                    // one aligned RNG group of 4 per q: one hash
       f32x4 v;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = fmaxf(ca[q][j] + cb[q][j], 0.f);
-        if (drop_p > 0.f) x = (km1[q] >> j) & 1u ? x * inv_keep : 0.f;
-        v[j] = x;
-        h1a[q * 4 + j] = x;
-      }
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(ca[q][j] + cb[q][j], 0.f);
+      if (drop_p > 0.f) mmg_drop4(v, key1, pid * 64ull + (uint64_t)(32 * h + q * 4), thr1, inv_keep);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h1a[q * 4 + j] = v[j];
       *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
     }
     // ---- (1) H2pre = H1 . W2^T
@@ -501,119 +494,121 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 }
 
 // ---------------------------------------------------------------------------- forward on MFMA
-// Same tiling as the backward: one wave per 32 pairs, H2pre = H1 . W2^T on the matrix cores (32 MFMA), the
-// 32->1 output layer is a butterfly reduction over the 32 unit lanes (16 shuffles per tile).
+// One wave per 32 pairs.  The layer-2 product is computed TRANSPOSED, H2pre^T[unit, pair] = W2 . H1^T (A = W2 rows in
+// registers, B = the pair's own h1 values): the accumulator then has lane = pair and registers = 16 of the 32 units
+// (the other 16 sit in lane + 32), so everything after the matrix product is lane-local -- bias, ReLU, the dropout
+// mask (registers 4i .. 4i+3 are one aligned RNG group: one hash each), the 32 -> 1 output layer as 16 FMAs -- and
+// one cross-half add finishes a prediction.  No LDS, no shuffles, no barrier.
+constexpr int PF_LDB = 68;           // LDS row stride of the lab-side table (floats): rows land 4 banks apart
 __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32_t* __restrict__ pi,
                                                           const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                           int thr, int want_low, int64_t n, float drop_p, uint64_t seed,
                                                           const uint64_t* __restrict__ seed_ptr,
                                                           const int64_t* __restrict__ pair_id, float* __restrict__ pred,
                                                           const int32_t* __restrict__ sel,
-                                                          const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io) {
+                                                          const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io,
+                                                          int n_labs_lds) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) n = *n_sel;
-  __shared__ unsigned PL[4][TP], PH[4][TP];
+  // the lab-side first-layer table B (a few dozen 256-B rows, read once per PAIR) lives in LDS when it fits:
+  // 4.3 M pairs x 256 B would otherwise stream from L2
+  extern __shared__ __attribute__((aligned(16))) float Bs[];
+  for (int i = threadIdx.x; i < n_labs_lds * 16; i += 256)
+    *reinterpret_cast<f32x4*>(Bs + (i >> 4) * PF_LDB + (i & 15) * 4) = *reinterpret_cast<const f32x4*>(H.B + (size_t)i * 4);
+  __syncthreads();
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  float w2b[32];
+  const uint32_t thr_keep = mmg_keep_threshold(drop_p);
+  const uint32_t key1 = mmg_rng_key(seed, SITE_H1), key2 = mmg_rng_key(seed, SITE_H2);
+  float w2b[32];                     // A operand: W2[unit = l31][k = 32 h + s]
 #pragma unroll
   for (int s = 0; s < 32; ++s) w2b[s] = H.W2[l31 * 64 + 32 * h + s];
-  const float b2v = H.b2[l31], w3v = H.W3[l31], b3 = H.b3[0];
+  float b2r[16], w3r[16];            // this lane's 16 units: crow(r, h)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { b2r[r] = H.b2[crow(r, h)]; w3r[r] = H.W3[crow(r, h)]; }
+  const float b3 = H.b3[0];
 
   const int64_t n_tiles = (n + TP - 1) / TP;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid, n_waves = (int64_t)gridDim.x * 4;
-  struct Meta { int p_i; int l_i; int k; uint64_t pid; };
-  auto load_meta = [&](int64_t t) {
-    Meta m{-1, 0, 0, 0ull};
-    int64_t k = t * TP + l31;
-    if (t < n_tiles && k < n) {
-      if (sel) k = sel[k];
-      const int pp = pi[k];
-      if (((int)(deg[pp] < thr)) == want_low) {
-        m.p_i = pp; m.l_i = li[k]; m.k = (int)k;
-        m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
-      }
+  // Three-deep software pipeline over this wave's tiles, one dependent load per stage, so that no load is waited
+  // for in the iteration that issues it:   tile t+3: list position -> pair index k   (sel[.])
+  //                                        tile t+2: k -> patient, lab, rng id, output slot
+  //                                        tile t+1: patient -> gate degree, A row;  lab -> B row
+  struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
+  auto load_k = [&](int64_t t) {
+    const int64_t idx = t * TP + l31;
+    int k = -1;
+    if (t < n_tiles && idx < n) k = sel ? sel[idx] : (int)idx;
+    return k;
+  };
+  auto load_meta = [&](int k) {
+    Meta m{k, -1, 0, 0, 0ull};
+    if (k >= 0) {
+      m.p_i = pi[k]; m.l_i = li[k];
+      m.o = io ? (int)io[k] : k;
+      m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
     }
     return m;
   };
-  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb) {
-    const float* ap = H.A + (size_t)(m.p_i >= 0 ? m.p_i : 0) * 64 + 32 * h;
+  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg) {
+    const int pp = m.p_i >= 0 ? m.p_i : 0;
+    *dg = deg[pp];
+    const float* ap = H.A + (size_t)pp * 64 + 32 * h;
     const float* bp = H.B + (size_t)m.l_i * 64 + 32 * h;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       ra[q] = *reinterpret_cast<const f32x4*>(ap + q * 4);
-      rb[q] = *reinterpret_cast<const f32x4*>(bp + q * 4);
+      if (!n_labs_lds) rb[q] = *reinterpret_cast<const f32x4*>(bp + q * 4);
     }
   };
-  Meta m0 = load_meta(wave_id), m1 = load_meta(wave_id + n_waves);
+  int k2 = load_k(wave_id + 2 * n_waves);
+  Meta m0 = load_meta(load_k(wave_id)), m1 = load_meta(load_k(wave_id + n_waves));
   f32x4 ra[8], rb[8];
-  load_rows(m0, ra, rb);
+  int dg0;
+  load_rows(m0, ra, rb, &dg0);
   for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
     const Meta mc = m0;
+    const bool active = mc.p_i >= 0 && ((int)(dg0 < thr)) == want_low;
     f32x4 ca[8], cb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
-    const Meta m2 = load_meta(t + 2 * n_waves);
-    load_rows(m1, ra, rb);
-    m0 = m1; m1 = m2;
-    if (__ballot(mc.p_i >= 0) == 0ull) continue;
-    if (drop_p > 0.f && h == 0) { PL[wid][l31] = (unsigned)mc.pid; PH[wid][l31] = (unsigned)(mc.pid >> 32); }
+    const int k3 = load_k(t + 3 * n_waves);
+    const Meta m2 = load_meta(k2);
+    load_rows(m1, ra, rb, &dg0);
+    m0 = m1; m1 = m2; k2 = k3;
+    if (__ballot(active) == 0ull) continue;
+    if (n_labs_lds) {
+      const float* bl = Bs + mc.l_i * PF_LDB + 32 * h;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cb[q] = *reinterpret_cast<const f32x4*>(bl + q * 4);
+    }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    uint32_t km1[8];                                 // keep bits of the 8 aligned groups of 4 (one hash each)
-    if (drop_p > 0.f) {
-      const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) km1[q] = mmg_keep4(key1, mc.pid * 64ull + (uint64_t)(32 * h + q * 4), thr1);
+    for (int q = 0; q < 8; ++q) {                    // one aligned RNG group of 4 per q: one hash
+      f32x4 x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = fmaxf(ca[q][j] + cb[q][j], 0.f);
+      if (drop_p > 0.f) mmg_drop4(x, key1, mc.pid * 64ull + (uint64_t)(32 * h + q * 4), thr_keep, inv_keep);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2b[q * 4 + j], x[j], acc, 0, 0, 0);   // C^T: lane = pair, reg = unit
     }
+    // lane = pair l31, register r = unit crow(r, h) = (r & 3) + 8 (r >> 2) + 4 h
+    float part = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int i = 0; i < 4; ++i) {                    // units 8 i + 4 h + 0..3: one aligned RNG group
+      f32x4 post;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = fmaxf(ca[q][j] + cb[q][j], 0.f);
-        if (drop_p > 0.f) x = (km1[q] >> j) & 1u ? x * inv_keep : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, w2b[q * 4 + j], acc, 0, 0, 0);
-      }
-    // C layout: lane = unit u (l31), reg r = pair row crow(r,h).  v[r] = W3[u] * dropout(relu(pre))
-    float v[16];
-    uint32_t kb[16];
-    if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PL[wid], PH[wid], h, l31, kb);
+      for (int e = 0; e < 4; ++e) post[e] = fmaxf(acc[4 * i + e] + b2r[4 * i + e], 0.f);
+      if (drop_p > 0.f) mmg_drop4(post, key2, mc.pid * 32ull + (uint64_t)(8 * i + 4 * h), thr_keep, inv_keep);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float post = fmaxf(acc[r] + b2v, 0.f);
-      if (drop_p > 0.f) post = kb[r] >= mmg_keep_threshold(drop_p) ? post * inv_keep : 0.f;
-      v[r] = w3v * post;
+      for (int e = 0; e < 4; ++e) part = fmaf(w3r[4 * i + e], post[e], part);
     }
-    // butterfly over the 32 unit lanes: after the 5 steps lane l31 holds the full sum of reg r = l31 >> 1
-    const bool b4 = l31 & 16, b3b = l31 & 8, b2b = l31 & 4, b1b = l31 & 2;
-    float w8[8], w4[4], w2[2], w1;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float send = b4 ? v[i] : v[i + 8], keep = b4 ? v[i + 8] : v[i];
-      w8[i] = keep + __shfl_xor(send, 16, 64);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float send = b3b ? w8[i] : w8[i + 4], keep = b3b ? w8[i + 4] : w8[i];
-      w4[i] = keep + __shfl_xor(send, 8, 64);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float send = b2b ? w4[i] : w4[i + 2], keep = b2b ? w4[i + 2] : w4[i];
-      w2[i] = keep + __shfl_xor(send, 4, 64);
-    }
-    {
-      const float send = b1b ? w2[0] : w2[1], keep = b1b ? w2[1] : w2[0];
-      w1 = keep + __shfl_xor(send, 2, 64);
-    }
-    w1 += __shfl_xor(w1, 1, 64);
-    const int r = (b4 ? 8 : 0) + (b3b ? 4 : 0) + (b2b ? 2 : 0) + (b1b ? 1 : 0);
-    const int row = crow(r, h);
-    const int owner = __shfl(mc.p_i, row, 64);          // lane `row` (half 0) holds that pair's metadata
-    const int ok = __shfl(mc.k, row, 64);
-    if ((l31 & 1) == 0 && owner >= 0) pred[io ? io[ok] : ok] = w1 + b3;
+    part += __shfl_xor(part, 32, 64);
+    if (h == 0 && active) pred[mc.o] = part + b3;
   }
 }
 
@@ -735,7 +730,7 @@ int check_head(const mmg_head_t* h, const char* what) {
 }  // namespace
 
 extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
-                                 int degree_threshold, int want_low, int64_t n_pairs, float drop_p, uint64_t seed,
+                                 int degree_threshold, int want_low, int64_t n_pairs, int n_labs, float drop_p, uint64_t seed,
                                  const uint64_t* seed_ptr, const int64_t* pair_id, float* pred, const int32_t* sel,
                                  const int32_t* n_sel, const int64_t* io_perm, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0, "pair_head_fwd: n_pairs < 0");
@@ -749,8 +744,13 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   int64_t g = ((n_pairs + TP - 1) / TP + 3) / 4;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(k_pair_fwd_mfma, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, H, pi, li, deg,
-                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel, io_perm);
+  const int n_labs_lds = (n_labs > 0 && n_labs <= 256) ? n_labs : 0;       // 256 rows x 272 B = 68 KB: two workgroups per CU
+  const size_t lds = (size_t)n_labs_lds * PF_LDB * sizeof(float);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)k_pair_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_pair_fwd_mfma, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, H, pi, li, deg,
+                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel, io_perm,
+                     n_labs_lds);
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;
 }

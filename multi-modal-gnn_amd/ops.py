@@ -440,7 +440,8 @@ def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, s
     h = head.c()
     _tok = _pb("pair_head_fwd")
     check(lib.mmg_pair_head_fwd(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
-                                int(want_low), n, float(p), seed & 0xFFFFFFFFFFFFFFFF, _p(seed_dev, torch.int64),
+                                int(want_low), n, int(head.B.shape[0]), float(p), seed & 0xFFFFFFFFFFFFFFFF,
+                                _p(seed_dev, torch.int64),
                                 _p(pair_id, torch.int64), _p(pred), _p(sel, torch.int32), _p(n_sel, torch.int32),
                                 _p(io_perm, torch.int64), _stream()), "mmg_pair_head_fwd")
     _pe(_tok, "pair_head_fwd", n * 12 + 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (64 * 32 + 32 + 64))
