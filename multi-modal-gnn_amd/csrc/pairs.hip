@@ -285,24 +285,30 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 
   const int64_t n_tiles = (n + TP - 1) / TP;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid, n_waves = (int64_t)gridDim.x * 4;
-  // software pipeline: pair metadata two tiles ahead, the A/B row halves one tile ahead
-  struct Meta { int p_i; int l_i; float dout; uint64_t pid; };
-  auto load_meta = [&](int64_t t) {
-    Meta m{-1, 0, 0.f, 0ull};
-    int64_t k = t * TP + l31;
-    if (t < n_tiles && k < n) {
-      if (sel) k = sel[k];
-      const int pp = pi[k];
-      if (((int)(deg[pp] < thr)) == want_low) {
-        m.p_i = pp; m.l_i = li[k];
-        m.dout = dpred[io ? io[k] : k];
-        m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
-      }
+  // Three-deep software pipeline over this wave's tiles, one dependent load per stage (no load is waited for in
+  // the iteration that issues it):  t+3: list position -> pair index;  t+2: pair -> patient, lab, rng id, slot of
+  // its upstream gradient;  t+1: gate degree, upstream gradient, the A / B row halves.
+  struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
+  auto load_k = [&](int64_t t) {
+    const int64_t idx = t * TP + l31;
+    int k = -1;
+    if (t < n_tiles && idx < n) k = sel ? sel[idx] : (int)idx;
+    return k;
+  };
+  auto load_meta = [&](int k) {
+    Meta m{k, -1, 0, 0, 0ull};
+    if (k >= 0) {
+      m.p_i = pi[k]; m.l_i = li[k];
+      m.o = io ? (int)io[k] : k;
+      m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
     }
     return m;
   };
-  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb) {
-    const float* ap = H.A + (size_t)(m.p_i >= 0 ? m.p_i : 0) * 64 + 32 * h;
+  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
+    const int pp = m.p_i >= 0 ? m.p_i : 0;
+    *dg = deg[pp];
+    *dv = m.p_i >= 0 ? dpred[m.o] : 0.f;
+    const float* ap = H.A + (size_t)pp * 64 + 32 * h;
     const float* bp = H.B + (size_t)m.l_i * 64 + 32 * h;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -310,19 +316,23 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
       rb[q] = *reinterpret_cast<const f32x4*>(bp + q * 4);
     }
   };
-  Meta m0 = load_meta(wave_id), m1 = load_meta(wave_id + n_waves);
+  int k2 = load_k(wave_id + 2 * n_waves);
+  Meta m0 = load_meta(load_k(wave_id)), m1 = load_meta(load_k(wave_id + n_waves));
   f32x4 ra[8], rb[8];
-  load_rows(m0, ra, rb);
+  int dg0; float dv0;
+  load_rows(m0, ra, rb, &dg0, &dv0);
   for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
     const Meta mc = m0;
+    const bool active = mc.p_i >= 0 && ((int)(dg0 < thr)) == want_low;
+    const float dout = active ? dv0 : 0.f;
     f32x4 ca[8], cb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
-    const Meta m2 = load_meta(t + 2 * n_waves);
-    load_rows(m1, ra, rb);                       // next tile's rows: in flight during this tile's MFMAs
-    m0 = m1; m1 = m2;
-    const int p_i = mc.p_i, l_i = mc.l_i;
-    const float dout = mc.dout;
+    const int k3 = load_k(t + 3 * n_waves);
+    const Meta m2 = load_meta(k2);
+    load_rows(m1, ra, rb, &dg0, &dv0);           // next tile's rows: in flight during this tile's MFMAs
+    m0 = m1; m1 = m2; k2 = k3;
+    const int p_i = active ? mc.p_i : -1, l_i = mc.l_i;
     const uint64_t pid = mc.pid;
     if (__ballot(p_i >= 0) == 0ull) continue;    // no pair of this tile belongs to this head (wave-uniform)
     if (h == 0) {
