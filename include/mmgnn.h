@@ -238,11 +238,13 @@ int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,
 
 /* Stable two-way compaction of pair positions by head: position k goes to sel_low if deg[pi[k]] < threshold,
  * else to sel_high -- and only if dpred is NULL or dpred[k] != 0.  Order inside a list = pair order (pairs sorted
- * by patient stay sorted).  counts[0], counts[1] (device) = list lengths.  sel_low / sel_high: capacity n each. */
+ * by patient stay sorted).  counts[0], counts[1] (device) = list lengths.  sel_low / sel_high: capacity n each.
+ * dpred is read through io_perm (nullable); dpred_sorted (nullable, [n]) receives dpred in pair order -- the ONE
+ * random pass over the gradient -- for mmg_pair_head_bwd to read sequentially (with io_perm = NULL). */
 size_t mmg_pair_select_ws_bytes(int64_t n_pairs);
 int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold, const float* dpred,
-                    const int64_t* io_perm, int64_t n_pairs, int32_t* sel_low, int32_t* sel_high, int32_t* counts,
-                    void* ws, size_t ws_bytes, void* stream);
+                    const int64_t* io_perm, float* dpred_sorted, int64_t n_pairs, int32_t* sel_low, int32_t* sel_high,
+                    int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -626,15 +626,36 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
 constexpr int SEL_PER = 8, SEL_CH = 256 * SEL_PER;      // pairs per thread / per workgroup
 
 // packed per-thread counts: low list in bits 0..15, high list in bits 16..31 (a chunk holds 2048 pairs)
+// dps (nullable): the upstream gradient in SORTED pair order.  The count pass fills it (the one random pass through
+// io_perm); the write pass and the backward kernel then read it sequentially.
+template <bool FILL>
 __device__ inline unsigned sel_flags(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg, int thr,
-                                     const float* __restrict__ dpred, const int64_t* __restrict__ io, int64_t n,
-                                     int64_t k0, unsigned* bits) {
+                                     const float* __restrict__ dpred, const int64_t* __restrict__ io,
+                                     float* __restrict__ dps, int64_t n, int64_t k0, unsigned* bits) {
   unsigned cnt = 0, lowbits = 0, anybits = 0;
+  // all loads of a thread's 8 pairs are issued before any is used (indices clamped, no branches in between):
+  // the gather through io_perm is a chain of two dependent random loads per pair
+  const int64_t kl = n - 1;
+  float d[SEL_PER];
+  int dg[SEL_PER];
+  int64_t src[SEL_PER];
+#pragma unroll
+  for (int j = 0; j < SEL_PER; ++j) {
+    const int64_t k = k0 + j < kl ? k0 + j : kl;
+    src[j] = (dpred && io && (FILL || !dps)) ? io[k] : k;
+  }
+#pragma unroll
+  for (int j = 0; j < SEL_PER; ++j) {
+    const int64_t k = k0 + j < kl ? k0 + j : kl;
+    d[j] = !dpred ? 1.f : ((FILL || !dps) ? dpred[src[j]] : dps[k]);
+    dg[j] = deg[pi[k]];
+  }
 #pragma unroll
   for (int j = 0; j < SEL_PER; ++j) {
     const int64_t k = k0 + j;
-    if (k < n && (!dpred || dpred[io ? io[k] : k] != 0.f)) {
-      const bool low = deg[pi[k]] < thr;
+    if (k < n && FILL && dpred && dps) dps[k] = d[j];
+    if (k < n && d[j] != 0.f) {
+      const bool low = dg[j] < thr;
       anybits |= 1u << j;
       if (low) { lowbits |= 1u << j; cnt += 1u; } else cnt += 1u << 16;
     }
@@ -662,11 +683,12 @@ __device__ inline unsigned block_excl_scan(unsigned v, unsigned* total, unsigned
 
 __global__ __launch_bounds__(256) void k_sel_count(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg,
                                                    int thr, const float* __restrict__ dpred,
-                                                   const int64_t* __restrict__ io, int64_t n,
+                                                   const int64_t* __restrict__ io, float* __restrict__ dps, int64_t n,
                                                    unsigned* __restrict__ cnt) {
   __shared__ unsigned sm[4];
   unsigned bits, tot;
-  const unsigned c = sel_flags(pi, deg, thr, dpred, io, n, (int64_t)blockIdx.x * SEL_CH + threadIdx.x * SEL_PER, &bits);
+  const unsigned c = sel_flags<true>(pi, deg, thr, dpred, io, dps, n,
+                                     (int64_t)blockIdx.x * SEL_CH + threadIdx.x * SEL_PER, &bits);
   block_excl_scan(c, &tot, sm);
   if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
 }
@@ -706,13 +728,13 @@ __global__ __launch_bounds__(1024) void k_sel_scan(const unsigned* __restrict__ 
 
 __global__ __launch_bounds__(256) void k_sel_write(const int32_t* __restrict__ pi, const int32_t* __restrict__ deg,
                                                    int thr, const float* __restrict__ dpred,
-                                                   const int64_t* __restrict__ io, int64_t n,
+                                                   const int64_t* __restrict__ io, float* __restrict__ dps, int64_t n,
                                                    const int2* __restrict__ base, int32_t* __restrict__ sel_low,
                                                    int32_t* __restrict__ sel_high) {
   __shared__ unsigned sm[4];
   unsigned bits, tot;
   const int64_t k0 = (int64_t)blockIdx.x * SEL_CH + threadIdx.x * SEL_PER;
-  const unsigned c = sel_flags(pi, deg, thr, dpred, io, n, k0, &bits);
+  const unsigned c = sel_flags<false>(pi, deg, thr, dpred, io, dps, n, k0, &bits);
   const unsigned off = block_excl_scan(c, &tot, sm);
   const int2 b = base[blockIdx.x];
   int ol = b.x + (int)(off & 0xFFFFu), oh = b.y + (int)(off >> 16);
@@ -817,8 +839,8 @@ extern "C" size_t mmg_pair_select_ws_bytes(int64_t n_pairs) {
 }
 
 extern "C" int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold, const float* dpred,
-                               const int64_t* io_perm, int64_t n_pairs, int32_t* sel_low, int32_t* sel_high,
-                               int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+                               const int64_t* io_perm, float* dpred_sorted, int64_t n_pairs, int32_t* sel_low,
+                               int32_t* sel_high, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0 && n_pairs < (int64_t)INT32_MAX, "pair_select: n_pairs out of range");
   MMG_CHECK_ARG(counts, "pair_select: counts is null");
   hipStream_t st = (hipStream_t)stream;
@@ -834,10 +856,11 @@ extern "C" int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree
   const int nb = (int)((n_pairs + SEL_CH - 1) / SEL_CH);
   int2* base = reinterpret_cast<int2*>(ws);                                  // 8-byte aligned: first in the workspace
   unsigned* cnt = reinterpret_cast<unsigned*>(base + nb);
-  hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, io_perm, n_pairs, cnt);
+  hipLaunchKernelGGL(k_sel_count, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, io_perm, dpred_sorted,
+                     n_pairs, cnt);
   hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, cnt, nb, base, counts);
-  hipLaunchKernelGGL(k_sel_write, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, io_perm, n_pairs, base,
-                     sel_low, sel_high);
+  hipLaunchKernelGGL(k_sel_write, dim3(nb), dim3(256), 0, st, pi, deg, degree_threshold, dpred, io_perm, dpred_sorted,
+                     n_pairs, base, sel_low, sel_high);
   MMG_CHECK_LAUNCH("pair_select");
   return MMG_OK;
 }

@@ -657,15 +657,16 @@ class _Run:
         gsets = {}
         # pairs with a zero upstream gradient (everything outside the supervision subset, train.py:366-370) add
         # exactly nothing: visit only the others, split by head
-        bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps, io_perm=perm)
+        dsorted = torch.empty_like(dps)          # dpred in sorted pair order: the one random pass, made by the selection
+        bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps, io_perm=perm, dpred_sorted=dsorted)
         for which, src, want_low in (("edge_predictor", rec["fin"], False), ("tabular_mlp", rec["init"], True)):
             head, w1a, w1b, xP = rec[which]
             g = ops.Head(torch.zeros_like(head.A), torch.zeros_like(head.B), torch.zeros_like(head.W2),
                          torch.zeros_like(head.b2), torch.zeros_like(head.W3), torch.zeros_like(head.b3))
             sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
             ops.pair_head_bwd(head, g, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr,
-                              want_low, n_lab, self.p, self.seed, ids, dps,
-                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb, io_perm=perm)
+                              want_low, n_lab, self.p, self.seed, ids, dsorted,
+                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb)
             self.allreduce(g.B)                  # lab-side partials from sharded pairs
             self.acc(f"{which}.mlp.3.weight", g.W2, partial=True)
             self.acc(f"{which}.mlp.3.bias", g.b2, partial=True)

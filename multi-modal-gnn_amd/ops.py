@@ -411,9 +411,10 @@ class Head:
         return HeadT(_p(self.A), _p(self.B), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3))
 
 
-def pair_select(pi, deg, thr: int, dpred=None, io_perm=None):
+def pair_select(pi, deg, thr: int, dpred=None, io_perm=None, dpred_sorted=None):
     """Stable compaction of pair positions by head (mmg_pair_select) -> (sel_low, sel_high, counts[2] on device).
-    With `dpred`, positions whose upstream gradient is exactly 0 are dropped (dpred is read through io_perm)."""
+    With `dpred`, positions whose upstream gradient is exactly 0 are dropped (dpred is read through io_perm; if
+    `dpred_sorted` ([n] float) is given it receives dpred in pair order)."""
     lib = _lib.load()
     n = pi.numel()
     sel_low = torch.empty(max(n, 1), dtype=torch.int32, device=pi.device)
@@ -421,8 +422,8 @@ def pair_select(pi, deg, thr: int, dpred=None, io_perm=None):
     counts = torch.empty(2, dtype=torch.int32, device=pi.device)
     ws = workspace(lib.mmg_pair_select_ws_bytes(n), pi.device)
     _tok = _pb("pair_select")
-    check(lib.mmg_pair_select(_p(pi, torch.int32), _p(deg, torch.int32), thr, _p(dpred), _p(io_perm, torch.int64), n,
-                              _p(sel_low, torch.int32),
+    check(lib.mmg_pair_select(_p(pi, torch.int32), _p(deg, torch.int32), thr, _p(dpred), _p(io_perm, torch.int64),
+                              _p(dpred_sorted), n, _p(sel_low, torch.int32),
                               _p(sel_high, torch.int32), _p(counts, torch.int32), _p(ws, torch.uint8), ws.numel(),
                               _stream()), "mmg_pair_select")
     _pe(_tok, "pair_select", n * 24)

@@ -176,7 +176,7 @@ class SoloComm:
 
 def test_piecewise_graph_chain_matches_eager_steps():
     """The chain of hipGraph segments (cut at every collective, forward/backward driven by hand) must train exactly like
-    eager autograd steps: same losses, same parameters after three Adam steps (dropout 0: no RNG in the way)."""
+    eager autograd steps: same losses, same parameters after three optimizer steps (dropout 0: no RNG in the way)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import mmgnn  # noqa: F401
@@ -202,8 +202,9 @@ def test_piecewise_graph_chain_matches_eager_steps():
         plan = build_plan(g, dev, use_cache=False)
         md.shard_plan(plan, comm, 0, plan.n_rows)
         md.shard_model(m, comm)
-        opt = torch.optim.Adam([p for n, p in m.named_parameters() if not n.startswith("embeddings.")], lr=1e-2,
-                               capturable=True, fused=True)
+        # SGD: Adam would turn the rounding noise of near-zero gradient entries into +-lr steps (a flaky comparison)
+        opt = torch.optim.SGD([p for n, p in m.named_parameters() if not n.startswith("embeddings.")], lr=0.05,
+                              momentum=0.9)
         return m, plan, comm, opt
 
     m1, plan1, comm1, opt1 = make()
@@ -230,8 +231,5 @@ def test_piecewise_graph_chain_matches_eager_steps():
     for a, b in zip(losses1, losses2):
         assert abs(a - b) <= 2e-5 * abs(a), (losses1, losses2)
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
-        # a bias in front of a BatchNorm has a zero gradient up to rounding noise, which Adam turns into +-lr steps
-        feeds_bn = n in ("patient_transform.0.bias", "patient_transform.4.bias") or n.endswith("lin_l.bias")
-        if not n.startswith("embeddings.") and not feeds_bn:
-            # (Adam normalises tiny gradients: atomics-order noise shows up at a few 1e-5; a structural error is O(lr))
-            assert float((p1 - p2).abs().max()) <= 1e-3 * float(p1.abs().max()) + 1e-5, n
+        if not n.startswith("embeddings."):
+            assert float((p1 - p2).abs().max()) <= 1e-4 * float(p1.abs().max()) + 1e-6, n
