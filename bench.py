@@ -208,9 +208,9 @@ def main():
     gstep = None
     if world == 1 and not args.no_graph:
         try:
-            from mmgnn.train import GraphedTrainStep
-            gstep = GraphedTrainStep(w["model"], w["plan"], w["pi"], w["li"], w["y"], w["wlab"], w["opt"], w["sup"],
-                                     n_sup_global=w["n_sup"], warmup=2)
+            from mmgnn.train import PiecewiseGraphedTrainStep
+            gstep = PiecewiseGraphedTrainStep(w["model"], w["plan"], w["pi"], w["li"], w["y"], w["wlab"], w["opt"], w["sup"],
+                                              None, n_sup_global=w["n_sup"], warmup=2)
         except Exception as e:   # capture is an optimisation, never a requirement
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             w["model"]._seed_dev = None

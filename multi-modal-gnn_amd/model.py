@@ -454,12 +454,14 @@ class _Run:
         self.acc(bn_prefix + ".weight", dbg[1])
         return dy
 
-    def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False):
-        """grads of  y = pro(x) W^T + b."""
+    def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False, dx_into=None):
+        """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one."""
         self.acc(wname, ops.linear_wgrad(dy, x, pro), partial)
         if bname is not None:
             self.acc(bname, ops.col_reduce2(dy)[0].float(), partial)
         if need_dx:
+            if dx_into is not None:
+                return ops.linear_fwd(dy, self.W(wname), w_kn=True, out=dx_into, accumulate=True)
             return ops.linear_fwd(dy, self.W(wname), w_kn=True)          # dX = dY . W, W read in place
         return None
 
@@ -472,10 +474,13 @@ class _Run:
         dz2 = self.bn_bwd(g, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5", sharded=True)
         g = self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
         dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True)
-        need_dE = self.params[f"embeddings.{ROW_TYPE}.weight"].requires_grad
-        dE = self.lin_bwd(dz1, enc["E"], None, f"{pt}.0.weight", f"{pt}.0.bias", need_dx=need_dE, partial=True)
-        if dE is not None:
-            self.acc(f"embeddings.{ROW_TYPE}.weight", dE)
+        ename = f"embeddings.{ROW_TYPE}.weight"
+        need_dE = self.params[ename].requires_grad
+        # the second encoder pass (dropout: encode_nodes runs twice, F7) adds its dE inside the GEMM
+        dE = self.lin_bwd(dz1, enc["E"], None, f"{pt}.0.weight", f"{pt}.0.bias", need_dx=need_dE, partial=True,
+                          dx_into=self.grads.get(ename))
+        if dE is not None and ename not in self.grads:
+            self.acc(ename, dE)
 
     # ======================================================================== HeteroConv layers
     def layers_fwd(self, x):

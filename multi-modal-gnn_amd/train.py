@@ -292,7 +292,9 @@ class GraphedTrainStep:
 
 
 class PiecewiseGraphedTrainStep:
-    """The sharded training step as a CHAIN of hipGraphs with the RCCL all-reduces between them.
+    """The training step with forward, loss and backward driven by hand (no autograd engine: gradients are assigned to
+    ``.grad`` directly, nothing is cloned) and recorded into hipGraphs: ONE graph on a single GPU (``comm=None``), a
+    CHAIN of graphs with the RCCL all-reduces between them when the patients are sharded.
 
     A patient-sharded step has ~14 tiny all-reduces (Sync-BN statistics, vocab-side partial sums, the gradient bucket;
     dist.py) between its ~330 kernel launches.  Collectives are not captured: every ``ShardComm.all_reduce`` met while
