@@ -129,9 +129,10 @@ typedef struct {
 int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
                    float* Y, int64_t M, int N, int K, int flags, void* stream);
 
-/* dW[N,K] (+)= dY[M,N]^T . prologue(X)[M,K]   (reduction over the M rows)          */
+/* dW[N,K] (+)= dY[M,N]^T . prologue(X)[M,K]   (reduction over the M rows);
+ * dbias (nullable, [N]) (+)= the column sums of dY -- the bias gradient of the same layer, from the same pass */
 size_t mmg_linear_wgrad_ws_bytes(int64_t M, int N, int K);
-int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW,
+int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, float* dbias,
                      int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* column reductions over rows: out[0,:] = sum_m A[m,:], out[1,:] = sum_m A[m,:]*B[m,:] (fp64 out) */

@@ -469,7 +469,8 @@ __device__ __forceinline__ xbf16x8 tr_frag(const __bf16* p, int row_stride) {   
 template <int TN, int TK, int WNN, int WNK>      // WNN x WNK waves over the [TN, TK] output tile
 __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float* __restrict__ dY, const float* __restrict__ X,
                                                          ProDev pr, float* __restrict__ slab, int64_t M, int N, int K,
-                                                         int64_t rows_per_split, int direct_accumulate) {
+                                                         int64_t rows_per_split, int direct_accumulate,
+                                                         int64_t slab_stride, float* __restrict__ dbias) {
   pr.resolve();
   constexpr int NTHR = 64 * WNN * WNK;
   constexpr int MT = TN / (32 * WNN), KT = TK / (32 * WNK);      // 32x32 tiles per wave along n and k
@@ -522,6 +523,8 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
     *reinterpret_cast<xbf16x4*>(plane0 + plane_elems + off) = q1;
     *reinterpret_cast<xbf16x4*>(plane0 + 2 * plane_elems + off) = q2;
   };
+  static_assert(NTHR % (TN / 4) == 0, "a thread must keep its dY column quad across passes");
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   auto stage = [&](int64_t r0, int buf) {
     __bf16* yb = wplanes + (size_t)buf * (PY + PX);
     __bf16* xb = yb + PY;
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
       const int i = tid + u * NTHR, r = i / (TN / 4), c4 = i - r * (TN / 4);
       f32x4 v = ny[u];
       if (r0 + r >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      bsum += v;                                 // column sums of dY (the bias gradient) ride along: c4 is fixed per thread
       split_store(v, yb, WG_ROWS * SY, r * SY + c4 * 4);
     }
 #pragma unroll
@@ -593,8 +597,8 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
     __syncthreads();
     buf ^= 1;
   }
-  // slab[split][N][K]; with a single split `slab` is dW itself (direct_accumulate: 1 = overwrite, 2 = add)
-  float* dst = slab + (size_t)blockIdx.y * N * K;
+  // slab[split][N*K (+N bias sums)]; with a single split `slab` is dW itself (direct_accumulate: 1 = overwrite, 2 = add)
+  float* dst = slab + (size_t)blockIdx.y * slab_stride;
 #pragma unroll
   for (int x = 0; x < MT; ++x)
 #pragma unroll
@@ -607,22 +611,38 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
         if (direct_accumulate == 2) v += dst[(size_t)n * K + k];
         dst[(size_t)n * K + k] = v;
       }
+  if (dbias && tk0 == 0) {                       // one k-tile column of workgroups owns the bias sums of its TN columns
+    float* red = reinterpret_cast<float*>(wplanes);          // the planes are dead: every wave passed the last barrier
+    constexpr int GROUPS = NTHR / (TN / 4);
+    const int c4 = tid % (TN / 4), grp = tid / (TN / 4);
+    *reinterpret_cast<f32x4*>(red + grp * TN + c4 * 4) = bsum;
+    __syncthreads();
+    if (tid < TN) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < GROUPS; ++q) t += red[q * TN + tid];
+      float* bdst = direct_accumulate ? dbias : dst + (size_t)N * K;
+      if (direct_accumulate == 2) t += bdst[tn0 + tid];
+      bdst[tn0 + tid] = t;
+    }
+  }
 }
 
 template <int TN, int TK, int WNN, int WNK>
 void launch_wgrad_x6(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
-                     int N, int K, int64_t rps, int direct) {
+                     int N, int K, int64_t rps, int direct, int64_t slab_stride, float* dbias) {
   const size_t lds = (size_t)2 * 3 * WG_ROWS * ((TN + 32) + (TK + 32)) * 2;
   (void)hipFuncSetAttribute((const void*)k_linear_wgrad_x6<TN, TK, WNN, WNK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
   hipLaunchKernelGGL((k_linear_wgrad_x6<TN, TK, WNN, WNK>), grid, dim3(64 * WNN * WNK), lds, st, dY, X, pr, target, M, N, K,
-                     rps, direct);
+                     rps, direct, slab_stride, dbias);
 }
 
 struct EpiStore {
   float* out; int accumulate;
+  float* out2; int64_t n4_first;          // elements past n4_first float4s go to out2 (the bias sums behind a dW slab)
   __device__ void operator()(int64_t i4, mmg_f4 v) const {
-    mmg_f4* o = reinterpret_cast<mmg_f4*>(out) + i4;
+    mmg_f4* o = i4 < n4_first ? reinterpret_cast<mmg_f4*>(out) + i4 : reinterpret_cast<mmg_f4*>(out2) + (i4 - n4_first);
     *o = accumulate ? (*o + v) : v;
   }
 };
@@ -723,19 +743,23 @@ extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const f
 extern "C" size_t mmg_linear_wgrad_ws_bytes(int64_t M, int N, int K) {
   if (M < 0 || N <= 0 || K <= 0 || N % 64 || K % 64) return 0;
   WgradPlan p = plan_wgrad(M, N, K);
-  return (size_t)p.n_split * N * K * 4 + 256;
+  return (size_t)p.n_split * ((size_t)N * K + N) * 4 + 256;       // + N: the optional bias sums behind every slab
 }
 
-extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, int64_t M,
-                                int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, float* dbias,
+                                int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(M >= 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "linear_wgrad: N=%d K=%d must be multiples of 64", N, K);
   MMG_CHECK_ARG(dW, "linear_wgrad: dW is null");
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    if (!accumulate) hipMemsetAsync(dW, 0, (size_t)N * K * 4, st);
+    if (!accumulate) {
+      hipMemsetAsync(dW, 0, (size_t)N * K * 4, st);
+      if (dbias) hipMemsetAsync(dbias, 0, (size_t)N * 4, st);
+    }
     return MMG_OK;
   }
   MMG_CHECK_ARG(dY && X && ws, "linear_wgrad: null buffer");
+  MMG_CHECK_ARG(!dbias || !fp32_mfma(), "linear_wgrad: the bias sums are produced by the bf16-split kernel only");
   const size_t need = mmg_linear_wgrad_ws_bytes(M, N, K);
   if (ws_bytes < need) {
     mmg_set_error("linear_wgrad: workspace %zu < %zu", ws_bytes, need);
@@ -747,12 +771,14 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
   dim3 grid((unsigned)p.n_tiles, (unsigned)p.n_split);
   const int direct = p.n_split == 1 ? (accumulate ? 2 : 1) : 0;     // small M: no slab, no reduce launch
   float* target = direct ? dW : slab;
+  const int64_t stride = (int64_t)N * K + (dbias ? N : 0);
   if (!fp32_mfma()) {
     // eight waves (two per SIMD: one stages while the other multiplies) wherever the tile has 8 sub-tiles
-    if (p.TN == 128 && p.TK == 128) launch_wgrad_x6<128, 128, 4, 2>(grid, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
-    else if (p.TN == 128) launch_wgrad_x6<128, 64, 4, 2>(grid, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
-    else if (p.TK == 128) launch_wgrad_x6<64, 128, 2, 4>(grid, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
-    else launch_wgrad_x6<64, 64, 2, 2>(grid, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
+    const int64_t rps = p.rows_per_split;
+    if (p.TN == 128 && p.TK == 128) launch_wgrad_x6<128, 128, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
+    else if (p.TN == 128) launch_wgrad_x6<128, 64, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
+    else if (p.TK == 128) launch_wgrad_x6<64, 128, 2, 4>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
+    else launch_wgrad_x6<64, 64, 2, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
   } else if (p.TN == 128 && p.TK == 128)
     hipLaunchKernelGGL((k_linear_wgrad<128, 128>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
   else if (p.TN == 128)
@@ -762,9 +788,8 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
   else
     hipLaunchKernelGGL((k_linear_wgrad<64, 64>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
   if (!direct) {
-    const int64_t n = (int64_t)N * K;
-    hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiStore>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4,
-                       p.n_split, EpiStore{dW, accumulate});
+    hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiStore>), dim3((unsigned)((stride / 4 + 15) / 16)), dim3(256), 0, st, slab,
+                       stride / 4, p.n_split, EpiStore{dW, accumulate, dbias, (int64_t)N * K / 4});
   }
   MMG_CHECK_LAUNCH("linear_wgrad");
   return MMG_OK;

@@ -456,9 +456,12 @@ class _Run:
 
     def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False, dx_into=None):
         """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one."""
-        self.acc(wname, ops.linear_wgrad(dy, x, pro), partial)
-        if bname is not None:
-            self.acc(bname, ops.col_reduce2(dy)[0].float(), partial)
+        if bname is not None:            # the bias gradient (column sums of dy) comes out of the same pass over dy
+            dW, db = ops.linear_wgrad(dy, x, pro, with_bias=True)
+            self.acc(wname, dW, partial)
+            self.acc(bname, db, partial)
+        else:
+            self.acc(wname, ops.linear_wgrad(dy, x, pro), partial)
         if need_dx:
             if dx_into is not None:
                 return ops.linear_fwd(dy, self.W(wname), w_kn=True, out=dx_into, accumulate=True)
@@ -581,8 +584,7 @@ class _Run:
         dyP = dy.get(ROW_TYPE)
         if dyP is not None and rec["rin"]:
             xP = x[ROW_TYPE]
-            dWsum = ops.linear_wgrad(dyP, xP)
-            dbsum = ops.col_reduce2(dyP)[0].float()
+            dWsum, dbsum = ops.linear_wgrad(dyP, xP, with_bias=True)
             add_dgrad(ROW_TYPE, dyP, rec["Wsum"])
             rels, dTs, off = [], [], 0
             buf = torch.empty(sum(r.n_cols for r in rec["rin"]), D, device=self.dev)

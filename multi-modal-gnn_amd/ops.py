@@ -7,6 +7,7 @@ fp32 (indices int32 unless stated); violations raise instead of silently copying
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -272,9 +273,13 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out
 
 
+_WGRAD_BIAS = os.environ.get("MMG_LINEAR_FP32", "0") in ("", "0")     # the bf16-split kernel produces the bias sums
+
+
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, out: Optional[torch.Tensor] = None,
-                 accumulate: bool = False):
-    """out[N,K] (+)= dy[M,N]^T @ pro(x)[M,K]."""
+                 accumulate: bool = False, with_bias: bool = False):
+    """out[N,K] (+)= dy[M,N]^T @ pro(x)[M,K].  with_bias: also return the column sums of dy ([N] float, the bias
+    gradient of the same layer), computed in the same pass over dy."""
     lib = _lib.load()
     M, N = dy.shape
     K = x.shape[1]
@@ -283,12 +288,17 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, o
     if out is None:
         out = torch.empty(N, K, dtype=torch.float32, device=x.device)
         accumulate = False
+    dbias = torch.empty(N, dtype=torch.float32, device=x.device) if (with_bias and _WGRAD_BIAS) else None
     nb = lib.mmg_linear_wgrad_ws_bytes(M, N, K)
     ws = workspace(nb, x.device)
     _tok = _pb("linear_wgrad")
-    check(lib.mmg_linear_wgrad(_p(dy), _p(x), _pro(pro), _p(out), M, N, K, int(accumulate), _p(ws, torch.uint8),
-                               ws.numel(), _stream()), "mmg_linear_wgrad")
+    check(lib.mmg_linear_wgrad(_p(dy), _p(x), _pro(pro), _p(out), _p(dbias), M, N, K, int(accumulate),
+                               _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_linear_wgrad")
     _pe(_tok, "linear_wgrad", 4 * (M * N + M * K + N * K), 2 * M * N * K)
+    if with_bias:
+        if dbias is None:
+            dbias = col_reduce2(dy)[0].float()
+        return out, dbias
     return out
 
 

@@ -270,6 +270,9 @@ def test_linear_wgrad_shapes(ops, dev, M, N, K):
     dy, x = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
     dW = ops.linear_wgrad(dy.to(dev), x.to(dev))
     assert rel(dW, dy.double().t() @ x.double()) <= 1e-5
+    dW2, db = ops.linear_wgrad(dy.to(dev), x.to(dev), with_bias=True)       # bias gradient from the same pass
+    assert torch.equal(dW2, dW)
+    assert rel(db, dy.double().sum(0)) <= 2e-6
 
 
 @pytest.mark.parametrize("M,N", [(1, 128), (50, 128), (1834, 64), (100000, 128), (777, 256)])
