@@ -128,6 +128,12 @@ typedef struct {
 #define MMG_LIN_W_KN 2
 int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
                    float* Y, int64_t M, int N, int K, int flags, void* stream);
+/* the same, plus col_sums[2,N] (fp64) = (sum_m Y, sum_m Y^2): the batch statistics of the BatchNorm that follows
+ * (src/model.py:95,99), taken in the GEMM epilogue instead of a second pass over Y */
+size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N);
+int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
+                         float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,
+                         size_t ws_bytes, void* stream);
 
 /* dW[N,K] (+)= dY[M,N]^T . prologue(X)[M,K]   (reduction over the M rows);
  * dbias (nullable, [N]) (+)= the column sums of dY -- the bias gradient of the same layer, from the same pass */

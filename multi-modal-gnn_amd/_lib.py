@@ -58,6 +58,8 @@ SIGNATURES = {
     "mmg_scatter_rows_ws_bytes": (_sz, [_P(RelT), _i32, _i64, _i32]),
     "mmg_scatter_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _vp, _sz, _vp]),
     "mmg_linear_fwd": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "mmg_linear_fwd_stats_ws_bytes": (_sz, [_i64, _i32]),
+    "mmg_linear_fwd_stats": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "mmg_linear_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32]),
     "mmg_linear_wgrad": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "mmg_col_reduce2_ws_bytes": (_sz, [_i64, _i32]),

@@ -322,6 +322,13 @@ int run_col_reduce(const float* A, const float* B, const ProDev& pr, const float
 
 }  // namespace
 
+// internal (gemm.hip): out[i] = sum over n_rows partial rows, one wave per output, fixed order
+extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream) {
+  hipLaunchKernelGGL(k_partial_sum, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, out, n, n_rows);
+  MMG_CHECK_LAUNCH("partial_sum");
+  return MMG_OK;
+}
+
 extern "C" size_t mmg_col_reduce2_ws_bytes(int64_t M, int N) {
   ColGeom g;
   if (M < 0 || !col_geom(M, N, &g)) return 0;

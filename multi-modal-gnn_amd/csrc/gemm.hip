@@ -153,9 +153,11 @@ typedef __bf16 xbf16x4 __attribute__((ext_vector_type(4)));
 template <int K, int WN>          // WN waves along N (32 columns each), 2 along M: 128 * WN threads
 __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restrict__ X, ProDev pr,
                                                             const float* __restrict__ W, const float* __restrict__ bias,
-                                                            float* __restrict__ Y, int64_t M, int N, int flags) {
+                                                            float* __restrict__ Y, int64_t M, int N, int flags,
+                                                            double* __restrict__ stat_partial) {
   pr.resolve();
   const int accumulate = flags & MMG_LIN_ACCUMULATE;
+  double cs1 = 0.0, cs2 = 0.0;          // column statistics of the output (BatchNorm batch stats) ride along: lane = column
   constexpr int LDP = K + 8;            // plane row stride in bf16 (K*2 + 16 bytes: fragment reads hit 64 distinct banks)
   constexpr int BN = 32 * WN, NK = K / 16, NTHR = 128 * WN;
   extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][0], acc, 0, 0, 0);
     }
     const int64_t row0 = tt * BM;
+    float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int64_t gr = row0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -275,29 +278,51 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
         float v = acc[i] + bv;
         if (accumulate) v += *dst;
         *dst = v;
+        t1 += v; t2 = fmaf(v, v, t2);
       }
     }
+    if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }     // 16 rows in fp32, tiles in fp64
     __syncthreads();                         // buf fully read, buf^1 fully written
   };
   for (; t < n_tiles; t += 2 * G) {
     tile_body(t, 0, nxa);
     if (t + G < n_tiles) tile_body(t + G, 1, nxb);
   }
+  if (stat_partial) {
+    // four partials per column (2 row-waves x 2 lane halves) -> one: partial[blockIdx.y][2][N], fixed order
+    double* red = reinterpret_cast<double*>(planes);          // the planes are dead: every wave passed the last barrier
+    red[((wm * 2 + h) * 2 + 0) * BN + wn * 32 + l31] = cs1;
+    red[((wm * 2 + h) * 2 + 1) * BN + wn * 32 + l31] = cs2;
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, c = tid % BN;
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v += red[(q * 2 + which) * BN + c];
+      stat_partial[((size_t)blockIdx.y * 2 + which) * N + blockIdx.x * BN + c] = v;
+    }
+  }
 }
 
-template <int K, int WN>
-int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
-                  int accumulate, hipStream_t st) {
-  constexpr int BN = 32 * WN;
+inline int64_t fwd_x6_rows(int64_t M, int N, int BN) {      // grid.y of the bf16-split forward (= partial stat rows)
   const int n_slices = N / BN;
   const int64_t n_tiles = (M + BM - 1) / BM;
   int64_t gy = 256 / n_slices;               // one persistent workgroup per CU
   if (gy < 1) gy = 1;
   if (gy > n_tiles) gy = n_tiles;
+  return gy;
+}
+
+template <int K, int WN>
+int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                  int accumulate, hipStream_t st, double* stat_partial = nullptr) {
+  constexpr int BN = 32 * WN;
+  const int n_slices = N / BN;
+  const int64_t gy = fwd_x6_rows(M, N, BN);
   const size_t lds = (size_t)2 * 3 * BM * (K + 8) * 2;
   (void)hipFuncSetAttribute((const void*)k_linear_fwd_x6<K, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((k_linear_fwd_x6<K, WN>), dim3((unsigned)n_slices, (unsigned)gy), dim3(128 * WN), lds, st, X, pr, W,
-                     bias, Y, M, N, accumulate);
+                     bias, Y, M, N, accumulate, stat_partial);
   return 0;
 }
 
@@ -697,9 +722,36 @@ int launch_small(const float* X, const ProDev& pr, const float* W, const float* 
 
 }  // namespace
 
+extern "C" int mmg_col_reduce2(const float* A, const float* B, double* out, int64_t M, int N, void* ws, size_t ws_bytes,
+                               void* stream);
+extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream);
+
+extern "C" size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N) {
+  if (M < 0 || N <= 0) return 0;
+  const size_t a = (size_t)256 * 2 * N * sizeof(double) + 256;       // <= 256 partial rows from the GEMM epilogue
+  const size_t b = mmg_col_reduce2_ws_bytes(M, N);                   // fallback: a separate column reduction
+  return a > b ? a : b;
+}
+
+extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
+                                    float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,
+                                    size_t ws_bytes, void* stream);
+
 extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias, float* Y,
                               int64_t M, int N, int K, int flags, void* stream) {
+  return mmg_linear_fwd_stats(X, pro, W, bias, Y, M, N, K, flags, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
+                                    float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,
+                                    size_t ws_bytes, void* stream) {
   const int accumulate = flags;           // the launchers forward the whole flag word
+  if (col_sums) {
+    MMG_CHECK_ARG(ws && ws_bytes >= mmg_linear_fwd_stats_ws_bytes(M, N), "linear_fwd_stats: workspace too small");
+    MMG_CHECK_ARG(M > 0, "linear_fwd_stats: M must be positive");
+  }
+  double* partial = col_sums ? (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+  bool stats_done = false;
   MMG_CHECK_ARG(M >= 0, "linear_fwd: M < 0");
   MMG_CHECK_ARG((flags & ~(MMG_LIN_ACCUMULATE | MMG_LIN_W_KN)) == 0, "linear_fwd: unknown flag bits");
   MMG_CHECK_ARG(K == 64 || K == 128 || K == 256, "linear_fwd: K=%d unsupported (64|128|256)", K);
@@ -716,11 +768,17 @@ extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const f
   } else if (K <= 128 && !fp32_mfma()) {
     // exact-product 6-term bf16 split on the bf16 matrix cores (MMG_LINEAR_FP32=1: the fp32-MFMA kernels below)
     if (K == 64) {
-      if (N % 128 == 0) launch_fwd_x6<64, 4>(X, pr, W, bias, Y, M, N, accumulate, st);
-      else launch_fwd_x6<64, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
+      if (N % 128 == 0) launch_fwd_x6<64, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+      else launch_fwd_x6<64, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
     } else {
-      if (N % 128 == 0) launch_fwd_x6<128, 4>(X, pr, W, bias, Y, M, N, accumulate, st);
-      else launch_fwd_x6<128, 2>(X, pr, W, bias, Y, M, N, accumulate, st);
+      if (N % 128 == 0) launch_fwd_x6<128, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+      else launch_fwd_x6<128, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+    }
+    if (col_sums) {     // partial[gy][2][N] -> col_sums[2][N]
+      const int rows = (int)fwd_x6_rows(M, N, N % 128 == 0 ? 128 : 64);
+      int rc2 = mmg_partial_sum(partial, col_sums, 2 * N, rows, stream);
+      if (rc2) return rc2;
+      stats_done = true;
     }
   } else if (K == 64) {
     if (N % 128 == 0) launch_fwd<64, 2, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
@@ -737,6 +795,8 @@ extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const f
     launch_fwd<256, 1, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
   }
   MMG_CHECK_LAUNCH("linear_fwd");
+  if (col_sums && !stats_done)            // small-M / fp32 kernels: a separate pass over Y
+    return mmg_col_reduce2(Y, nullptr, col_sums, M, N, ws, ws_bytes, stream);
   return MMG_OK;
 }
 

@@ -399,11 +399,13 @@ class _Run:
         return out
 
     # ======================================================================== encode_nodes
-    def bn_fold(self, y, mod: nn.BatchNorm1d, n_updates=1, sharded=False) -> ops.BNFold:
-        """Batch statistics (train) or running statistics (eval) folded to scale/shift."""
+    def bn_fold(self, y, mod: nn.BatchNorm1d, n_updates=1, sharded=False, sums=None) -> ops.BNFold:
+        """Batch statistics (train) or running statistics (eval) folded to scale/shift.  sums: the column sums of
+        y and y^2 when the producing kernel already took them."""
         count = y.shape[0]
         if self.T:
-            sums = ops.col_reduce2(y)
+            if sums is None:
+                sums = ops.col_reduce2(y)
             if sharded and self.comm is not None:
                 self.allreduce(sums)
                 count = self.plan.n_rows_global
@@ -420,11 +422,14 @@ class _Run:
         pt = self.m.patient_transform
         E = self.W(f"embeddings.{ROW_TYPE}.weight")
         off = self.plan.row_offset
-        z1 = ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach())
-        f1 = self.bn_fold(z1, pt[1], n_updates, sharded=True)
+        # the batch statistics of z1 / z2 come out of the GEMM epilogue (training mode)
+        z1, s1 = ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach(), with_stats=True) if self.T else \
+            (ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach()), None)
+        f1 = self.bn_fold(z1, pt[1], n_updates, sharded=True, sums=s1)
         pro1 = Pro(f1.scale, f1.shift, True, self.p, self.seed, 2 * call, off, self.seed_dev)
-        z2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1)
-        f2 = self.bn_fold(z2, pt[5], n_updates, sharded=True)
+        z2, s2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1, with_stats=True) if self.T else \
+            (ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1), None)
+        f2 = self.bn_fold(z2, pt[5], n_updates, sharded=True, sums=s2)
         pro2 = Pro(f2.scale, f2.shift, True, self.p, self.seed, 2 * call + 1, off, self.seed_dev)
         z3 = ops.linear_fwd(z2, pt[8].weight.detach(), pt[8].bias.detach(), pro=pro2)
         x0, rn = ops.l2norm_fwd(z3)

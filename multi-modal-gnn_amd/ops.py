@@ -253,8 +253,10 @@ def scatter_rows(rels: Sequence[Rel], n_rows: int, D: int, x: torch.Tensor):
 
 # ------------------------------------------------------------------------------------------ dense
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, pro: Optional[Pro] = None,
-               out: Optional[torch.Tensor] = None, accumulate: bool = False, w_kn: bool = False):
-    """out[M,N] (+)= pro(x)[M,K] @ W[N,K]^T + bias;  w_kn: W is stored [K,N] (out = x @ W), read in place."""
+               out: Optional[torch.Tensor] = None, accumulate: bool = False, w_kn: bool = False,
+               with_stats: bool = False):
+    """out[M,N] (+)= pro(x)[M,K] @ W[N,K]^T + bias;  w_kn: W is stored [K,N] (out = x @ W), read in place.
+    with_stats: also return fp64 [2,N] = (column sums, column sums of squares) of out, from the GEMM epilogue."""
     lib = _lib.load()
     M, K = x.shape
     N = W.shape[1] if w_kn else W.shape[0]
@@ -267,10 +269,18 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
     elif tuple(out.shape) != (M, N):
         raise ValueError("linear_fwd: out shape")
     _tok = _pb("linear_fwd")
-    check(lib.mmg_linear_fwd(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"), _p(out, name="out"),
-                             M, N, K, int(accumulate) | (2 if w_kn else 0), _stream()), "mmg_linear_fwd")
+    flags = int(accumulate) | (2 if w_kn else 0)
+    if with_stats:
+        sums = torch.empty(2, N, dtype=torch.float64, device=x.device)
+        ws = workspace(lib.mmg_linear_fwd_stats_ws_bytes(M, N), x.device)
+        check(lib.mmg_linear_fwd_stats(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"),
+                                       _p(out, name="out"), M, N, K, flags, _p(sums, torch.float64), _p(ws, torch.uint8),
+                                       ws.numel(), _stream()), "mmg_linear_fwd_stats")
+    else:
+        check(lib.mmg_linear_fwd(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"), _p(out, name="out"),
+                                 M, N, K, flags, _stream()), "mmg_linear_fwd")
     _pe(_tok, "linear_fwd", 4 * (M * K + N * K + M * N * (2 if accumulate else 1)), 2 * M * N * K)
-    return out
+    return (out, sums) if with_stats else out
 
 
 _WGRAD_BIAS = os.environ.get("MMG_LINEAR_FP32", "0") in ("", "0")     # the bf16-split kernel produces the bias sums

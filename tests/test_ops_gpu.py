@@ -229,6 +229,10 @@ def test_linear_fwd(ops, dev, M, N, K):
     # the weight stored [K, N] (data-gradient GEMMs read the forward weight in place): same arithmetic, same bits
     y3 = ops.linear_fwd(x.to(dev), W.t().contiguous().to(dev), b.to(dev), w_kn=True)
     assert torch.equal(y3, y)
+    y4, sums = ops.linear_fwd(x.to(dev), W.to(dev), b.to(dev), with_stats=True)   # BatchNorm statistics from the epilogue
+    assert torch.equal(y4, y)
+    yd = y.double().cpu()
+    assert rel(sums[0], yd.sum(0)) <= 1e-6 and rel(sums[1], (yd * yd).sum(0)) <= 1e-6
     assert rel(y, ref) <= 2e-6                     # the 6-term bf16 split keeps fp32 accuracy
 
 
