@@ -96,6 +96,11 @@ int mmg_rel_mask_build(const int32_t* rowptr, const int32_t* col, int64_t n_rows
 
 int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
                     float* out, int accumulate, void* stream);
+/* the same, plus col_sums[2,D] (fp64) = (sum_rows out, sum_rows out^2) of the FINAL output: the batch statistics of
+ * the per-type BatchNorm that follows the HeteroConv sum (src/model.py:258-262), from the gather epilogue */
+size_t mmg_gather_rows_stats_ws_bytes(int64_t n_rows, int D);
+int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                          double* col_sums, void* ws, size_t ws_bytes, void* stream);
 
 size_t mmg_scatter_rows_ws_bytes(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D);
 int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,

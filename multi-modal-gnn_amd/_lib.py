@@ -55,6 +55,8 @@ SIGNATURES = {
     "mmg_rel_mask_words": (_sz, [_i64, C.c_int32]),
     "mmg_rel_mask_build": (C.c_int, [_vp, _vp, _i64, C.c_int32, _vp, _vp, _vp]),
     "mmg_gather_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _i32, _vp]),
+    "mmg_gather_rows_stats_ws_bytes": (_sz, [_i64, _i32]),
+    "mmg_gather_rows_stats": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "mmg_scatter_rows_ws_bytes": (_sz, [_P(RelT), _i32, _i64, _i32]),
     "mmg_scatter_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _vp, _sz, _vp]),
     "mmg_linear_fwd": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),

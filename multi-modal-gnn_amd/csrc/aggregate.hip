@@ -817,7 +817,9 @@ __global__ __launch_bounds__(256) void k_mask_build(const int32_t* __restrict__ 
 template <int NK, int K1, int K2, bool ACCUM, int KH>
 __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_rows, int n_tile_total, int D,
                                                  float* __restrict__ out, const unsigned (*lut)[4],
-                                                 float (*rss)[3][32], float (*xch)[4][16][64]) {
+                                                 float (*rss)[3][32], float (*xch)[4][16][64],
+                                                 double* __restrict__ stat_partial) {
+  double cs1 = 0.0, cs2 = 0.0;       // column sums / sums of squares of the final output (lane = feature column)
   constexpr int KB = KH * (NK / 2), KE = KB + NK / 2;               // this wave's k-steps
   constexpr bool USE0 = KB < K1, USE1 = KB < K2 && KE > K1, USE2 = KE > K2;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -941,21 +943,37 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
     __syncthreads();
     if (KH == 0) {
       const unsigned vo = (unsigned)(((tile - t_beg) * 32 + 4 * h) * D + dcol) * 4u;
+      float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         float t = v[i] + xb[i][lane];
         if (ACCUM) t += pc[i];
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0);
+        if ((int64_t)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < n_rows) { t1 += t; t2 = fmaf(t, t, t2); }
       }
+      if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }
     }
 #pragma unroll
     for (int i = 0; i < NK / 4; ++i) mcur[i] = mnxt[i];
+  }
+  if (stat_partial) {                    // (a workgroup-uniform branch: both wave halves take it)
+    __syncthreads();                     // the exchange tiles are dead
+    double* red = reinterpret_cast<double*>(&xch[0][0][0][0]);      // [h][which][128]
+    if (KH == 0) {
+      red[(h * 2 + 0) * 128 + ft * 32 + l31] = cs1;
+      red[(h * 2 + 1) * 128 + ft * 32 + l31] = cs2;
+    }
+    __syncthreads();
+    if (KH == 0) {
+      const int which = tid >> 7, c = tid & 127;
+      stat_partial[((size_t)blockIdx.x * 2 + which) * D + blockIdx.y * 128 + c] = red[which * 128 + c] + red[(2 + which) * 128 + c];
+    }
   }
 }
 
 template <int NK, int K1, int K2, bool ACCUM>
 __global__ __launch_bounds__(512) void k_gather_bits(RelPack rp, int64_t n_rows, int n_tile_total, int D,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, double* __restrict__ stat_partial) {
   __shared__ __attribute__((aligned(16))) unsigned lut[256][4];
   __shared__ __attribute__((aligned(16))) float rss[8][3][32];
   __shared__ __attribute__((aligned(16))) float xch[2][4][16][64];
@@ -966,8 +984,8 @@ __global__ __launch_bounds__(512) void k_gather_bits(RelPack rp, int64_t n_rows,
       lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
   }
   __syncthreads();
-  if ((tid >> 8) == 0) gather_bits_body<NK, K1, K2, ACCUM, 0>(rp, n_rows, n_tile_total, D, out, lut, rss, xch);
-  else gather_bits_body<NK, K1, K2, ACCUM, 1>(rp, n_rows, n_tile_total, D, out, lut, rss, xch);
+  if ((tid >> 8) == 0) gather_bits_body<NK, K1, K2, ACCUM, 0>(rp, n_rows, n_tile_total, D, out, lut, rss, xch, stat_partial);
+  else gather_bits_body<NK, K1, K2, ACCUM, 1>(rp, n_rows, n_tile_total, D, out, lut, rss, xch, stat_partial);
 }
 
 // row-major bit planes: field [row][half][col / 16] (uint16) |= 1 << (4 + col % 8), half = (col % 16) / 8
@@ -1058,8 +1076,34 @@ int pack(const mmg_rel_t* rels, int n_rel, RelPack* rp, bool need_table, bool ne
 
 }  // namespace
 
+extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream);
+extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                                     double* col_sums, void* ws, size_t ws_bytes, void* stream);
+
+extern "C" size_t mmg_gather_rows_stats_ws_bytes(int64_t n_rows, int D) {
+  if (n_rows < 0 || D <= 0) return 0;
+  const size_t a = (size_t)256 * 2 * D * sizeof(double) + 256, b = mmg_col_reduce2_ws_bytes(n_rows, D);
+  return a > b ? a : b;
+}
+
 extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
                                void* stream) {
+  return mmg_gather_rows_stats(rels, n_rel, n_rows, D, out, accumulate, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                                     double* col_sums, void* ws, size_t ws_bytes, void* stream) {
+  if (col_sums) {
+    MMG_CHECK_ARG(n_rows > 0 && ws && ws_bytes >= mmg_gather_rows_stats_ws_bytes(n_rows, D),
+                  "gather_rows_stats: workspace too small");
+  }
+  double* partial = col_sums ? (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
+#define MMG_GATHER_TAIL(what)                                                                                 \
+  do {                                                                                                        \
+    MMG_CHECK_LAUNCH(what);                                                                                   \
+    if (col_sums) return mmg_col_reduce2(out, nullptr, col_sums, n_rows, D, ws, ws_bytes, stream);            \
+    return MMG_OK;                                                                                            \
+  } while (0)
   MMG_CHECK_ARG(mmg_valid_D(D), "gather_rows: D=%d unsupported (64|128|256)", D);
   MMG_CHECK_ARG(n_rows >= 0 && n_rows < 2147483647LL / 64, "gather_rows: n_rows out of range");
   MMG_CHECK_ARG(out || n_rows == 0, "gather_rows: out is null");
@@ -1087,8 +1131,7 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
       for (int r = 0; r < n_rel; ++r) { rb.r[r].acc_off = off; off += (rels[r].n_cols + 15) & ~15; }
       if (vp <= 12 * 16) launch_gather_bf16<12>(rb, n_rows, D, out, accumulate, st);
       else launch_gather_bf16<20>(rb, n_rows, D, out, accumulate, st);
-      MMG_CHECK_LAUNCH("gather_rows(bf16)");
-      return MMG_OK;
+      MMG_GATHER_TAIL("gather_rows(bf16)");
     }
   }
   // bit-plane matrix-core kernel: simple relations in a layout with a static instance -- the eICU vocabulary
@@ -1105,9 +1148,10 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
       int g = 256 / n_dchunks;
       if (g > n_tiles) g = n_tiles;
       dim3 grid((unsigned)g, (unsigned)n_dchunks);
-      if (accumulate) hipLaunchKernelGGL((k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out);
-      else hipLaunchKernelGGL((k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out);
+      if (accumulate) hipLaunchKernelGGL((k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
+      else hipLaunchKernelGGL((k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       MMG_CHECK_LAUNCH("gather_rows(bits)");
+      if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
       return MMG_OK;
     }
     if (okb) {
@@ -1116,9 +1160,10 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
       int g = 256 / n_dchunks;
       if (g > n_tiles) g = n_tiles;
       dim3 grid((unsigned)g, (unsigned)n_dchunks);
-      if (accumulate) hipLaunchKernelGGL((k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out);
-      else hipLaunchKernelGGL((k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out);
+      if (accumulate) hipLaunchKernelGGL((k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
+      else hipLaunchKernelGGL((k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       MMG_CHECK_LAUNCH("gather_rows(bits)");
+      if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
       return MMG_OK;
     }
   }
@@ -1142,15 +1187,14 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
       (void)hipFuncSetAttribute((const void*)k_gather_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL_LDS_BUDGET);
       hipLaunchKernelGGL(k_gather_lds<1>, grid, dim3(GL_THREADS), lds, st, rp, n_rows, rows_per_blk, D, out, accumulate);
     }
-    MMG_CHECK_LAUNCH("gather_rows(lds)");
-    return MMG_OK;
+    MMG_GATHER_TAIL("gather_rows(lds)");
   }
   const unsigned nb = (unsigned)((n_rows + 3) / 4);
   if (D == 64) hipLaunchKernelGGL(k_gather<1>, dim3(nb), dim3(256), 0, st, rp, n_rows, out, accumulate);
   else if (D == 128) hipLaunchKernelGGL(k_gather<2>, dim3(nb), dim3(256), 0, st, rp, n_rows, out, accumulate);
   else hipLaunchKernelGGL(k_gather<4>, dim3(nb), dim3(256), 0, st, rp, n_rows, out, accumulate);
-  MMG_CHECK_LAUNCH("gather_rows");
-  return MMG_OK;
+  MMG_GATHER_TAIL("gather_rows");
+#undef MMG_GATHER_TAIL
 }
 
 extern "C" size_t mmg_scatter_rows_ws_bytes(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {

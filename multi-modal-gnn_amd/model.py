@@ -521,9 +521,14 @@ class _Run:
             for r, nme in zip(rin, names):
                 Tv = ops.linear_fwd(x[r.other], self.W(nme + ".lin_l.weight"))
                 rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv, simple=r.simple, mask_r=r.mask_r))
-            ops.gather_rows(rels, P, D, yP, accumulate=True)
+            ysums = None
+            if self.T and self.m.use_batch_norm and P > 0:       # BatchNorm statistics of y_P from the gather epilogue
+                _, ysums = ops.gather_rows(rels, P, D, yP, accumulate=True, with_stats=True)
+            else:
+                ops.gather_rows(rels, P, D, yP, accumulate=True)
             y[ROW_TYPE] = yP
             rec["Wsum"] = Wsum
+            rec["ysums"] = ysums
         # ---- dst = vocab type v: y_v = mean_scatter(x_P) W_l^T + b + x_v W_r^T   (summed over relations into v)
         if rout:
             aggs, rels, off = [], [], 0
@@ -550,7 +555,8 @@ class _Run:
             if t not in y:
                 continue
             sharded = t == ROW_TYPE
-            fold = self.bn_fold(y[t], self.m.batch_norms[l][t], 1, sharded) if self.m.use_batch_norm else None
+            fold = self.bn_fold(y[t], self.m.batch_norms[l][t], 1, sharded,
+                                sums=rec.get("ysums") if t == ROW_TYPE else None) if self.m.use_batch_norm else None
             pro = Pro(fold.scale if fold else None, fold.shift if fold else None, True, p, self.seed,
                       SITE_CONV + 8 * l + ti, plan.row_offset if sharded else 0, self.seed_dev)
             out[t] = ops.affine_act_drop(y[t], pro)

@@ -220,7 +220,8 @@ def rel_mask_build(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int):
     return mask_t, mask_r
 
 
-def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, accumulate: bool):
+def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, accumulate: bool, with_stats: bool = False):
+    """with_stats: also return fp64 [2,D] = (column sums, column sums of squares) of the final `out`."""
     lib = _lib.load()
     if tuple(out.shape) != (n_rows, D):
         raise ValueError("gather_rows: out shape")
@@ -229,9 +230,15 @@ def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, acc
             raise ValueError("gather_rows: rowptr length")
     arr = _rels(rels, D, need_table=True)
     _tok = _pb("gather_rows")
-    check(lib.mmg_gather_rows(arr, len(rels), n_rows, D, _p(out), int(accumulate), _stream()), "mmg_gather_rows")
+    if with_stats:
+        sums = torch.empty(2, D, dtype=torch.float64, device=out.device)
+        ws = workspace(lib.mmg_gather_rows_stats_ws_bytes(n_rows, D), out.device)
+        check(lib.mmg_gather_rows_stats(arr, len(rels), n_rows, D, _p(out), int(accumulate), _p(sums, torch.float64),
+                                        _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_gather_rows_stats")
+    else:
+        check(lib.mmg_gather_rows(arr, len(rels), n_rows, D, _p(out), int(accumulate), _stream()), "mmg_gather_rows")
     _pe(_tok, "gather_rows", _agg_bytes(rels, n_rows, D, accumulate), 0)
-    return out
+    return (out, sums) if with_stats else out
 
 
 def scatter_rows(rels: Sequence[Rel], n_rows: int, D: int, x: torch.Tensor):

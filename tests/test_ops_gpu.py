@@ -193,8 +193,9 @@ def test_aggregates_simple_graph_paths(ops, dev, D, n_rows):
     ops.gather_rows(grels, n_rows, D, o, accumulate=True)
     assert rel(o, gref + base.double()) <= 1e-6
     o2 = torch.empty(n_rows, D, device=dev)
-    ops.gather_rows(grels, n_rows, D, o2, accumulate=False)
+    _, gs = ops.gather_rows(grels, n_rows, D, o2, accumulate=False, with_stats=True)
     assert rel(o2, gref) <= 1e-6
+    assert rel(gs[0], gref.sum(0)) <= 2e-6 and rel(gs[1], (gref * gref).sum(0)) <= 2e-6      # epilogue statistics
     o3 = torch.empty(n_rows, D, device=dev)                 # first relation alone (last layer's backward)
     ops.gather_rows(grels[:1], n_rows, D, o3, accumulate=False)
     assert rel(o3, gref0) <= 1e-6
