@@ -326,52 +326,66 @@ int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float*
   return 0;
 }
 
-// Small M (the vocab-side tables: 50..200 rows): one wave per 32x32 output tile, both operands
-// straight from L2 into registers -- no LDS, no barrier, M/32 x N/32 independent waves.
+// Small M (the vocab-side tables: 50..200 rows): one 256-thread workgroup per 32x32 output tile, the k axis split
+// over its four waves (and over the lane halves inside a wave), every operand load issued up front straight from
+// L2 into registers, the four partial tiles summed through LDS.  These launches are pure latency (a dependent chain
+// load -> MFMAs -> store): a quarter of the chain per wave, one load round trip.
 template <int K>
-__global__ __launch_bounds__(64) void k_linear_small(const float* __restrict__ X, ProDev pr,
-                                                     const float* __restrict__ W, const float* __restrict__ bias,
-                                                     float* __restrict__ Y, int64_t M, int N, int flags) {
+__global__ __launch_bounds__(256) void k_linear_small(const float* __restrict__ X, ProDev pr,
+                                                      const float* __restrict__ W, const float* __restrict__ bias,
+                                                      float* __restrict__ Y, int64_t M, int N, int flags) {
   pr.resolve();
+  __shared__ float part[4][16][64];
   const int accumulate = flags & MMG_LIN_ACCUMULATE;
   const bool wkn = (flags & MMG_LIN_W_KN) != 0;
-  const int lane = threadIdx.x, h = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  constexpr int KW = K / 8;                       // k values per (wave, lane half)
+  const int kb = wid * (K / 4) + h * KW;
   const int n0 = blockIdx.x * 32;
   const int64_t row0 = (int64_t)blockIdx.y * 32;
   const int64_t ar = row0 + l31;
-  const float* xp = X + (size_t)(ar < M ? ar : 0) * K + h * (K / 2);
-  const float* wp = wkn ? W + (size_t)(h * (K / 2)) * N + n0 + l31 : W + (size_t)(n0 + l31) * K + h * (K / 2);
+  const float* xp = X + (size_t)(ar < M ? ar : 0) * K + kb;
+  const float* wp = wkn ? W + (size_t)kb * N + n0 + l31 : W + (size_t)(n0 + l31) * K + kb;
+  f32x4 a[KW / 4], w[KW / 4];
+#pragma unroll
+  for (int q = 0; q < KW / 4; ++q) {
+    a[q] = *reinterpret_cast<const f32x4*>(xp + q * 4);
+    if (wkn) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[q][j] = wp[(size_t)(q * 4 + j) * N];
+    } else {
+      w[q] = *reinterpret_cast<const f32x4*>(wp + q * 4);
+    }
+  }
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 4
-  for (int q = 0; q < K / 8; ++q) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(xp + q * 4);
-    f32x4 w;
-    if (wkn) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = wp[(size_t)(q * 4 + j) * N];
-    } else {
-      w = *reinterpret_cast<const f32x4*>(wp + q * 4);
-    }
+  for (int q = 0; q < KW / 4; ++q) {
     if (pr.scale || pr.relu || pr.p > 0.f) {
-      const int k0 = h * (K / 2) + q * 4;
+      const int k0 = kb + q * 4;
       f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
       if (pr.scale) { s4 = *reinterpret_cast<const f32x4*>(pr.scale + k0); sh4 = *reinterpret_cast<const f32x4*>(pr.shift + k0); }
-      mmg_pro_apply4(pr, a, s4, sh4, ar, k0, K);
+      mmg_pro_apply4(pr, a[q], s4, sh4, ar, k0, K);
     }
-    if (ar >= M) a = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ar >= M) a[q] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], w[j], acc, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], w[q][j], acc, 0, 0, 0);
   }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) part[wid][i][lane] = acc[i];
+  __syncthreads();
+  // wave w finishes accumulator registers 4w .. 4w+3 (rows (i & 3) + 8 w + 4 h)
   const int col = n0 + l31;
   const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int e = 0; e < 4; ++e) {
+    const int i = 4 * wid + e;
+    const float v0 = part[0][i][lane] + part[1][i][lane] + part[2][i][lane] + part[3][i][lane];
     const int64_t gr = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
     if (gr < M) {
       float* dst = Y + (size_t)gr * N + col;
-      float v = acc[i] + bv;
+      float v = v0 + bv;
       if (accumulate) v += *dst;
       *dst = v;
     }
@@ -715,7 +729,7 @@ inline bool fp32_mfma() {
 template <int K>
 int launch_small(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                  int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL((k_linear_small<K>), dim3((unsigned)(N / 32), (unsigned)((M + 31) / 32)), dim3(64), 0, st, X, pr, W,
+  hipLaunchKernelGGL((k_linear_small<K>), dim3((unsigned)(N / 32), (unsigned)((M + 31) / 32)), dim3(256), 0, st, X, pr, W,
                      bias, Y, M, N, accumulate);
   return 0;
 }
