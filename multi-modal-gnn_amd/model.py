@@ -265,6 +265,7 @@ class _Run:
         self.grads: Dict[str, torch.Tensor] = {}
         self.partial = set()         # param grads that are per-shard partial sums (need the final all-reduce)
         self.tape = {}
+        self._nbt = {}               # BatchNorm step counters to advance: {id(module): [buffer, increment]}
         self.pairs = None
         for t in self.plan.node_types:
             if t not in model.embeddings:
@@ -279,7 +280,8 @@ class _Run:
 
     def acc(self, name, g, partial=False):
         if name in self.grads:
-            self.grads[name] = self.grads[name] + g
+            if g is not self.grads[name]:            # (a producer that accumulated in place hands the same tensor back)
+                self.grads[name] = self.grads[name] + g
         else:
             self.grads[name] = g
         if partial:
@@ -313,7 +315,20 @@ class _Run:
         return {t: o for t, o in zip(self.out_types, outs)}
 
     # ======================================================================== forward driver
+    def _bump_counters(self):
+        by_inc = {}
+        for buf, inc in self._nbt.values():
+            by_inc.setdefault(inc, []).append(buf)
+        for inc, bufs in by_inc.items():
+            torch._foreach_add_(bufs, inc)           # one multi-tensor launch for all num_batches_tracked buffers
+        self._nbt = {}
+
     def run_forward(self, mode):
+        outs = self._run_forward(mode)
+        self._bump_counters()
+        return outs
+
+    def _run_forward(self, mode):
         T, plan = self.T, self.plan
         if mode == "encode":
             enc = self.enc_fwd(0, 1)
@@ -413,7 +428,8 @@ class _Run:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {list(y.shape)}")
             fold = ops.bn_finalize(sums, count, mod.weight.detach(), mod.bias.detach(), mod.running_mean,
                                    mod.running_var, True, n_updates)
-            mod.num_batches_tracked += n_updates
+            ent = self._nbt.setdefault(id(mod), [mod.num_batches_tracked, 0])           # bumped once, together
+            ent[1] += int(n_updates)
             return fold
         return ops.bn_finalize(None, count, mod.weight.detach(), mod.bias.detach(), mod.running_mean, mod.running_var,
                                False, 0)
@@ -461,12 +477,18 @@ class _Run:
 
     def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False, dx_into=None):
         """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one."""
+        gw = self.grads.get(wname)       # a second contribution (the encoder runs twice) accumulates inside the kernel
         if bname is not None:            # the bias gradient (column sums of dy) comes out of the same pass over dy
-            dW, db = ops.linear_wgrad(dy, x, pro, with_bias=True)
+            gb = self.grads.get(bname)
+            if gw is not None and gb is not None:
+                ops.linear_wgrad(dy, x, pro, out=gw, accumulate=True, with_bias=True, bias_out=gb)
+                dW, db = gw, gb
+            else:
+                dW, db = ops.linear_wgrad(dy, x, pro, with_bias=True)
             self.acc(wname, dW, partial)
             self.acc(bname, db, partial)
         else:
-            self.acc(wname, ops.linear_wgrad(dy, x, pro), partial)
+            self.acc(wname, ops.linear_wgrad(dy, x, pro, out=gw, accumulate=gw is not None), partial)
         if need_dx:
             if dx_into is not None:
                 return ops.linear_fwd(dy, self.W(wname), w_kn=True, out=dx_into, accumulate=True)
@@ -679,8 +701,13 @@ class _Run:
         bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps, io_perm=perm, dpred_sorted=dsorted)
         for which, src, want_low in (("edge_predictor", rec["fin"], False), ("tabular_mlp", rec["init"], True)):
             head, w1a, w1b, xP = rec[which]
-            g = ops.Head(torch.zeros_like(head.A), torch.zeros_like(head.B), torch.zeros_like(head.W2),
-                         torch.zeros_like(head.b2), torch.zeros_like(head.W3), torch.zeros_like(head.b3))
+            small = [head.B, head.W2, head.b2, head.W3, head.b3]          # one zero-fill for the five small gradients
+            flat = torch.zeros(sum(t.numel() for t in small), device=self.dev)
+            views, o = [], 0
+            for t in small:
+                views.append(flat[o:o + t.numel()].view(t.shape))
+                o += t.numel()
+            g = ops.Head(torch.zeros_like(head.A), *views)
             sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
             ops.pair_head_bwd(head, g, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr,
                               want_low, n_lab, self.p, self.seed, ids, dsorted,

@@ -294,7 +294,7 @@ _WGRAD_BIAS = os.environ.get("MMG_LINEAR_FP32", "0") in ("", "0")     # the bf16
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, out: Optional[torch.Tensor] = None,
-                 accumulate: bool = False, with_bias: bool = False):
+                 accumulate: bool = False, with_bias: bool = False, bias_out: Optional[torch.Tensor] = None):
     """out[N,K] (+)= dy[M,N]^T @ pro(x)[M,K].  with_bias: also return the column sums of dy ([N] float, the bias
     gradient of the same layer), computed in the same pass over dy."""
     lib = _lib.load()
@@ -305,7 +305,9 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, o
     if out is None:
         out = torch.empty(N, K, dtype=torch.float32, device=x.device)
         accumulate = False
-    dbias = torch.empty(N, dtype=torch.float32, device=x.device) if (with_bias and _WGRAD_BIAS) else None
+    dbias = None
+    if with_bias and _WGRAD_BIAS:
+        dbias = bias_out if (bias_out is not None and accumulate) else torch.empty(N, dtype=torch.float32, device=x.device)
     nb = lib.mmg_linear_wgrad_ws_bytes(M, N, K)
     ws = workspace(nb, x.device)
     _tok = _pb("linear_wgrad")
@@ -315,6 +317,8 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, o
     if with_bias:
         if dbias is None:
             dbias = col_reduce2(dy)[0].float()
+            if bias_out is not None and accumulate:
+                dbias = bias_out.add_(dbias)
         return out, dbias
     return out
 
