@@ -531,9 +531,20 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thr_keep = mmg_keep_threshold(drop_p);
   const uint32_t key1 = mmg_rng_key(seed, SITE_H1), key2 = mmg_rng_key(seed, SITE_H2);
-  float w2b[32];                     // A operand: W2[unit = l31][k = 32 h + s]
+  // A operand: W2[unit = l31][k = 16 ks + 8 h + j] as three exact bf16 pieces (the 6-term split of gemm.hip: the
+  // fp32 matrix instruction shares the vector ALU's multipliers -- its 2048 cycles per tile ADD to the VALU time of
+  // this VALU-heavy kernel -- while the bf16 matrix pipe runs beside it)
+  pbf16x8 w2p[4][3];
 #pragma unroll
-  for (int s = 0; s < 32; ++s) w2b[s] = H.W2[l31 * 64 + 32 * h + s];
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = H.W2[l31 * 64 + 16 * ks + 8 * h + j];
+      const __bf16 a = (__bf16)v;
+      const float r1 = v - (float)a;
+      const __bf16 b = (__bf16)r1;
+      w2p[ks][0][j] = a; w2p[ks][1][j] = b; w2p[ks][2][j] = (__bf16)(r1 - (float)b);
+    }
   float b2r[16], w3r[16];            // this lane's 16 units: crow(r, h)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { b2r[r] = H.b2[crow(r, h)]; w3r[r] = H.W3[crow(r, h)]; }
@@ -564,12 +575,12 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
   auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg) {
     const int pp = m.p_i >= 0 ? m.p_i : 0;
     *dg = deg[pp];
-    const float* ap = H.A + (size_t)pp * 64 + 32 * h;
-    const float* bp = H.B + (size_t)m.l_i * 64 + 32 * h;
+    const float* ap = H.A + (size_t)pp * 64 + 8 * h;
+    const float* bp = H.B + (size_t)m.l_i * 64 + 8 * h;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      ra[q] = *reinterpret_cast<const f32x4*>(ap + q * 4);
-      if (!n_labs_lds) rb[q] = *reinterpret_cast<const f32x4*>(bp + q * 4);
+    for (int q = 0; q < 8; ++q) {              // q = 2 ks + half-chunk: floats 16 ks + 8 h + 4 (q & 1) ..
+      ra[q] = *reinterpret_cast<const f32x4*>(ap + (q >> 1) * 16 + (q & 1) * 4);
+      if (!n_labs_lds) rb[q] = *reinterpret_cast<const f32x4*>(bp + (q >> 1) * 16 + (q & 1) * 4);
     }
   };
   int k2 = load_k(wave_id + 2 * n_waves);
@@ -589,22 +600,40 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
     m0 = m1; m1 = m2; k2 = k3;
     if (__ballot(active) == 0ull) continue;
     if (n_labs_lds) {
-      const float* bl = Bs + mc.l_i * PF_LDB + 32 * h;
+      const float* bl = Bs + mc.l_i * PF_LDB + 8 * h;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) cb[q] = *reinterpret_cast<const f32x4*>(bl + q * 4);
+      for (int q = 0; q < 8; ++q) cb[q] = *reinterpret_cast<const f32x4*>(bl + (q >> 1) * 16 + (q & 1) * 4);
     }
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {                    // one aligned RNG group of 4 per q: one hash
-      f32x4 x;
+    for (int ks = 0; ks < 4; ++ks) {                 // 16 h1 columns per k-step, this lane: 16 ks + 8 h + 0..7
+      float x8[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[j] = fmaxf(ca[q][j] + cb[q][j], 0.f);
-      if (drop_p > 0.f) mmg_drop4(x, key1, mc.pid * 64ull + (uint64_t)(32 * h + q * 4), thr_keep, inv_keep);
+      for (int c = 0; c < 2; ++c) {                  // one aligned RNG group of 4 per chunk: one hash
+        f32x4 x;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w2b[q * 4 + j], x[j], acc, 0, 0, 0);   // C^T: lane = pair, reg = unit
+        for (int j = 0; j < 4; ++j) x[j] = fmaxf(ca[2 * ks + c][j] + cb[2 * ks + c][j], 0.f);
+        if (drop_p > 0.f) mmg_drop4(x, key1, mc.pid * 64ull + (uint64_t)(16 * ks + 8 * h + 4 * c), thr_keep, inv_keep);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x8[4 * c + j] = x[j];
+      }
+      pbf16x8 x1, x2, x3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 a = (__bf16)x8[j];
+        const float r1 = x8[j] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        x1[j] = a; x2[j] = b; x3[j] = (__bf16)(r1 - (float)b);
+      }
+      // C^T: lane = pair, reg = unit.  W2 . h1^T, six exact products, small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[ks][2], x1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[ks][0], x3, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[ks][1], x2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[ks][1], x1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[ks][0], x2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2p[ks][0], x1, acc, 0, 0, 0);
     }
     // lane = pair l31, register r = unit crow(r, h) = (r & 3) + 8 (r >> 2) + 4 h
     float part = 0.f;
