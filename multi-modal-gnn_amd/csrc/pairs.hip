@@ -481,19 +481,48 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
       if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
     }
   }
-  // ---- final flush of the per-wave accumulators
+  // ---- final flush: the four waves' accumulators are summed through LDS first (one workgroup = one set of global
+  //      atomics: every dW2 / dB address is hit once per workgroup, not once per wave)
+  __syncthreads();                                   // every wave is done with its tile buffers in `sm`
+  float* red = sm;                                   // [(2 + 2 LT) x 16 regs][64 lanes], the waves add in turn
+  constexpr int NR = (2 + 2 * LT) * 16;
+  static_assert(NR * 64 <= 4 * WAVE_LDS, "reduction tile must fit the per-wave buffers");
+  for (int w = 0; w < 4; ++w) {
+    if (wid == w) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int u = crow(r, h);
-    atomicAdd(Gd.dW2 + u * 64 + l31, accW2[0][r]);
-    atomicAdd(Gd.dW2 + u * 64 + 32 + l31, accW2[1][r]);
+      for (int r = 0; r < 16; ++r) {
+        if (w == 0) {
+          red[r * 64 + lane] = accW2[0][r];
+          red[(16 + r) * 64 + lane] = accW2[1][r];
 #pragma unroll
-    for (int lt = 0; lt < LT; ++lt) {
-      const int lab = lt * 32 + u;
-      if (lab < n_labs) {
-        atomicAdd(Gd.dB + (size_t)lab * 64 + l31, accB[lt][0][r]);
-        atomicAdd(Gd.dB + (size_t)lab * 64 + 32 + l31, accB[lt][1][r]);
+          for (int lt = 0; lt < LT; ++lt) {
+            red[(32 + lt * 32 + r) * 64 + lane] = accB[lt][0][r];
+            red[(48 + lt * 32 + r) * 64 + lane] = accB[lt][1][r];
+          }
+        } else {
+          red[r * 64 + lane] += accW2[0][r];
+          red[(16 + r) * 64 + lane] += accW2[1][r];
+#pragma unroll
+          for (int lt = 0; lt < LT; ++lt) {
+            red[(32 + lt * 32 + r) * 64 + lane] += accB[lt][0][r];
+            red[(48 + lt * 32 + r) * 64 + lane] += accB[lt][1][r];
+          }
+        }
       }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NR * 64; e += 256) {         // element e = (slot, lane'): slot = which accumulator register
+    const int slot = e >> 6, ln = e & 63;
+    const float v = red[e];
+    const int hh = ln >> 5, c31 = ln & 31;
+    if (slot < 32) {                                 // dW2: slot = ct * 16 + r
+      const int ct = slot >> 4, r = slot & 15;
+      atomicAdd(Gd.dW2 + crow(r, hh) * 64 + ct * 32 + c31, v);
+    } else {                                         // dB: slot - 32 = lt * 32 + ct * 16 + r
+      const int q = slot - 32, lt = q >> 5, ct = (q >> 4) & 1, r = q & 15;
+      const int lab = lt * 32 + crow(r, hh);
+      if (lab < n_labs) atomicAdd(Gd.dB + (size_t)lab * 64 + ct * 32 + c31, v);
     }
   }
   w3acc += __shfl_xor(w3acc, 32, 64);
@@ -836,7 +865,7 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
   if (n_labs <= 128) {
     // MFMA path: one wave per 32-pair tile, 4 waves per workgroup, persistent grid
     int64_t g = ((n_pairs + TP - 1) / TP + 3) / 4;
-    if (g > 1024) g = 1024;
+    if (g > 512) g = 512;                // two resident workgroups per CU; fewer workgroups = fewer global atomics
     if (g < 1) g = 1;
 #define MMG_LAUNCH_PBWD(LT_)                                                                                          \
   hipLaunchKernelGGL((k_pair_bwd_mfma<LT_>), dim3((unsigned)g), dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, \
