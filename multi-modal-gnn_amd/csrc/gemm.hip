@@ -150,19 +150,24 @@ __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 xbf16x4 __attribute__((ext_vector_type(4)));
 
-template <int K, int WN>          // WN waves along N (32 columns each), 2 along M: 128 * WN threads
-__global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restrict__ X, ProDev pr,
-                                                            const float* __restrict__ W, const float* __restrict__ bias,
-                                                            float* __restrict__ Y, int64_t M, int N, int flags,
-                                                            double* __restrict__ stat_partial) {
-  pr.resolve();
-  const int accumulate = flags & MMG_LIN_ACCUMULATE;
+// Memory pipeline: every global access goes through a per-tile buffer descriptor (rows past M and tiles past the end
+// read 0 / are dropped by the range check), so the tile loop is straight-line code without a branch around a load or a
+// store and the compiler's vmcnt waits are exact: X runs two tiles ahead in registers, the epilogue's stores are never
+// waited for (gfx9 counts stores in vmcnt, in order: a conservative wait exposes the full store-acknowledge latency
+// once per tile, which is what the first version of this kernel did), and in accumulate mode the old output tile is
+// loaded INTO the accumulator before the next tile is staged, so its latency hides under the split.
+typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
+
+template <int K, int WN, bool PRO, bool ACC>   // WN waves along N (32 columns each) over a 32-row tile: 64 * WN threads
+__global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_fwd_x6(
+    const float* __restrict__ X, ProDev pr, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Y, int64_t M, int N, int flags, double* __restrict__ stat_partial) {
+  if (PRO) pr.resolve();
   double cs1 = 0.0, cs2 = 0.0;          // column statistics of the output (BatchNorm batch stats) ride along: lane = column
   constexpr int LDP = K + 8;            // plane row stride in bf16 (K*2 + 16 bytes: fragment reads hit 64 distinct banks)
-  constexpr int BN = 32 * WN, NK = K / 16, NTHR = 128 * WN;
+  constexpr int BN = 32 * WN, NK = K / 16, NTHR = 64 * WN, BM = 32;   // BM shadows the file-level tile height
   extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WN, wn = wid % WN;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int col = blockIdx.x * BN + wn * 32 + l31;
 
@@ -196,33 +201,48 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
   constexpr int ROWS_PER_PASS = NTHR / K4;
   constexpr int NP = BM / ROWS_PER_PASS;    // 16-B loads per thread per tile
   const int prow = tid / K4;
-  const int64_t n_tiles = (M + BM - 1) / BM;
-  f32x4 nxa[NP], nxb[NP];                   // two tiles of X in flight (64 KB per CU): tiles alternate between them
-  auto fetch = [&](int64_t tile, f32x4* nx) {
-    const int64_t row0 = tile * BM;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      int64_t gr = row0 + p * ROWS_PER_PASS + prow;
-      if (gr > M - 1) gr = M - 1;           // clamp (no exec-masked loads); such rows are never stored
-      nx[p] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + kc4 * 4);
-    }
-  };
-  auto stage = [&](int64_t tile, int buf, const f32x4* nx) {  // prologue + split + three plane writes
-    const int64_t row0 = tile * BM;
-    __bf16* pb = planes + (size_t)buf * 3 * BM * LDP;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    const bool has_pro = pr.scale || pr.relu || pr.p > 0.f;
+  // prologue constants, loaded once (identity when a part is absent: x*1+0, max(x,-inf))
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  float floor_v = -__builtin_inff();
+  bool drop = false;
+  if (PRO) {
     if (pr.scale) {
       sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
       sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
     }
+    if (pr.relu) floor_v = 0.f;
+    drop = pr.p > 0.f;
+  }
+  const int64_t n_tiles = (M + BM - 1) / BM;
+  const int64_t G = gridDim.y, t0 = blockIdx.y;
+  if (t0 >= n_tiles) return;
+  const int n_my = (int)((n_tiles - t0 + G - 1) / G);      // tiles t0, t0+G, ... of this workgroup
+  auto rows_of = [&](int64_t tile) -> int {                // valid rows of a tile (0 past the end)
+    const int64_t r = M - tile * BM;
+    return r <= 0 ? 0 : (r < BM ? (int)r : BM);
+  };
+  f32x4 nxa[NP], nxb[NP];                   // two tiles of X in flight: tiles alternate between them
+  const int xvo = (prow * K + kc4 * 4) * 4;
+  auto fetch = [&](int64_t tile, f32x4* nx) {
+    const int rows = rows_of(tile);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X) + (size_t)(rows ? tile : 0) * BM * K, 0, rows * K * 4, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      nx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo, p * ROWS_PER_PASS * K * 4, 0));
+  };
+  auto stage = [&](int64_t tile, int buf, const f32x4* nx) {  // prologue + split + three plane writes
+    const int64_t row0 = tile * BM;
+    __bf16* pb = planes + (size_t)buf * 3 * BM * LDP;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int r = p * ROWS_PER_PASS + prow;
-      const int64_t gr = row0 + r < M ? row0 + r : M - 1;
       f32x4 v = nx[p];
-      if (has_pro) {
-        mmg_pro_apply4(pr, v, sc, sh, gr, kc4 * 4, K);
+      if (PRO) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), floor_v);
+        if (drop)
+          mmg_drop4(v, pr.key, (uint64_t)(pr.row_offset + row0 + r) * (uint64_t)K + (uint64_t)(kc4 * 4), pr.thr, pr.inv_keep);
       }
       xbf16x4 q0, q1, q2;
 #pragma unroll
@@ -237,25 +257,27 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
       *reinterpret_cast<xbf16x4*>(pb + (2 * BM + r) * LDP + kc4 * 4) = q2;
     }
   };
-  const int64_t G = gridDim.y;
-  int64_t t = blockIdx.y;
-  if (t >= n_tiles) return;
-  fetch(t, nxa);
-  stage(t, 0, nxa);
-  fetch(t + G < n_tiles ? t + G : t, nxa);          // tile t+G  (clamped re-reads past the end are never staged)
-  fetch(t + 2 * G < n_tiles ? t + 2 * G : t, nxb);  // tile t+2G
+  fetch(t0, nxa);
+  stage(t0, 0, nxa);
+  fetch(t0 + G, nxa);
+  fetch(t0 + 2 * G, nxb);
   __syncthreads();
+  const int yvo = ((4 * h) * N + wn * 32 + l31) * 4;     // C/D map: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+  const int c0 = blockIdx.x * BN;
   auto tile_body = [&](int64_t tt, int buf, f32x4* nx) {
     // nx holds tile tt+G (fetched two tiles ago); after staging it, the registers take tile tt+3G
-    const int64_t tn = tt + G;
-    if (tn < n_tiles) {
-      stage(tn, buf ^ 1, nx);                // the other buffer: its readers passed the barrier of the last tile
-      fetch(tn + 2 * G < n_tiles ? tn + 2 * G : tn, nx);
-    }
+    const int rows = rows_of(tt);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(
+        Y + (size_t)(rows ? tt : 0) * BM * N + c0, 0, rows ? (rows * N - c0) * 4 : 0, 0x00020000);
     f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + (wm * 32 + l31) * LDP + 8 * h;
+    for (int i = 0; i < 16; ++i)
+      acc[i] = ACC ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, yvo, ((i & 3) + 8 * (i >> 2)) * N * 4, 0))
+                   : 0.f;
+    stage(tt + G, buf ^ 1, nx);                // the other buffer: its readers passed the barrier of the last tile
+    fetch(tt + 3 * G, nx);
+    __builtin_amdgcn_sched_barrier(0);         // keep the fetch ahead of the matrix loop (the scheduler sinks it otherwise)
+    const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + l31 * LDP + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
       const xbf16x8 a1 = *reinterpret_cast<const xbf16x8*>(ap + ks * 16);
@@ -268,62 +290,71 @@ __global__ __launch_bounds__(128 * WN) void k_linear_fwd_x6(const float* __restr
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][0], acc, 0, 0, 0);
     }
-    const int64_t row0 = tt * BM;
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int64_t gr = row0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (gr < M) {
-        float* dst = Y + (size_t)gr * N + col;
-        float v = acc[i] + bv;
-        if (accumulate) v += *dst;
-        *dst = v;
-        t1 += v; t2 = fmaf(v, v, t2);
-      }
+      const int r = (i & 3) + 8 * (i >> 2);
+      const float v = acc[i] + bv;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, yvo, r * N * 4, 0);
+      const float vs = r + 4 * h < rows ? v : 0.f;
+      t1 += vs; t2 = fmaf(vs, vs, t2);
     }
     if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }     // 16 rows in fp32, tiles in fp64
     __syncthreads();                         // buf fully read, buf^1 fully written
   };
-  for (; t < n_tiles; t += 2 * G) {
-    tile_body(t, 0, nxa);
-    if (t + G < n_tiles) tile_body(t + G, 1, nxb);
+  // A tile index past the end is harmless (zero-sized descriptors).  The first pair is peeled: the loop is then entered
+  // with the same loads / stores in flight as on its back edge, and the wait counts the compiler derives (the minimum
+  // over both edges) are the steady-state ones.
+  tile_body(t0, 0, nxa);
+  tile_body(t0 + G, 1, nxb);
+  for (int i = 2; i < n_my; i += 2) {
+    tile_body(t0 + (int64_t)i * G, 0, nxa);
+    tile_body(t0 + (int64_t)(i + 1) * G, 1, nxb);
   }
   if (stat_partial) {
-    // four partials per column (2 row-waves x 2 lane halves) -> one: partial[blockIdx.y][2][N], fixed order
+    // two partials per column (the lane halves) -> one: partial[blockIdx.y][2][N], fixed order
     double* red = reinterpret_cast<double*>(planes);          // the planes are dead: every wave passed the last barrier
-    red[((wm * 2 + h) * 2 + 0) * BN + wn * 32 + l31] = cs1;
-    red[((wm * 2 + h) * 2 + 1) * BN + wn * 32 + l31] = cs2;
+    red[(h * 2 + 0) * BN + wn * 32 + l31] = cs1;
+    red[(h * 2 + 1) * BN + wn * 32 + l31] = cs2;
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, c = tid % BN;
-      double v = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v += red[(q * 2 + which) * BN + c];
-      stat_partial[((size_t)blockIdx.y * 2 + which) * N + blockIdx.x * BN + c] = v;
+    for (int e = tid; e < 2 * BN; e += NTHR) {
+      const int which = e / BN, c = e % BN;
+      stat_partial[((size_t)blockIdx.y * 2 + which) * N + blockIdx.x * BN + c] = red[which * BN + c] + red[(2 + which) * BN + c];
     }
   }
 }
 
 inline int64_t fwd_x6_rows(int64_t M, int N, int BN) {      // grid.y of the bf16-split forward (= partial stat rows)
   const int n_slices = N / BN;
-  const int64_t n_tiles = (M + BM - 1) / BM;
-  int64_t gy = 256 / n_slices;               // one persistent workgroup per CU
+  const int64_t n_tiles = (M + 31) / 32;
+  int64_t gy = 512 / n_slices;               // persistent workgroups, 52 KB of LDS each: two per CU
   if (gy < 1) gy = 1;
   if (gy > n_tiles) gy = n_tiles;
   return gy;
 }
 
-template <int K, int WN>
-int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
-                  int accumulate, hipStream_t st, double* stat_partial = nullptr) {
+template <int K, int WN, bool PRO, bool ACC>
+int launch_fwd_x6_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                    int flags, hipStream_t st, double* stat_partial) {
   constexpr int BN = 32 * WN;
   const int n_slices = N / BN;
   const int64_t gy = fwd_x6_rows(M, N, BN);
-  const size_t lds = (size_t)2 * 3 * BM * (K + 8) * 2;
-  (void)hipFuncSetAttribute((const void*)k_linear_fwd_x6<K, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((k_linear_fwd_x6<K, WN>), dim3((unsigned)n_slices, (unsigned)gy), dim3(128 * WN), lds, st, X, pr, W,
-                     bias, Y, M, N, accumulate, stat_partial);
+  const size_t lds = (size_t)2 * 3 * 32 * (K + 8) * 2;
+  (void)hipFuncSetAttribute((const void*)k_linear_fwd_x6<K, WN, PRO, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((k_linear_fwd_x6<K, WN, PRO, ACC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds, st, X,
+                     pr, W, bias, Y, M, N, flags, stat_partial);
   return 0;
+}
+
+template <int K, int WN>
+int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                  int flags, hipStream_t st, double* stat_partial = nullptr) {
+  const bool pro = pr.scale || pr.relu || pr.p > 0.f, acc = (flags & MMG_LIN_ACCUMULATE) != 0;
+  if (pro) return acc ? launch_fwd_x6_v<K, WN, true, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial)
+                      : launch_fwd_x6_v<K, WN, true, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial);
+  return acc ? launch_fwd_x6_v<K, WN, false, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial)
+             : launch_fwd_x6_v<K, WN, false, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial);
 }
 
 // Small M (the vocab-side tables: 50..200 rows): one 256-thread workgroup per 32x32 output tile, the k axis split
@@ -742,7 +773,7 @@ extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_
 
 extern "C" size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N) {
   if (M < 0 || N <= 0) return 0;
-  const size_t a = (size_t)256 * 2 * N * sizeof(double) + 256;       // <= 256 partial rows from the GEMM epilogue
+  const size_t a = (size_t)512 * 2 * N * sizeof(double) + 256;       // <= 512 partial rows from the GEMM epilogue
   const size_t b = mmg_col_reduce2_ws_bytes(M, N);                   // fallback: a separate column reduction
   return a > b ? a : b;
 }
