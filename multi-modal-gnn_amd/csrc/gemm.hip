@@ -536,12 +536,12 @@ __device__ __forceinline__ xbf16x8 tr_frag(const __bf16* p, int row_stride) {   
   return __builtin_bit_cast(xbf16x8, v);
 }
 
-template <int TN, int TK, int WNN, int WNK>      // WNN x WNK waves over the [TN, TK] output tile
+template <int TN, int TK, int WNN, int WNK, bool PRO>      // WNN x WNK waves over the [TN, TK] output tile
 __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float* __restrict__ dY, const float* __restrict__ X,
                                                          ProDev pr, float* __restrict__ slab, int64_t M, int N, int K,
                                                          int64_t rows_per_split, int direct_accumulate,
                                                          int64_t slab_stride, float* __restrict__ dbias) {
-  pr.resolve();
+  if (PRO) pr.resolve();
   constexpr int NTHR = 64 * WNN * WNK;
   constexpr int MT = TN / (32 * WNN), KT = TK / (32 * WNK);      // 32x32 tiles per wave along n and k
   static_assert(MT >= 1 && KT >= 1, "tile too small for the wave grid");
@@ -552,8 +552,13 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
   const int wn = wid / WNK, wk = wid % WNK;
   const int tiles_k = K / TK;
   const int tn0 = (blockIdx.x / tiles_k) * TN, tk0 = (blockIdx.x % tiles_k) * TK;
-  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_split;
-  const int64_t r_end = min(M, r_beg + rows_per_split);
+  // 32-row stages are dealt round-robin: workgroup y takes stages y, y + G, y + 2G, ...  At any moment the grid reads
+  // one contiguous window of dY and X (G x 16 KB each), which spreads over every HBM channel; a contiguous chunk per
+  // workgroup makes G streams advance in lockstep a fixed (power-of-two-ish) stride apart and pile onto few channels.
+  (void)rows_per_split;
+  const int64_t total_st = (M + WG_ROWS - 1) / WG_ROWS;
+  const int64_t G = gridDim.y;
+  const int n_st = (int64_t)blockIdx.y < total_st ? (int)((total_st - blockIdx.y + G - 1) / G) : 0;
 
   f32x16 acc[MT][KT];
 #pragma unroll
@@ -563,22 +568,33 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
+  // Memory pipeline: a ring of RING 32-row stages in registers on top of the double-buffered LDS planes (the stage
+  // time is far below the HBM latency: with one stage in flight the kernel ran at the pace of one round trip per 32
+  // rows).  All loads go through per-stage buffer descriptors (rows past the end read 0, stages past the end have a
+  // zero-sized descriptor), so the loop has no branch around a load and the vmcnt waits are exact.
+  constexpr int RING = 4;
   constexpr int NY = WG_ROWS * (TN / 4) / NTHR, NX = WG_ROWS * (TK / 4) / NTHR;   // 16-B loads per thread per stage
   static_assert(NY >= 1 && NX >= 1, "stage smaller than the workgroup");
-  f32x4 ny[NY], nxr[NX];
-  auto fetch = [&](int64_t r0) {                 // rows past the end are clamped and zeroed when staged
+  static_assert(NTHR % (TN / 4) == 0 && NTHR % (TK / 4) == 0, "a thread keeps its column quad across passes");
+  constexpr int RY = NTHR / (TN / 4), RX = NTHR / (TK / 4);      // rows covered per pass
+  const int yr = tid / (TN / 4), yc4 = tid % (TN / 4), xr = tid / (TK / 4), xc4 = tid % (TK / 4);
+  const int yvo = (yr * N + yc4 * 4) * 4, xvo = (xr * K + xc4 * 4) * 4;
+  f32x4 ny[RING][NY], nxr[RING][NX];
+  auto fetch = [&](int st, f32x4* fy, f32x4* fx) {
+    const int64_t r0 = ((int64_t)blockIdx.y + (int64_t)st * G) * WG_ROWS;
+    const int64_t left = M - r0;
+    const int rows = st < n_st ? (left < WG_ROWS ? (int)left : WG_ROWS) : 0;
+    const int64_t rb = rows ? r0 : 0;
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dY) + (size_t)rb * N + tn0, 0, rows ? (rows * N - tn0) * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(X) + (size_t)rb * K + tk0, 0, rows ? (rows * K - tk0) * 4 : 0, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < NY; ++u) {
-      const int i = tid + u * NTHR, r = i / (TN / 4), c4 = i - r * (TN / 4);
-      const int64_t gr = r0 + r < r_end ? r0 + r : r_end - 1;
-      ny[u] = *reinterpret_cast<const f32x4*>(dY + (size_t)gr * N + tn0 + c4 * 4);
-    }
+    for (int u = 0; u < NY; ++u)
+      fy[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ys, yvo, u * RY * N * 4, 0));
 #pragma unroll
-    for (int u = 0; u < NX; ++u) {
-      const int i = tid + u * NTHR, r = i / (TK / 4), c4 = i - r * (TK / 4);
-      const int64_t gr = r0 + r < r_end ? r0 + r : r_end - 1;
-      nxr[u] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + tk0 + c4 * 4);
-    }
+    for (int u = 0; u < NX; ++u)
+      fx[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, xvo, u * RX * K * 4, 0));
   };
   auto split_store = [&](f32x4 v, __bf16* plane0, int plane_elems, int off) {
     xbf16x4 q0, q1, q2;
@@ -593,33 +609,41 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
     *reinterpret_cast<xbf16x4*>(plane0 + plane_elems + off) = q1;
     *reinterpret_cast<xbf16x4*>(plane0 + 2 * plane_elems + off) = q2;
   };
-  static_assert(NTHR % (TN / 4) == 0, "a thread must keep its dY column quad across passes");
+  // prologue constants of this thread's column quad (identity when a part is absent: x*1+0, max(x,-inf))
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  float floor_v = -__builtin_inff();
+  bool drop = false;
+  if (PRO) {
+    if (pr.scale) {
+      sc = *reinterpret_cast<const f32x4*>(pr.scale + tk0 + xc4 * 4);
+      sh = *reinterpret_cast<const f32x4*>(pr.shift + tk0 + xc4 * 4);
+    }
+    if (pr.relu) floor_v = 0.f;
+    drop = pr.p > 0.f;
+  }
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  auto stage = [&](int64_t r0, int buf) {
+  auto stage = [&](int st, int buf, const f32x4* fy, const f32x4* fx) {
     __bf16* yb = wplanes + (size_t)buf * (PY + PX);
     __bf16* xb = yb + PY;
-    const bool has_pro = pr.scale || pr.relu || pr.p > 0.f;
+    const int64_t r0 = ((int64_t)blockIdx.y + (int64_t)st * G) * WG_ROWS;
 #pragma unroll
     for (int u = 0; u < NY; ++u) {
-      const int i = tid + u * NTHR, r = i / (TN / 4), c4 = i - r * (TN / 4);
-      f32x4 v = ny[u];
-      if (r0 + r >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      bsum += v;                                 // column sums of dY (the bias gradient) ride along: c4 is fixed per thread
-      split_store(v, yb, WG_ROWS * SY, r * SY + c4 * 4);
+      const f32x4 v = fy[u];                     // rows past the end arrive as zeros
+      bsum += v;                                 // column sums of dY (the bias gradient) ride along: the quad is fixed per thread
+      split_store(v, yb, WG_ROWS * SY, (yr + u * RY) * SY + yc4 * 4);
     }
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
-      const int i = tid + u * NTHR, r = i / (TK / 4), c4 = i - r * (TK / 4);
-      f32x4 v = nxr[u];
-      const int64_t gr = r0 + r;
-      if (gr < r_end && has_pro) {
-        const int k = tk0 + c4 * 4;
-        f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-        if (pr.scale) { s4 = *reinterpret_cast<const f32x4*>(pr.scale + k); sh4 = *reinterpret_cast<const f32x4*>(pr.shift + k); }
-        mmg_pro_apply4(pr, v, s4, sh4, gr, k, K);
+      f32x4 v = fx[u];
+      if (PRO) {
+        const int64_t gr = r0 + xr + u * RX;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), floor_v);
+        if (drop)
+          mmg_drop4(v, pr.key, (uint64_t)(pr.row_offset + gr) * (uint64_t)K + (uint64_t)(tk0 + xc4 * 4), pr.thr, pr.inv_keep);
+        // no zeroing of the rows past the end: their dY rows are zero, so they contribute 0 to every product
       }
-      if (gr >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      split_store(v, xb, WG_ROWS * SX, r * SX + c4 * 4);
+      split_store(v, xb, WG_ROWS * SX, (xr + u * RX) * SX + xc4 * 4);
     }
   };
   // transposing-read lane roles: group g = lane >> 4 fetches rows 8 (g >> 1) + q, columns 16 (g & 1) + 4 p
@@ -627,18 +651,19 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
   const int tr_row = 8 * (g >> 1) + q, tr_col = 16 * (g & 1) + 4 * p4;
   const int h = lane >> 5, l31 = lane & 31;
 
-  if (r_beg < r_end) {
-    fetch(r_beg);
-    stage(r_beg, 0);
-    if (r_beg + WG_ROWS < r_end) fetch(r_beg + WG_ROWS);
-  }
+  // stage s lives in ring slot s % RING and LDS buffer s & 1
+#pragma unroll
+  for (int j = 0; j < RING; ++j) fetch(j, ny[j], nxr[j]);
+  stage(0, 0, ny[0], nxr[0]);
+  fetch(RING, ny[0], nxr[0]);
   __syncthreads();
-  int buf = 0;
-  for (int64_t r0 = r_beg; r0 < r_end; r0 += WG_ROWS) {
-    if (r0 + WG_ROWS < r_end) {
-      stage(r0 + WG_ROWS, buf ^ 1);
-      if (r0 + 2 * WG_ROWS < r_end) fetch(r0 + 2 * WG_ROWS);
-    }
+  auto body = [&](int st, int j) {               // j = st % RING (compile-time after unrolling), RING is even: buf = j & 1
+    constexpr int dummy = 0; (void)dummy;
+    const int jn = (j + 1) % RING;
+    stage(st + 1, (j + 1) & 1, ny[jn], nxr[jn]);
+    fetch(st + 1 + RING, ny[jn], nxr[jn]);
+    __builtin_amdgcn_sched_barrier(0);           // keep the fetch ahead of the matrix loop
+    const int buf = j & 1;
     const __bf16* yb = wplanes + (size_t)buf * (PY + PX) + tr_row * SY + wn * (TN / WNN) + tr_col;
     const __bf16* xb = wplanes + (size_t)buf * (PY + PX) + PY + tr_row * SX + wk * (TK / WNK) + tr_col;
 #pragma unroll
@@ -665,7 +690,11 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
         }
     }
     __syncthreads();
-    buf ^= 1;
+  };
+  static_assert(RING % 2 == 0, "the LDS buffer parity must follow the ring slot");
+  for (int s = 0; s < n_st; s += RING) {         // stages past the end multiply zeros (at most RING - 1 per workgroup)
+#pragma unroll
+    for (int j = 0; j < RING; ++j) body(s + j, j);
   }
   // slab[split][N*K (+N bias sums)]; with a single split `slab` is dW itself (direct_accumulate: 1 = overwrite, 2 = add)
   float* dst = slab + (size_t)blockIdx.y * slab_stride;
@@ -698,14 +727,23 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
   }
 }
 
+template <int TN, int TK, int WNN, int WNK, bool PRO>
+void launch_wgrad_x6_v(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
+                       int N, int K, int64_t rps, int direct, int64_t slab_stride, float* dbias) {
+  const size_t lds = (size_t)2 * 3 * WG_ROWS * ((TN + 32) + (TK + 32)) * 2;
+  (void)hipFuncSetAttribute((const void*)k_linear_wgrad_x6<TN, TK, WNN, WNK, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+  hipLaunchKernelGGL((k_linear_wgrad_x6<TN, TK, WNN, WNK, PRO>), grid, dim3(64 * WNN * WNK), lds, st, dY, X, pr, target, M, N,
+                     K, rps, direct, slab_stride, dbias);
+}
+
 template <int TN, int TK, int WNN, int WNK>
 void launch_wgrad_x6(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
                      int N, int K, int64_t rps, int direct, int64_t slab_stride, float* dbias) {
-  const size_t lds = (size_t)2 * 3 * WG_ROWS * ((TN + 32) + (TK + 32)) * 2;
-  (void)hipFuncSetAttribute((const void*)k_linear_wgrad_x6<TN, TK, WNN, WNK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  hipLaunchKernelGGL((k_linear_wgrad_x6<TN, TK, WNN, WNK>), grid, dim3(64 * WNN * WNK), lds, st, dY, X, pr, target, M, N, K,
-                     rps, direct, slab_stride, dbias);
+  if (pr.scale || pr.relu || pr.p > 0.f)
+    launch_wgrad_x6_v<TN, TK, WNN, WNK, true>(grid, st, dY, X, pr, target, M, N, K, rps, direct, slab_stride, dbias);
+  else
+    launch_wgrad_x6_v<TN, TK, WNN, WNK, false>(grid, st, dY, X, pr, target, M, N, K, rps, direct, slab_stride, dbias);
 }
 
 struct EpiStore {
@@ -725,7 +763,8 @@ WgradPlan plan_wgrad(int64_t M, int N, int K) {
   p.n_tiles = (N / p.TN) * (K / p.TK);
   int64_t max_split = (M + WG_ROWS - 1) / WG_ROWS;
   if (max_split < 1) max_split = 1;
-  int64_t want = 512 / p.n_tiles;
+  static const int wg_target = [] { const char* e = getenv("MMG_WGRAD_WGS"); return e ? atoi(e) : 256; }();
+  int64_t want = wg_target / p.n_tiles;
   if (want < 1) want = 1;
   p.n_split = (int)(want < max_split ? want : max_split);
   if (M <= 256) p.n_split = 1;            // vocab-side tables: one workgroup per output tile, direct write
