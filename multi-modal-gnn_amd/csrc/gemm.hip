@@ -727,6 +727,178 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
   }
 }
 
+// Role-specialised variant for the plain (no prologue) 128 x 128 tile.  Waves 0..3 only multiply (a 64 x 64 quadrant
+// each, one wave per SIMD), waves 4..7 only stage (loads -> 3-way split -> LDS for stage s+1 while the multipliers work on
+// stage s).  The stagers transpose in registers: a stager thread owns an 8-row x 4-column block (8 coalesced 16-B loads),
+// splits it and writes, per piece and column, the 8 rows as ONE 16-B entry of a fragment-ordered plane
+// [operand][piece][8-row group][column (swizzled)][8 rows]; a multiplier lane fetches a whole MFMA operand fragment with
+// one conflict-free ds_read_b128: 24 reads per 48 MFMAs instead of 96 ds_read_b64_tr_b16 (which move 64 B/clk).
+// Ablations at [183400 x 128]^T [183400 x 128] (us): empty skeleton 12, loads only 31-33, stagers only 35, multipliers
+// only 33 (1075 MFMAs per wave: 42 clocks each against 32 issue-bound), staging + multiplying without loads 46, all 50.
+// Staging and multiplying still do not overlap fully (they share the VALU issue port and the LDS), and the fixed
+// part (launch, ring priming, slab write, tail) is a quarter of the kernel; the HBM floor of the 188 MB is ~31 us.
+__global__ __launch_bounds__(512) void k_linear_wgrad_ws(const float* __restrict__ dY, const float* __restrict__ X,
+                                                         float* __restrict__ slab, int64_t M, int N, int K,
+                                                         int direct_accumulate, int64_t slab_stride,
+                                                         float* __restrict__ dbias) {
+  constexpr int TN = 128, TK = 128;
+  constexpr int GRP = 128 * 8;                   // one (operand, piece, row group): 128 columns x 8 rows (bf16 elements)
+  constexpr int BUF = 2 * 3 * 4 * GRP;           // one stage: 2 operands x 3 pieces x 4 row groups = 48 KB
+  extern __shared__ __attribute__((aligned(16))) __bf16 wplanes[];   // [2 buffers][BUF]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_k = K / TK;
+  const int tn0 = (blockIdx.x / tiles_k) * TN, tk0 = (blockIdx.x % tiles_k) * TK;
+  const int64_t total_st = (M + WG_ROWS - 1) / WG_ROWS;
+  const int64_t G = gridDim.y;                   // stages are dealt round-robin (see k_linear_wgrad_x6)
+  const int n_st = (int64_t)blockIdx.y < total_st ? (int)((total_st - blockIdx.y + G - 1) / G) : 0;
+  constexpr int RING = 4;
+  const int n_pad = (n_st + RING - 1) / RING * RING;
+  float* dst = slab + (size_t)blockIdx.y * slab_stride;
+
+  if (wid >= 4) {
+    // ------------------------------------------------------------------ stagers: waves 4,5 stage dY, waves 6,7 stage X
+    const int op = wid >> 1 & 1;                             // wave-uniform
+    const int t = tid & 127, g = t >> 5, c4 = t & 31;        // 8-row group, column quad
+    const float* src = op ? X : dY;
+    const int ld = op ? K : N, c0 = op ? tk0 : tn0;
+    const int vo = (8 * g * ld + c4 * 4) * 4;
+    f32x4 ring[RING][8];
+    auto fetch = [&](int st, f32x4* f) {
+      const int64_t r0 = ((int64_t)blockIdx.y + (int64_t)st * G) * WG_ROWS;
+      const int64_t left = M - r0;
+      const int rows = st < n_st ? (left < WG_ROWS ? (int)left : WG_ROWS) : 0;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(src) + (size_t)(rows ? r0 : 0) * ld + c0, 0, rows ? (rows * ld - c0) * 4 : 0, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        f[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, j * ld * 4, 0));
+    };
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int st, int buf, const f32x4* f) {
+      xbf16x8 q[3][4];                             // [piece][column of the quad] = 8 rows
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 v = f[j];                      // rows past the end arrive as zeros
+        bsum += v;                                 // column sums of dY (the bias gradient); ignored by the X waves
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const __bf16 a = (__bf16)v[e];
+          const float r1 = v[e] - (float)a;
+          const __bf16 b = (__bf16)r1;
+          q[0][e][j] = a; q[1][e][j] = b; q[2][e][j] = (__bf16)(r1 - (float)b);
+        }
+      }
+      // column c of a group sits at entry (c & ~15) | ((c / 4 + 4 (c % 4)) & 15): 16 consecutive lanes then touch 16
+      // distinct 16-B bank groups both here (lane = column quad, fixed e) and in the fragment reads (lane = column)
+      __bf16* base = wplanes + (size_t)buf * BUF + (size_t)(op * 3 * 4 + g) * GRP + (c4 >> 2) * 128;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<xbf16x8*>(base + pc * 4 * GRP + ((c4 + 4 * e) & 15) * 8) = q[pc][e];
+    };
+#pragma unroll
+    for (int j = 0; j < RING; ++j) fetch(j, ring[j]);
+    stage(0, 0, ring[0]);
+    fetch(RING, ring[0]);
+    __syncthreads();
+    for (int s = 0; s < n_pad; s += RING) {
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {             // stage s+j+1 lives in ring slot (j+1) % RING, LDS buffer (j+1) & 1
+        constexpr int dummy = 0; (void)dummy;
+        const int jn = (j + 1) % RING;
+        stage(s + j + 1, (j + 1) & 1, ring[jn]);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(s + j + 1 + RING, ring[jn]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+      }
+    }
+    const bool own_bias = dbias && tk0 == 0;       // one k-tile column of workgroups owns the bias sums of its TN columns
+    if (own_bias && !op) {
+      float* red = reinterpret_cast<float*>(wplanes);        // the planes are dead: every wave passed the last barrier
+      *reinterpret_cast<f32x4*>(red + g * TN + c4 * 4) = bsum;
+    }
+    __syncthreads();
+    if (own_bias && !op) {
+      const float* red = reinterpret_cast<const float*>(wplanes);
+      const float v = red[t] + red[TN + t] + red[2 * TN + t] + red[3 * TN + t];
+      float* bdst = direct_accumulate ? dbias : dst + (size_t)N * K;
+      bdst[tn0 + t] = direct_accumulate == 2 ? bdst[tn0 + t] + v : v;
+    }
+  } else {
+    // ------------------------------------------------------------------ multipliers: wave w owns quadrant (w >> 1, w & 1)
+    const int wn = wid >> 1, wk = wid & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int h = lane >> 5, l31 = lane & 31;
+    auto entry = [](int c) { return (c & ~15) | (((c >> 2) + 4 * (c & 3)) & 15); };     // the stagers' column swizzle
+    int ya[2], xa[2];                              // dY / X entries: row group 2 ks + h, column x * 32 + l31 of the quadrant
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      ya[x] = h * GRP + entry(wn * 64 + x * 32 + l31) * 8;
+      xa[x] = 3 * 4 * GRP + h * GRP + entry(wk * 64 + x * 32 + l31) * 8;
+    }
+    __syncthreads();
+    for (int s = 0; s < n_pad; s += 2) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (s + j < n_st) {
+          const __bf16* pb = wplanes + (size_t)j * BUF;
+#pragma unroll
+          for (int ks = 0; ks < WG_ROWS / 16; ++ks) {
+            xbf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) {
+                a[x][pc] = *reinterpret_cast<const xbf16x8*>(pb + ya[x] + (pc * 4 + 2 * ks) * GRP);
+                b[x][pc] = *reinterpret_cast<const xbf16x8*>(pb + xa[x] + (pc * 4 + 2 * ks) * GRP);
+              }
+            // small terms first; consecutive MFMAs go to different accumulators
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+              for (int x = 0; x < 2; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                  acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[x][PA[tm]], b[y][PB[tm]], acc[x][y], 0, 0, 0);
+          }
+        }
+        __syncthreads();
+      }
+    }
+    // slab[split][N*K (+N bias sums)]; with a single split `slab` is dW itself (direct_accumulate: 1 = overwrite, 2 = add)
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = tn0 + wn * 64 + x * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          const int k = tk0 + wk * 64 + y * 32 + l31;
+          float v = acc[x][y][i];
+          if (direct_accumulate == 2) v += dst[(size_t)n * K + k];
+          dst[(size_t)n * K + k] = v;
+        }
+    __syncthreads();                               // pairs with the stagers' bias-sum barrier
+  }
+}
+
+void launch_wgrad_ws(dim3 grid, hipStream_t st, const float* dY, const float* X, float* target, int64_t M, int N, int K,
+                     int direct, int64_t slab_stride, float* dbias) {
+  const size_t lds = (size_t)2 * 2 * 3 * 4 * 128 * 8 * 2;      // two stages of fragment-ordered planes: 96 KB
+  (void)hipFuncSetAttribute((const void*)k_linear_wgrad_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_linear_wgrad_ws, grid, dim3(512), lds, st, dY, X, target, M, N, K, direct, slab_stride, dbias);
+}
+
 template <int TN, int TK, int WNN, int WNK, bool PRO>
 void launch_wgrad_x6_v(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
                        int N, int K, int64_t rps, int direct, int64_t slab_stride, float* dbias) {
@@ -919,7 +1091,12 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
   if (!fp32_mfma()) {
     // eight waves (two per SIMD: one stages while the other multiplies) wherever the tile has 8 sub-tiles
     const int64_t rps = p.rows_per_split;
-    if (p.TN == 128 && p.TK == 128) launch_wgrad_x6<128, 128, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
+    // role-specialised kernel for the plain 128 x 128 case (MMG_WGRAD_ROLES=0: the symmetric kernel everywhere); with a
+    // prologue the X stagers would also carry the dropout hashes and the symmetric kernel is faster (53 vs 64 us)
+    static const int ws_roles = [] { const char* e = getenv("MMG_WGRAD_ROLES"); return e ? atoi(e) : 1; }();
+    const bool has_pro = pr.scale || pr.relu || pr.p > 0.f;
+    if (p.TN == 128 && p.TK == 128 && ws_roles && !has_pro) launch_wgrad_ws(grid, st, dY, X, target, M, N, K, direct, stride, dbias);
+    else if (p.TN == 128 && p.TK == 128) launch_wgrad_x6<128, 128, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
     else if (p.TN == 128) launch_wgrad_x6<128, 64, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
     else if (p.TK == 128) launch_wgrad_x6<64, 128, 2, 4>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
     else launch_wgrad_x6<64, 64, 2, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
