@@ -849,13 +849,13 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
   constexpr int NF0 = K1, NF1 = K2 - K1, NF2 = NK - K2;             // 16-bit fields per (row, half)
   static_assert(NF0 % 2 == 0 && NF1 % 2 == 0 && NF2 % 2 == 0 && K1 % 2 == 0 && K2 % 2 == 0 && NK % 4 == 0,
                 "fields are loaded as dwords");
-  const int t_beg = (int)((int64_t)blockIdx.x * n_tile_total / gridDim.x);
-  const int t_end = (int)((int64_t)(blockIdx.x + 1) * n_tile_total / gridDim.x);
+  // 32-patient tiles are dealt round-robin: workgroup b takes tiles b, b + G, ... (the grid then works on one contiguous
+  // window of `out` and of the bit planes, which spreads over every HBM channel; a contiguous range per workgroup makes
+  // G read-modify-write streams advance a fixed stride apart).  `out` is addressed through one descriptor over the
+  // whole tensor (the launcher checks that it is below 4 GB).
+  const int t_beg = blockIdx.x, t_step = gridDim.x, t_end = n_tile_total;
   const int64_t last_row = n_rows - 1;
-  const int64_t wg_row0 = (int64_t)t_beg * 32;
-  const int64_t wg_rows = ((int64_t)t_end * 32 < n_rows ? (int64_t)t_end * 32 : n_rows) - wg_row0;
-  const __amdgpu_buffer_rsrc_t osrc =
-      __builtin_amdgcn_make_buffer_rsrc(out + (size_t)wg_row0 * D, 0, (int)(wg_rows * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(unsigned)(n_rows * D * 4), 0x00020000);
   const unsigned row_bytes = (unsigned)D * 4u;
   unsigned mcur[NK / 4], mnxt[NK / 4];                              // fields KB..KE-1 as dwords
   float rsn[3], prev[16];
@@ -878,7 +878,7 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
     for (int r = 0; r < 3; ++r) dst[r] = (r < rp.n && rp.r[r].rowscale) ? rp.r[r].rowscale[row] : 1.f;
   };
   auto loadprev = [&](int tile, float* dst) {
-    const unsigned vo = (unsigned)(((tile - t_beg) * 32 + 4 * h) * D + dcol) * 4u;
+    const unsigned vo = ((unsigned)(tile * 32 + 4 * h) * (unsigned)D + (unsigned)dcol) * 4u;
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0));
@@ -888,8 +888,9 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
     if (ACCUM && KH == 0) loadprev(t_beg, prev);
   }
 
-  for (int tile = t_beg; tile < t_end; ++tile) {
-    const int tn = tile + 1 < t_end ? tile + 1 : tile;
+  int par = 0;
+  for (int tile = t_beg; tile < t_end; tile += t_step, par ^= 1) {
+    const int tn = tile + t_step < t_end ? tile + t_step : tile;
     loadm(tn, mnxt);
     if (h == 0) {
 #pragma unroll
@@ -935,14 +936,14 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
         v[i] = t;
       }
     }
-    float (*xb)[64] = xch[tile & 1][ft];
+    float (*xb)[64] = xch[par][ft];
     if (KH == 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) xb[i][lane] = v[i];
     }
     __syncthreads();
     if (KH == 0) {
-      const unsigned vo = (unsigned)(((tile - t_beg) * 32 + 4 * h) * D + dcol) * 4u;
+      const unsigned vo = ((unsigned)(tile * 32 + 4 * h) * (unsigned)D + (unsigned)dcol) * 4u;
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -1138,7 +1139,8 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
   // (64 | 128 | 128 padded items) or its first relation alone (the last layer's backward only reaches the labs)
   {
     static const int no_bits = [] { const char* e = getenv("MMG_GATHER_LDS"); return e ? atoi(e) : 0; }();
-    bool okb = !no_bits && (n_rel == 3 || n_rel == 1) && D >= 128 && n_rows >= 32;
+    bool okb = !no_bits && (n_rel == 3 || n_rel == 1) && D >= 128 && n_rows >= 32 &&
+               (uint64_t)n_rows * (uint64_t)D * 4u < (1ull << 32);     // `out` sits behind one 32-bit buffer descriptor
     for (int r = 0; r < n_rel && okb; ++r) okb = (rels[r].flags & MMG_REL_SIMPLE) != 0 && rels[r].mask_r != nullptr;
     okb = okb && ((rels[0].n_cols + 31) & ~31) == 64;
     if (n_rel == 3) okb = okb && ((rels[1].n_cols + 31) & ~31) == 128 && ((rels[2].n_cols + 31) & ~31) == 128;

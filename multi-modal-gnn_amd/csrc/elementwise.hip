@@ -70,20 +70,27 @@ __global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, 
       s1[j] += (double)av * (double)bv;
     }
   };
-  int64_t r = r0 + rr;
-  for (; r + 3 * rl < r1; r += 4 * rl) {       // 4 independent 16-B loads per operand in flight
-    f32x4 a[4], b[4];
+  // Chunks of 4*rl rows are dealt round-robin over the workgroups (the grid then reads one contiguous window that
+  // spreads over every HBM channel; one contiguous range per workgroup makes the streams advance a fixed stride apart).
+  (void)r0; (void)r1;
+  const int64_t chunk = 4 * (int64_t)rl;
+  for (int64_t cb = (int64_t)blockIdx.x * chunk; cb < M; cb += (int64_t)gridDim.x * chunk) {
+    const int64_t r = cb + rr;
+    if (cb + chunk <= M) {                       // 4 independent 16-B loads per operand in flight
+      f32x4 a[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4*>(A + (size_t)(r + u * rl) * N + c4 * 4);
+      for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const f32x4*>(A + (size_t)(r + u * rl) * N + c4 * 4);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) b[u] = B ? *reinterpret_cast<const f32x4*>(B + (size_t)(r + u * rl) * N + c4 * 4) : a[u];
+      for (int u = 0; u < 4; ++u) b[u] = B ? *reinterpret_cast<const f32x4*>(B + (size_t)(r + u * rl) * N + c4 * 4) : a[u];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) body(r + u * rl, a[u], b[u]);
-  }
-  for (; r < r1; r += rl) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)r * N + c4 * 4);
-    const f32x4 b = B ? *reinterpret_cast<const f32x4*>(B + (size_t)r * N + c4 * 4) : a;
-    body(r, a, b);
+      for (int u = 0; u < 4; ++u) body(r + u * rl, a[u], b[u]);
+    } else {
+      for (int64_t q = r; q < M; q += rl) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(A + (size_t)q * N + c4 * 4);
+        const f32x4 b = B ? *reinterpret_cast<const f32x4*>(B + (size_t)q * N + c4 * 4) : a;
+        body(q, a, b);
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
