@@ -64,8 +64,11 @@ def main(fetch_csv, write_csv, out_json):
     for k, v in per_kernel.items():
         for frag, op in OP_OF_KERNEL:
             if k.startswith(frag) or ("<" in frag and k.startswith(frag)):
+                # an op is served by several kernel variants (prologue / accumulate / small-table instances): report the
+                # one that moves the most bytes per step, which is the launch shape bench.py's roofline describes
                 cur = per_op.get(op)
-                if cur is None or v["hbm_bytes_per_launch"] > cur["hbm_bytes_per_launch"]:
+                if cur is None or v["hbm_bytes_per_launch"] * v["launches_profiled"] > \
+                        cur["hbm_bytes_per_launch"] * cur["launches_profiled"]:
                     per_op[op] = dict(kernel=k, **v)
                 break
     json.dump(dict(correction="HBM bytes = 2*FETCH_SIZE + WRITE_SIZE, counters in KB, separate --pmc passes "
