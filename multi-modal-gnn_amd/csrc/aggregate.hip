@@ -580,8 +580,8 @@ __global__ __launch_bounds__(256, 2) void k_scatter_mfma(RelPack rp, int64_t n_r
 // A rowscale (backward of the mean gather) multiplies x per relation before the split.
 // Measured on MI355X (x100 eICU shape, 183,400 rows x 128, 320 padded items): 46 us without / 57 us with rowscale
 // (the fp32-MFMA indicator kernel above: 192 / 216 us).  Ablations: no x loads 45 us, no split and no LUT reads
-// 42 us -- the kernel runs at the pace of its 1.38 M matrix instructions (37 GFLOP of bf16 MFMA at the ~1.3 PF/s
-// the chip sustains on random data), not of HBM (94 MB, 2.0 TB/s).
+// 42 us -- the kernel runs at the pace of its 1.38 M matrix instructions, not of HBM (94 MB, 2.0 TB/s); by the issue-rate
+// probe (profiles/probes/mfma_rate.hip: 32 clocks per MFMA per wave) their pure issue time is ~21 us.
 constexpr int SB_SR = 64;                    // patient rows per stage = bits per mask word (4 k-steps of 16)
 
 __device__ inline void split8(const float* v, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
