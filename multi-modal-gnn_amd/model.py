@@ -16,6 +16,7 @@ Algebra used (exact up to fp32 re-association, inside the 1e-4 parity bar):
 from __future__ import annotations
 
 import logging
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -267,6 +268,14 @@ class _Run:
         self.tape = {}
         self._nbt = {}               # BatchNorm step counters to advance: {id(module): [buffer, increment]}
         self.pairs = None
+        # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
+        # dependency chain) runs on a side stream underneath the patient-side kernels of the same layer.  Off when
+        # sharded: the vocab path then contains all-reduces, which cut the hipGraph segments (MMG_OVERLAP=0 forces off).
+        self.overlap = self.comm is None and os.environ.get("MMG_OVERLAP", "1") != "0"
+        if self.overlap:
+            if getattr(model, "_side_stream", None) is None:
+                model._side_stream = torch.cuda.Stream(device=self.dev)
+            self.side = model._side_stream
         for t in self.plan.node_types:
             if t not in model.embeddings:
                 raise KeyError(f"no embedding table for node type '{t}': call model._init_embeddings(data) first")
@@ -530,19 +539,63 @@ class _Run:
         rout = [r for r in plan.rels_from_patient() if r.other in x and xP is not None]
         y: Dict[str, torch.Tensor] = {}
         rec = dict(x=x, rin=rin, rout=rout)
-        # ---- dst = patient: y_P = x_P (sum_r W_r)^T + sum_r b_r + sum_r mean_gather(x_v W_l^T)
-        if rin:
-            names = [self.conv_name(l, r.edge_type) for r in rin]
+        last = l == self.m.num_layers - 1
+        p = 0.0 if last else self.p
+        out, folds, pros = {}, {}, {}
+
+        def bn_act(t):       # per-type BN -> ReLU -> Dropout (model.py:258-269)
+            ti = plan.node_types.index(t)
+            sharded = t == ROW_TYPE
+            fold = self.bn_fold(y[t], self.m.batch_norms[l][t], 1, sharded,
+                                sums=rec.get("ysums") if t == ROW_TYPE else None) if self.m.use_batch_norm else None
+            pro = Pro(fold.scale if fold else None, fold.shift if fold else None, True, p, self.seed,
+                      SITE_CONV + 8 * l + ti, plan.row_offset if sharded else 0, self.seed_dev)
+            out[t] = ops.affine_act_drop(y[t], pro)
+            folds[t], pros[t] = fold, pro
+
+        names = [self.conv_name(l, r.edge_type) for r in rin]
+        tables = []
+
+        def vocab_tables():  # T_v = x_v W_l^T: the transformed vocab rows the patient-side gather reads
+            for r, nme in zip(rin, names):
+                tables.append(ops.linear_fwd(x[r.other], self.W(nme + ".lin_l.weight")))
+
+        def vocab_side():
+            # ---- dst = vocab type v: y_v = mean_scatter(x_P) W_l^T + b + x_v W_r^T   (summed over relations into v)
+            if rout:
+                aggs, rels, off = [], [], 0
+                buf = torch.empty(sum(r.n_cols for r in rout), D, device=self.dev)   # one buffer = one all-reduce
+                for r in rout:
+                    agg = buf[off:off + r.n_cols]
+                    off += r.n_cols
+                    rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg, simple=r.simple, mask_t=r.mask_t))
+                    aggs.append(agg)
+                ops.scatter_rows(rels, P, D, xP)
+                self.allreduce(buf)                          # partial sums over patient shards
+                for r, agg in zip(rout, aggs):
+                    nme = self.conv_name(l, r.edge_type)
+                    first = r.other not in y
+                    y[r.other] = ops.linear_fwd(agg, self.W(nme + ".lin_l.weight"), self.W(nme + ".lin_l.bias"),
+                                                out=None if first else y[r.other], accumulate=not first)
+                    ops.linear_fwd(x[r.other], self.W(nme + ".lin_r.weight"), out=y[r.other], accumulate=True)
+                rec["aggs"] = aggs
+            for t in plan.node_types:
+                if t != ROW_TYPE and t in y:
+                    bn_act(t)
+
+        def patient_side(wait_tables):
+            # ---- dst = patient: y_P = x_P (sum_r W_r)^T + sum_r b_r + sum_r mean_gather(x_v W_l^T)
+            if not rin:
+                return
             Wsum = self.W(names[0] + ".lin_r.weight")
             bsum = self.W(names[0] + ".lin_l.bias")
             for nme in names[1:]:
                 Wsum = Wsum + self.W(nme + ".lin_r.weight")
                 bsum = bsum + self.W(nme + ".lin_l.bias")
             yP = ops.linear_fwd(xP, Wsum.contiguous(), bsum.contiguous())
-            rels = []
-            for r, nme in zip(rin, names):
-                Tv = ops.linear_fwd(x[r.other], self.W(nme + ".lin_l.weight"))
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv, simple=r.simple, mask_r=r.mask_r))
+            wait_tables()
+            rels = [ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv, simple=r.simple, mask_r=r.mask_r)
+                    for r, Tv in zip(rin, tables)]
             ysums = None
             if self.T and self.m.use_batch_norm and P > 0:       # BatchNorm statistics of y_P from the gather epilogue
                 _, ysums = ops.gather_rows(rels, P, D, yP, accumulate=True, with_stats=True)
@@ -551,39 +604,23 @@ class _Run:
             y[ROW_TYPE] = yP
             rec["Wsum"] = Wsum
             rec["ysums"] = ysums
-        # ---- dst = vocab type v: y_v = mean_scatter(x_P) W_l^T + b + x_v W_r^T   (summed over relations into v)
-        if rout:
-            aggs, rels, off = [], [], 0
-            buf = torch.empty(sum(r.n_cols for r in rout), D, device=self.dev)   # one buffer = one all-reduce
-            for r in rout:
-                agg = buf[off:off + r.n_cols]
-                off += r.n_cols
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg, simple=r.simple, mask_t=r.mask_t))
-                aggs.append(agg)
-            ops.scatter_rows(rels, P, D, xP)
-            self.allreduce(buf)                          # partial sums over patient shards
-            for r, agg in zip(rout, aggs):
-                nme = self.conv_name(l, r.edge_type)
-                first = r.other not in y
-                y[r.other] = ops.linear_fwd(agg, self.W(nme + ".lin_l.weight"), self.W(nme + ".lin_l.bias"),
-                                            out=None if first else y[r.other], accumulate=not first)
-                ops.linear_fwd(x[r.other], self.W(nme + ".lin_r.weight"), out=y[r.other], accumulate=True)
-            rec["aggs"] = aggs
-        # ---- per-type BN -> ReLU -> Dropout (model.py:258-269)
-        last = l == self.m.num_layers - 1
-        p = 0.0 if last else self.p
-        out, folds, pros = {}, {}, {}
-        for ti, t in enumerate(plan.node_types):
-            if t not in y:
-                continue
-            sharded = t == ROW_TYPE
-            fold = self.bn_fold(y[t], self.m.batch_norms[l][t], 1, sharded,
-                                sums=rec.get("ysums") if t == ROW_TYPE else None) if self.m.use_batch_norm else None
-            pro = Pro(fold.scale if fold else None, fold.shift if fold else None, True, p, self.seed,
-                      SITE_CONV + 8 * l + ti, plan.row_offset if sharded else 0, self.seed_dev)
-            out[t] = ops.affine_act_drop(y[t], pro)
-            folds[t], pros[t] = fold, pro
-        rec.update(y=y, folds=folds, pros=pros, l=l)
+            bn_act(ROW_TYPE)
+
+        if self.overlap:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(self.side):
+                vocab_tables()
+                ev.record(self.side)
+                vocab_side()
+            patient_side(lambda: main.wait_event(ev))
+            main.wait_stream(self.side)
+        else:
+            vocab_tables()
+            patient_side(lambda: None)
+            vocab_side()
+        rec.update(y=y, folds=folds, pros=pros, l=l, tables=tables)
         return out, rec
 
     def layers_bwd(self, recs, g):
@@ -595,16 +632,15 @@ class _Run:
         plan, D, P, l = self.plan, self.D, self.plan.n_rows, rec["l"]
         x, y = rec["x"], rec["y"]
         dy = {}
-        for t in y:
+
+        def bn_bwd_t(t):
             gt = g_out.get(t)
-            if gt is None:
-                continue
+            if gt is None or t not in y:
+                return
             bn_prefix = f"batch_norms.{l}.{t}" if self.m.use_batch_norm else None
             dy[t] = self.bn_bwd(gt.contiguous(), y[t], rec["pros"][t], rec["folds"][t], bn_prefix, sharded=(t == ROW_TYPE))
-        g_in: Dict[str, Optional[torch.Tensor]] = {t: None for t in x}
 
-        def add(t, v):
-            g_in[t] = v if g_in[t] is None else g_in[t].add_(v)
+        g_in: Dict[str, Optional[torch.Tensor]] = {t: None for t in x}
 
         def add_dgrad(t, dy_, W_):
             """g_in[t] += dy_ . W_  (W_ is the forward weight [N,K], read in place; accumulated by the GEMM itself)."""
@@ -613,9 +649,32 @@ class _Run:
             else:
                 ops.linear_fwd(dy_, W_, w_kn=True, out=g_in[t], accumulate=True)
 
-        # ---- patient destination
-        dyP = dy.get(ROW_TYPE)
-        if dyP is not None and rec["rin"]:
+        def vocab_1():
+            """BN backward of the vocab types and everything that only depends on it (vocab destinations)."""
+            for t in y:
+                if t != ROW_TYPE:
+                    bn_bwd_t(t)
+            rels = []
+            for r, agg in zip(rec["rout"], rec.get("aggs", [])):
+                dyv = dy.get(r.other)
+                if dyv is None:
+                    continue
+                nme = self.conv_name(l, r.edge_type)
+                dWl, dbl = ops.linear_wgrad(dyv, agg, with_bias=True)     # the bias gradient rides in the same pass
+                self.acc(nme + ".lin_l.weight", dWl)
+                self.acc(nme + ".lin_l.bias", dbl)
+                self.acc(nme + ".lin_r.weight", ops.linear_wgrad(dyv, x[r.other]))
+                add_dgrad(r.other, dyv, self.W(nme + ".lin_r.weight"))
+                dagg = ops.linear_fwd(dyv, self.W(nme + ".lin_l.weight"), w_kn=True)
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=dagg, simple=r.simple, mask_r=r.mask_r))
+            return rels
+
+        def patient_1():
+            """BN backward of the patient rows, their weight / data gradients, scatter of dy_P onto the vocab rows."""
+            bn_bwd_t(ROW_TYPE)
+            dyP = dy.get(ROW_TYPE)
+            if dyP is None or not rec["rin"]:
+                return None
             xP = x[ROW_TYPE]
             dWsum, dbsum = ops.linear_wgrad(dyP, xP, with_bias=True)
             add_dgrad(ROW_TYPE, dyP, rec["Wsum"])
@@ -628,32 +687,48 @@ class _Run:
                 dTs.append(dT)
             ops.scatter_rows(rels, P, D, dyP)
             self.allreduce(buf)
+            return dTs, dWsum, dbsum
+
+        def vocab_2(res):
+            """Per-relation work behind the scatter: gradients of the vocab-table transforms T_v = x_v W_l^T."""
+            if res is None:
+                return
+            dTs, dWsum, dbsum = res
             for r, dT in zip(rec["rin"], dTs):
                 nme = self.conv_name(l, r.edge_type)
                 self.acc(nme + ".lin_r.weight", dWsum, partial=True)
                 self.acc(nme + ".lin_l.bias", dbsum, partial=True)
                 self.acc(nme + ".lin_l.weight", ops.linear_wgrad(dT, x[r.other]))
                 add_dgrad(r.other, dT, self.W(nme + ".lin_l.weight"))
-        # ---- vocab destinations
-        if rec["rout"]:
-            rels = []
-            for r, agg in zip(rec["rout"], rec["aggs"]):
-                dyv = dy.get(r.other)
-                if dyv is None:
-                    continue
-                nme = self.conv_name(l, r.edge_type)
-                self.acc(nme + ".lin_l.weight", ops.linear_wgrad(dyv, agg))
-                self.acc(nme + ".lin_l.bias", ops.col_reduce2(dyv)[0].float())
-                self.acc(nme + ".lin_r.weight", ops.linear_wgrad(dyv, x[r.other]))
-                add_dgrad(r.other, dyv, self.W(nme + ".lin_r.weight"))
-                dagg = ops.linear_fwd(dyv, self.W(nme + ".lin_l.weight"), w_kn=True)
-                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=dagg, simple=r.simple, mask_r=r.mask_r))
+
+        def patient_2(rels):
             if rels:
                 if g_in[ROW_TYPE] is None:
                     g_in[ROW_TYPE] = torch.empty(P, D, device=self.dev)
                     ops.gather_rows(rels, P, D, g_in[ROW_TYPE], accumulate=False)
                 else:
                     ops.gather_rows(rels, P, D, g_in[ROW_TYPE], accumulate=True)
+
+        if self.overlap:
+            main, side = torch.cuda.current_stream(), self.side
+            side.wait_stream(main)
+            ev_tables, ev_scatter = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.stream(side):
+                rels = vocab_1()
+                ev_tables.record(side)
+            res = patient_1()
+            ev_scatter.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_scatter)
+                vocab_2(res)
+            main.wait_event(ev_tables)
+            patient_2(rels)
+            main.wait_stream(side)
+        else:
+            rels = vocab_1()
+            res = patient_1()
+            vocab_2(res)
+            patient_2(rels)
         return g_in
 
     # ======================================================================== heads
@@ -722,11 +797,11 @@ class _Run:
                 dW1a = ops.linear_wgrad(g.A, xP)
             else:
                 dW1a = torch.zeros(w1a.shape, device=self.dev)
-            dW1b = ops.linear_wgrad(g.B, xlab)
+            dW1b, db1 = ops.linear_wgrad(g.B, xlab, with_bias=True)
             if self.comm is not None:
                 self.allreduce(dW1a)             # so that the concatenated weight grad is uniformly "full"
             self.acc(f"{which}.mlp.0.weight", torch.cat([dW1a, dW1b], dim=1))
-            self.acc(f"{which}.mlp.0.bias", ops.col_reduce2(g.B)[0].float())
+            self.acc(f"{which}.mlp.0.bias", db1)
             glab = ops.linear_fwd(g.B, w1b, w_kn=True)
             if want_low:                         # gradient rows of the low-degree patients only: (row ids, rows)
                 gP = (low_rows, ops.linear_fwd(g.A, w1a, w_kn=True)) if xP.shape[0] else None

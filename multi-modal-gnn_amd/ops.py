@@ -91,11 +91,13 @@ _WS = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Growable scratch per (device, host thread).  Reuse is stream-ordered: every op of a thread runs on that
-    thread's current stream, and two host threads never share a buffer."""
+    """Growable scratch per (device, host thread, stream).  Reuse is stream-ordered: an op runs on the current stream,
+    and neither two host threads nor two streams (the model overlaps its vocab-side work on a side stream) share a
+    buffer."""
     import threading
     d = torch.device(device)
-    key = (d.index if d.index is not None else torch.cuda.current_device(), threading.get_ident())
+    key = (d.index if d.index is not None else torch.cuda.current_device(), threading.get_ident(),
+           torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
