@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 // mask (registers 4i .. 4i+3 are one aligned RNG group: one hash each), the 32 -> 1 output layer as 16 FMAs -- and
 // one cross-half add finishes a prediction.  No LDS, no shuffles, no barrier.
 constexpr int PF_LDB = 68;           // LDS row stride of the lab-side table (floats): rows land 4 banks apart
+template <bool B_LDS>
 __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32_t* __restrict__ pi,
                                                           const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                           int thr, int want_low, int64_t n, float drop_p, uint64_t seed,
@@ -552,9 +553,11 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
   // the lab-side first-layer table B (a few dozen 256-B rows, read once per PAIR) lives in LDS when it fits:
   // 4.3 M pairs x 256 B would otherwise stream from L2
   extern __shared__ __attribute__((aligned(16))) float Bs[];
-  for (int i = threadIdx.x; i < n_labs_lds * 16; i += 256)
-    *reinterpret_cast<f32x4*>(Bs + (i >> 4) * PF_LDB + (i & 15) * 4) = *reinterpret_cast<const f32x4*>(H.B + (size_t)i * 4);
-  __syncthreads();
+  if (B_LDS) {
+    for (int i = threadIdx.x; i < n_labs_lds * 16; i += 256)
+      *reinterpret_cast<f32x4*>(Bs + (i >> 4) * PF_LDB + (i & 15) * 4) = *reinterpret_cast<const f32x4*>(H.B + (size_t)i * 4);
+    __syncthreads();
+  }
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
@@ -585,20 +588,49 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
   // for in the iteration that issues it:   tile t+3: list position -> pair index k   (sel[.])
   //                                        tile t+2: k -> patient, lab, rng id, output slot
   //                                        tile t+1: patient -> gate degree, A row;  lab -> B row
+  // Every load of the pipeline is unconditional: list positions past the end and nullable arrays go through buffer
+  // descriptors (zero-sized for a null array: the load returns 0 and a select substitutes the default; unbounded for
+  // io / pair_id, whose length the kernel does not know: their indices come from the list), indices are clamped to 0.  A branch around a load makes the compiler's vmcnt waits conservative (minimum over both
+  // paths) and the first version of this loop drained the whole pipeline twice per tile.
   struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
-  auto load_k = [&](int64_t t) {
+  typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t sel_d = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int32_t*>(sel ? sel : pi), 0, sel ? (int)(n * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t io_d = __builtin_amdgcn_make_buffer_rsrc(
+      io ? (void*)const_cast<int64_t*>(io) : (void*)const_cast<int32_t*>(pi), 0, io ? -1 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t pid_d = __builtin_amdgcn_make_buffer_rsrc(
+      pair_id ? (void*)const_cast<int64_t*>(pair_id) : (void*)const_cast<int32_t*>(pi), 0,
+      pair_id ? -1 : 0, 0x00020000);
+  const bool has_sel = sel != nullptr, has_io = io != nullptr, has_pid = pair_id != nullptr;
+  // A stage only ISSUES loads; what it loaded is finalised (selects, clamps) one iteration later by the next stage, so
+  // nothing is waited for in the iteration that issued it.
+  struct RawMeta { int k, p, l; pu32x2 o2, d2; };
+  auto issue_k = [&](int64_t t) {                    // raw list entry of tile t (0 past the end / without a list)
     const int64_t idx = t * TP + l31;
-    int k = -1;
-    if (t < n_tiles && idx < n) k = sel ? sel[idx] : (int)idx;
-    return k;
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(sel_d, (int)(idx < n ? idx : 0) * 4, 0, 0);
   };
-  auto load_meta = [&](int k) {
-    Meta m{k, -1, 0, 0, 0ull};
-    if (k >= 0) {
-      m.p_i = pi[k]; m.l_i = li[k];
-      m.o = io ? (int)io[k] : k;
-      m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
-    }
+  auto fin_k = [&](int kr, int64_t t) {
+    const int64_t idx = t * TP + l31;
+    return idx < n ? (has_sel ? kr : (int)idx) : -1;
+  };
+  auto issue_meta = [&](int k) {
+    const int kc = k >= 0 ? k : 0;
+    RawMeta r;
+    r.k = k;
+    r.p = pi[kc];
+    r.l = li[kc];
+    r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, kc * 8, 0, 0);
+    r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, kc * 8, 0, 0);
+    return r;
+  };
+  auto fin_meta = [&](const RawMeta& r) {
+    const int kc = r.k >= 0 ? r.k : 0;
+    Meta m;
+    m.k = r.k;
+    m.p_i = r.k >= 0 ? r.p : -1;
+    m.l_i = r.l;
+    m.o = has_io ? (int)r.o2[0] : kc;
+    m.pid = has_pid ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
     return m;
   };
   auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg) {
@@ -609,11 +641,14 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
 #pragma unroll
     for (int q = 0; q < 8; ++q) {              // q = 2 ks + half-chunk: floats 16 ks + 8 h + 4 (q & 1) ..
       ra[q] = *reinterpret_cast<const f32x4*>(ap + (q >> 1) * 16 + (q & 1) * 4);
-      if (!n_labs_lds) rb[q] = *reinterpret_cast<const f32x4*>(bp + (q >> 1) * 16 + (q & 1) * 4);
+      if (!B_LDS) rb[q] = *reinterpret_cast<const f32x4*>(bp + (q >> 1) * 16 + (q & 1) * 4);
     }
   };
-  int k2 = load_k(wave_id + 2 * n_waves);
-  Meta m0 = load_meta(load_k(wave_id)), m1 = load_meta(load_k(wave_id + n_waves));
+  const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
+  int kr2 = issue_k(wave_id + 2 * n_waves);
+  const RawMeta rm0 = issue_meta(fin_k(kr0, wave_id));
+  RawMeta rm1 = issue_meta(fin_k(kr1, wave_id + n_waves));
+  Meta m0 = fin_meta(rm0);
   f32x4 ra[8], rb[8];
   int dg0;
   load_rows(m0, ra, rb, &dg0);
@@ -623,12 +658,15 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
     f32x4 ca[8], cb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
-    const int k3 = load_k(t + 3 * n_waves);
-    const Meta m2 = load_meta(k2);
+    const Meta m1 = fin_meta(rm1);                   // issued one iteration ago
+    const int k2 = fin_k(kr2, t + 2 * n_waves);
+    kr2 = issue_k(t + 3 * n_waves);
+    rm1 = issue_meta(k2);
     load_rows(m1, ra, rb, &dg0);
-    m0 = m1; m1 = m2; k2 = k3;
+    __builtin_amdgcn_sched_barrier(0);         // the three stages' loads stay ahead of this tile's arithmetic
+    m0 = m1;
     if (__ballot(active) == 0ull) continue;
-    if (n_labs_lds) {
+    if (B_LDS) {
       const float* bl = Bs + mc.l_i * PF_LDB + 8 * h;
 #pragma unroll
       for (int q = 0; q < 8; ++q) cb[q] = *reinterpret_cast<const f32x4*>(bl + (q >> 1) * 16 + (q & 1) * 4);
@@ -836,11 +874,18 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   if (g < 1) g = 1;
   const int n_labs_lds = (n_labs > 0 && n_labs <= 256) ? n_labs : 0;       // 256 rows x 272 B = 68 KB: two workgroups per CU
   const size_t lds = (size_t)n_labs_lds * PF_LDB * sizeof(float);
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)k_pair_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_pair_fwd_mfma, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, H, pi, li, deg,
-                     degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel, io_perm,
-                     n_labs_lds);
+  MMG_CHECK_ARG(n_pairs < (1ll << 29), "pair_head_fwd: %lld pairs exceed the 32-bit buffer descriptors", (long long)n_pairs);
+  if (n_labs_lds) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)k_pair_fwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_pair_fwd_mfma<true>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, H, pi, li, deg,
+                       degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel,
+                       io_perm, n_labs_lds);
+  } else {
+    hipLaunchKernelGGL(k_pair_fwd_mfma<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, H, pi, li, deg,
+                       degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel,
+                       io_perm, 0);
+  }
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;
 }
