@@ -246,7 +246,7 @@ __device__ __forceinline__ void layer2_fields(uint32_t key, const unsigned* PLo,
   bits[14] = quad_bcast_field<14>(hw0, hw1, sub); bits[15] = quad_bcast_field<15>(hw0, hw1, sub);
 }
 
-template <int LT>
+template <int LT, bool AUX>       // AUX: io_perm and / or pair_id are present (else neither is loaded)
 __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                        const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                        int thr, int want_low, int64_t n, int n_labs, float drop_p,
@@ -285,29 +285,56 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 
   const int64_t n_tiles = (n + TP - 1) / TP;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid, n_waves = (int64_t)gridDim.x * 4;
-  // Three-deep software pipeline over this wave's tiles, one dependent load per stage (no load is waited for in
-  // the iteration that issues it):  t+3: list position -> pair index;  t+2: pair -> patient, lab, rng id, slot of
-  // its upstream gradient;  t+1: gate degree, upstream gradient, the A / B row halves.
+  // Three-deep software pipeline over this wave's tiles, one dependent load per stage:  t+3: list position -> pair
+  // index;  t+2: pair -> patient, lab, rng id, slot of its upstream gradient;  t+1: gate degree, upstream gradient,
+  // the A / B row halves.  A stage only ISSUES loads; they are finalised (selects, clamps) one iteration later by the
+  // next stage.  Every load is unconditional -- list positions past the end and nullable arrays go through buffer
+  // descriptors (zero-sized for a null array, unbounded for io / pair_id whose length the kernel does not know),
+  // indices are clamped to element 0 -- because a branch around a load makes the compiler's vmcnt waits conservative.
   struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
-  auto load_k = [&](int64_t t) {
+  typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t sel_d = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int32_t*>(sel ? sel : pi), 0, sel ? (int)(n * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t io_d = __builtin_amdgcn_make_buffer_rsrc(
+      io ? (void*)const_cast<int64_t*>(io) : (void*)const_cast<int32_t*>(pi), 0, io ? -1 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t pid_d = __builtin_amdgcn_make_buffer_rsrc(
+      pair_id ? (void*)const_cast<int64_t*>(pair_id) : (void*)const_cast<int32_t*>(pi), 0, pair_id ? -1 : 0, 0x00020000);
+  const bool has_sel = sel != nullptr, has_io = io != nullptr, has_pid = pair_id != nullptr;
+  struct RawMeta { int k, p, l; pu32x2 o2, d2; };
+  auto issue_k = [&](int64_t t) {                    // raw list entry of tile t (0 past the end / without a list)
     const int64_t idx = t * TP + l31;
-    int k = -1;
-    if (t < n_tiles && idx < n) k = sel ? sel[idx] : (int)idx;
-    return k;
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(sel_d, (int)(idx < n ? idx : 0) * 4, 0, 0);
   };
-  auto load_meta = [&](int k) {
-    Meta m{k, -1, 0, 0, 0ull};
-    if (k >= 0) {
-      m.p_i = pi[k]; m.l_i = li[k];
-      m.o = io ? (int)io[k] : k;
-      m.pid = pair_id ? (uint64_t)pair_id[k] : (uint64_t)k;
+  auto fin_k = [&](int kr, int64_t t) {
+    const int64_t idx = t * TP + l31;
+    return idx < n ? (has_sel ? kr : (int)idx) : -1;
+  };
+  auto issue_meta = [&](int k) {
+    const int kc = k >= 0 ? k : 0;
+    RawMeta r;
+    r.k = k;
+    r.p = pi[kc];
+    r.l = li[kc];
+    if (AUX) {
+      r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, kc * 8, 0, 0);
+      r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, kc * 8, 0, 0);
     }
+    return r;
+  };
+  auto fin_meta = [&](const RawMeta& r) {
+    const int kc = r.k >= 0 ? r.k : 0;
+    Meta m;
+    m.k = r.k;
+    m.p_i = r.k >= 0 ? r.p : -1;
+    m.l_i = r.l;
+    m.o = (AUX && has_io) ? (int)r.o2[0] : kc;
+    m.pid = (AUX && has_pid) ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
     return m;
   };
   auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
     const int pp = m.p_i >= 0 ? m.p_i : 0;
     *dg = deg[pp];
-    *dv = m.p_i >= 0 ? dpred[m.o] : 0.f;
+    *dv = dpred[m.o];                          // (slot 0 for a position past the end: masked when it is used)
     const float* ap = H.A + (size_t)pp * 64 + 32 * h;
     const float* bp = H.B + (size_t)m.l_i * 64 + 32 * h;
 #pragma unroll
@@ -316,8 +343,11 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
       rb[q] = *reinterpret_cast<const f32x4*>(bp + q * 4);
     }
   };
-  int k2 = load_k(wave_id + 2 * n_waves);
-  Meta m0 = load_meta(load_k(wave_id)), m1 = load_meta(load_k(wave_id + n_waves));
+  const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
+  int kr2 = issue_k(wave_id + 2 * n_waves);
+  const RawMeta rm0 = issue_meta(fin_k(kr0, wave_id));
+  RawMeta rm1 = issue_meta(fin_k(kr1, wave_id + n_waves));
+  Meta m0 = fin_meta(rm0);
   f32x4 ra[8], rb[8];
   int dg0; float dv0;
   load_rows(m0, ra, rb, &dg0, &dv0);
@@ -328,10 +358,13 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
     f32x4 ca[8], cb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
-    const int k3 = load_k(t + 3 * n_waves);
-    const Meta m2 = load_meta(k2);
+    const Meta m1 = fin_meta(rm1);               // issued one iteration ago
+    const int k2 = fin_k(kr2, t + 2 * n_waves);
+    kr2 = issue_k(t + 3 * n_waves);
+    rm1 = issue_meta(k2);
     load_rows(m1, ra, rb, &dg0, &dv0);           // next tile's rows: in flight during this tile's MFMAs
-    m0 = m1; m1 = m2; k2 = k3;
+    __builtin_amdgcn_sched_barrier(0);           // the three stages' loads stay ahead of this tile's arithmetic
+    m0 = m1;
     const int p_i = active ? mc.p_i : -1, l_i = mc.l_i;
     const uint64_t pid = mc.pid;
     if (__ballot(p_i >= 0) == 0ull) continue;    // no pair of this tile belongs to this head (wave-uniform)
@@ -912,11 +945,13 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     int64_t g = ((n_pairs + TP - 1) / TP + 3) / 4;
     if (g > 512) g = 512;                // two resident workgroups per CU; fewer workgroups = fewer global atomics
     if (g < 1) g = 1;
-#define MMG_LAUNCH_PBWD(LT_)                                                                                          \
-  hipLaunchKernelGGL((k_pair_bwd_mfma<LT_>), dim3((unsigned)g), dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, \
-                     want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel, io_perm)
-    if (n_labs <= 64) MMG_LAUNCH_PBWD(2);
-    else MMG_LAUNCH_PBWD(4);
+#define MMG_LAUNCH_PBWD(LT_, AUX_)                                                                                    \
+  hipLaunchKernelGGL((k_pair_bwd_mfma<LT_, AUX_>), dim3((unsigned)g), dim3(256), 0, st, H, G, pi, li, deg,              \
+                     degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, seed_ptr, pair_id, dpred, sel,  \
+                     n_sel, io_perm)
+    const bool aux = pair_id != nullptr || io_perm != nullptr;
+    if (n_labs <= 64) { if (aux) MMG_LAUNCH_PBWD(2, true); else MMG_LAUNCH_PBWD(2, false); }
+    else { if (aux) MMG_LAUNCH_PBWD(4, true); else MMG_LAUNCH_PBWD(4, false); }
 #undef MMG_LAUNCH_PBWD
   } else {
     size_t lds = BWD_LDS_FIXED;
