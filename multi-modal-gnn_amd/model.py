@@ -269,9 +269,9 @@ class _Run:
         self._nbt = {}               # BatchNorm step counters to advance: {id(module): [buffer, increment]}
         self.pairs = None
         # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
-        # dependency chain) runs on a side stream underneath the patient-side kernels of the same layer.  Off when
-        # sharded: the vocab path then contains all-reduces, which cut the hipGraph segments (MMG_OVERLAP=0 forces off).
-        self.overlap = self.comm is None and os.environ.get("MMG_OVERLAP", "1") != "0"
+        # dependency chain) runs on a side stream underneath the patient-side kernels of the same layer
+        # (MMG_OVERLAP=0: one stream).  Sharded runs keep every collective on the main stream.
+        self.overlap = os.environ.get("MMG_OVERLAP", "1") != "0"
         if self.overlap:
             if getattr(model, "_side_stream", None) is None:
                 model._side_stream = torch.cuda.Stream(device=self.dev)
@@ -466,13 +466,21 @@ class _Run:
             x[t] = enc["x0"] if t == ROW_TYPE else self.W(f"embeddings.{t}.weight")
         return x
 
-    def bn_bwd(self, g, y, pro: Pro, fold: Optional[ops.BNFold], bn_prefix: Optional[str], sharded: bool):
-        """grad wrt the pre-BN tensor y of  x' = dropout(relu(BN(y)));  accumulates d gamma / d beta."""
-        if fold is None:        # no batch norm: relu/dropout only
-            return ops.bn_bwd_apply(g, y, pro, None)
+    def bn_bwd_sums(self, g, y, pro: Pro, fold: Optional[ops.BNFold], sharded: bool):
+        """first half of bn_bwd: the column statistics (all-reduced over the shards); None without batch norm."""
+        if fold is None:
+            return None
         sums = ops.bn_bwd_stats(g, y, pro, fold)
         if sharded and self.comm is not None:
             self.allreduce(sums)
+        return sums
+
+    def bn_bwd(self, g, y, pro: Pro, fold: Optional[ops.BNFold], bn_prefix: Optional[str], sharded: bool, sums=None):
+        """grad wrt the pre-BN tensor y of  x' = dropout(relu(BN(y)));  accumulates d gamma / d beta."""
+        if fold is None:        # no batch norm: relu/dropout only
+            return ops.bn_bwd_apply(g, y, pro, None)
+        if sums is None:
+            sums = self.bn_bwd_sums(g, y, pro, fold, sharded)
         N = y.shape[1]
         dbg = torch.empty(2, N, device=y.device)       # d beta | d gamma, written by the apply kernel
         if fold.training:
@@ -560,30 +568,37 @@ class _Run:
             for r, nme in zip(rin, names):
                 tables.append(ops.linear_fwd(x[r.other], self.W(nme + ".lin_l.weight")))
 
-        def vocab_side():
+        scat = {}
+
+        def vocab_scatter():
             # ---- dst = vocab type v: y_v = mean_scatter(x_P) W_l^T + b + x_v W_r^T   (summed over relations into v)
+            if not rout:
+                return
+            aggs, rels, off = [], [], 0
+            buf = torch.empty(sum(r.n_cols for r in rout), D, device=self.dev)   # one buffer = one all-reduce
+            for r in rout:
+                agg = buf[off:off + r.n_cols]
+                off += r.n_cols
+                rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg, simple=r.simple, mask_t=r.mask_t))
+                aggs.append(agg)
+            ops.scatter_rows(rels, P, D, xP)
+            self.allreduce(buf)                          # partial sums over patient shards
+            scat["aggs"] = aggs
+
+        def vocab_small():
             if rout:
-                aggs, rels, off = [], [], 0
-                buf = torch.empty(sum(r.n_cols for r in rout), D, device=self.dev)   # one buffer = one all-reduce
-                for r in rout:
-                    agg = buf[off:off + r.n_cols]
-                    off += r.n_cols
-                    rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, out=agg, simple=r.simple, mask_t=r.mask_t))
-                    aggs.append(agg)
-                ops.scatter_rows(rels, P, D, xP)
-                self.allreduce(buf)                          # partial sums over patient shards
-                for r, agg in zip(rout, aggs):
+                for r, agg in zip(rout, scat["aggs"]):
                     nme = self.conv_name(l, r.edge_type)
                     first = r.other not in y
                     y[r.other] = ops.linear_fwd(agg, self.W(nme + ".lin_l.weight"), self.W(nme + ".lin_l.bias"),
                                                 out=None if first else y[r.other], accumulate=not first)
                     ops.linear_fwd(x[r.other], self.W(nme + ".lin_r.weight"), out=y[r.other], accumulate=True)
-                rec["aggs"] = aggs
+                rec["aggs"] = scat["aggs"]
             for t in plan.node_types:
                 if t != ROW_TYPE and t in y:
                     bn_act(t)
 
-        def patient_side(wait_tables):
+        def patient_gather(wait_tables):
             # ---- dst = patient: y_P = x_P (sum_r W_r)^T + sum_r b_r + sum_r mean_gather(x_v W_l^T)
             if not rin:
                 return
@@ -604,22 +619,42 @@ class _Run:
             y[ROW_TYPE] = yP
             rec["Wsum"] = Wsum
             rec["ysums"] = ysums
-            bn_act(ROW_TYPE)
 
-        if self.overlap:
+        def patient_bn():
+            if rin:
+                bn_act(ROW_TYPE)                             # (sharded: all-reduce of the column sums inside)
+
+        if self.overlap and self.comm is None:
+            # single GPU: the whole vocab path, its scatter included, runs beside the patient path
             main = torch.cuda.current_stream()
             self.side.wait_stream(main)
             ev = torch.cuda.Event()
             with torch.cuda.stream(self.side):
                 vocab_tables()
                 ev.record(self.side)
-                vocab_side()
-            patient_side(lambda: main.wait_event(ev))
+                vocab_scatter()
+                vocab_small()
+            patient_gather(lambda: main.wait_event(ev))
+            patient_bn()
             main.wait_stream(self.side)
+        elif self.overlap:
+            # sharded: collectives stay on the main stream (they cut the hipGraph segments, so every fork is joined
+            # before the next one); the small vocab chains run beside the patient GEMM + gather between two of them
+            main = torch.cuda.current_stream()
+            vocab_tables()
+            vocab_scatter()
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                vocab_small()
+            patient_gather(lambda: None)
+            main.wait_stream(self.side)
+            patient_bn()
         else:
             vocab_tables()
-            patient_side(lambda: None)
-            vocab_side()
+            patient_gather(lambda: None)
+            patient_bn()
+            vocab_scatter()
+            vocab_small()
         rec.update(y=y, folds=folds, pros=pros, l=l, tables=tables)
         return out, rec
 
@@ -633,12 +668,19 @@ class _Run:
         x, y = rec["x"], rec["y"]
         dy = {}
 
-        def bn_bwd_t(t):
+        def bn_bwd_t(t, sums=None):
             gt = g_out.get(t)
             if gt is None or t not in y:
                 return
             bn_prefix = f"batch_norms.{l}.{t}" if self.m.use_batch_norm else None
-            dy[t] = self.bn_bwd(gt.contiguous(), y[t], rec["pros"][t], rec["folds"][t], bn_prefix, sharded=(t == ROW_TYPE))
+            dy[t] = self.bn_bwd(gt.contiguous(), y[t], rec["pros"][t], rec["folds"][t], bn_prefix,
+                                sharded=(t == ROW_TYPE), sums=sums)
+
+        def patient_sums():      # statistics of the patient rows' BN backward (sharded: a collective)
+            gt = g_out.get(ROW_TYPE)
+            if gt is None or ROW_TYPE not in y:
+                return None
+            return self.bn_bwd_sums(gt.contiguous(), y[ROW_TYPE], rec["pros"][ROW_TYPE], rec["folds"][ROW_TYPE], True)
 
         g_in: Dict[str, Optional[torch.Tensor]] = {t: None for t in x}
 
@@ -669,9 +711,9 @@ class _Run:
                 rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=dagg, simple=r.simple, mask_r=r.mask_r))
             return rels
 
-        def patient_1():
+        def patient_1(sums=None, reduce=True):
             """BN backward of the patient rows, their weight / data gradients, scatter of dy_P onto the vocab rows."""
-            bn_bwd_t(ROW_TYPE)
+            bn_bwd_t(ROW_TYPE, sums)
             dyP = dy.get(ROW_TYPE)
             if dyP is None or not rec["rin"]:
                 return None
@@ -686,14 +728,15 @@ class _Run:
                 rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=dT, simple=r.simple, mask_t=r.mask_t))
                 dTs.append(dT)
             ops.scatter_rows(rels, P, D, dyP)
-            self.allreduce(buf)
-            return dTs, dWsum, dbsum
+            if reduce:
+                self.allreduce(buf)
+            return dTs, dWsum, dbsum, buf
 
         def vocab_2(res):
             """Per-relation work behind the scatter: gradients of the vocab-table transforms T_v = x_v W_l^T."""
             if res is None:
                 return
-            dTs, dWsum, dbsum = res
+            dTs, dWsum, dbsum, _ = res
             for r, dT in zip(rec["rin"], dTs):
                 nme = self.conv_name(l, r.edge_type)
                 self.acc(nme + ".lin_r.weight", dWsum, partial=True)
@@ -709,7 +752,7 @@ class _Run:
                 else:
                     ops.gather_rows(rels, P, D, g_in[ROW_TYPE], accumulate=True)
 
-        if self.overlap:
+        if self.overlap and self.comm is None:
             main, side = torch.cuda.current_stream(), self.side
             side.wait_stream(main)
             ev_tables, ev_scatter = torch.cuda.Event(), torch.cuda.Event()
@@ -722,6 +765,23 @@ class _Run:
                 side.wait_event(ev_scatter)
                 vocab_2(res)
             main.wait_event(ev_tables)
+            patient_2(rels)
+            main.wait_stream(side)
+        elif self.overlap:
+            # sharded: the two collectives of this layer (BN statistics, scattered partial sums) stay on the main stream
+            # and every fork is joined before the next one
+            main, side = torch.cuda.current_stream(), self.side
+            sums = patient_sums()                        # collective
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rels = vocab_1()
+            res = patient_1(sums, reduce=False)
+            main.wait_stream(side)
+            if res is not None:
+                self.allreduce(res[3])                   # collective
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                vocab_2(res)
             patient_2(rels)
             main.wait_stream(side)
         else:
