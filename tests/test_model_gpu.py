@@ -175,6 +175,27 @@ def test_other_hidden_dims_match_oracle(dev, hidden):
         assert float((gr - ograds[k]).abs().max()) <= 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax, k
 
 
+def test_mimic_schema_vocabulary_matches_oracle(dev):
+    """BASELINE.json config 5: the MIMIC-III schema keeps the top 50 labs / 200 diagnoses / 100 medications
+    (conf/config.yaml:70,101,112) -- a vocabulary layout other than eICU's (64 | 224 | 128 padded item rows)."""
+    n = (900, 50, 200, 100)
+    model, g, gd, gv, sd, ei, ea = make(dev, n, 128)
+    tr, va, te = ot.edge_splits(ei.shape[1], 0.7, 0.15, 0.15, 42)
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    w = ot.lab_weights(li, y, gv.num_nodes["lab"])
+    sup = ot.supervision_mask(int(tr.sum()), 0.2, torch.Generator().manual_seed(5))
+    model.train()
+    pred = model.predict_lab_values(gd, pi.to(dev), li.to(dev))
+    loss = ((pred[sup.to(dev)] - y[sup].to(dev)).abs() * w[li[sup]].to(dev)).mean()
+    loss.backward()
+    oloss, opred, ograds, obufs = ot.train_step_grads(sd, gv, pi, li, y, w, sup, p=0.0)
+    assert rel_err(pred.detach().cpu(), opred) <= TOL
+    gmax = max(float(v.abs().max()) for v in ograds.values())
+    for k, pm in model.named_parameters():
+        gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
+        assert float((gr - ograds[k]).abs().max()) <= 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax, k
+
+
 def test_forward_and_encode_are_differentiable(dev):
     model, g, gd, gv, sd, ei, ea = make(dev, (300, 12, 15, 10), 64)
     model.train()
