@@ -271,7 +271,9 @@ class _Run:
         # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
         # dependency chain) runs on a side stream underneath the patient-side kernels of the same layer
         # (MMG_OVERLAP=0: one stream).  Sharded runs keep every collective on the main stream.
-        self.overlap = os.environ.get("MMG_OVERLAP", "1") != "0"
+        # (below ~16 k patient rows every kernel is launch-sized and the fork / join events cost more than they hide)
+        ov = os.environ.get("MMG_OVERLAP", "1")                     # 0 = never, 2 = always (tests), else by size
+        self.overlap = ov != "0" and (ov == "2" or self.plan.n_rows >= 16384)
         if self.overlap:
             if getattr(model, "_side_stream", None) is None:
                 model._side_stream = torch.cuda.Stream(device=self.dev)

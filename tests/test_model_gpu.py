@@ -152,6 +152,17 @@ def test_train_step_matches_oracle_with_injected_dropout(dev, p):
             assert rel_err(b.cpu(), obufs[k]) <= TOL, k
 
 
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_train_step_with_side_stream_overlap(dev, p, monkeypatch):
+    """The vocab-side work of every layer on a side stream (on by default only above 16 k patients): same results."""
+    monkeypatch.setenv("MMG_OVERLAP", "2")
+    test_train_step_matches_oracle_with_injected_dropout(dev, p)
+    import mmgnn.model as mm
+    n, hidden = (500, 20, 25, 18), 128
+    model, g, gd, *_ = make(dev, n, hidden)
+    assert mm._Run(model, gd).overlap
+
+
 @pytest.mark.parametrize("hidden", [64, 256])
 def test_other_hidden_dims_match_oracle(dev, hidden):
     """BASELINE.json config 4 runs 256-d; the reference's own smoke test builds a 64-d model (model.py:642-648)."""

@@ -46,10 +46,12 @@ class ThreadComm:
             off += x.numel()
 
 
+@pytest.mark.parametrize("overlap", ["1", "2"])      # "2": vocab-side work on a side stream whatever the graph size
 @pytest.mark.parametrize("dropout", [0.0, 0.2])
-def test_two_virtual_shards_match_unsharded(dropout):
+def test_two_virtual_shards_match_unsharded(dropout, overlap, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    monkeypatch.setenv("MMG_OVERLAP", overlap)
     import mmgnn  # noqa: F401
     from mmgnn import dist as md
     from mmgnn.data import build_plan
@@ -174,11 +176,13 @@ class SoloComm:
             off += x.numel()
 
 
-def test_piecewise_graph_chain_matches_eager_steps():
+@pytest.mark.parametrize("overlap", ["1", "2"])
+def test_piecewise_graph_chain_matches_eager_steps(overlap, monkeypatch):
     """The chain of hipGraph segments (cut at every collective, forward/backward driven by hand) must train exactly like
     eager autograd steps: same losses, same parameters after three optimizer steps (dropout 0: no RNG in the way)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    monkeypatch.setenv("MMG_OVERLAP", overlap)
     import mmgnn  # noqa: F401
     from mmgnn import dist as md, ops
     from mmgnn.data import build_plan
