@@ -826,25 +826,41 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
   const int h = lane >> 5, l31 = lane & 31, ft = wid & 3;
   const int dcol = blockIdx.y * 128 + ft * 32 + l31;
   // ---- table pieces: B[k = item 16 ks + 8 h + j][n = this lane's feature column]
+  // (every load is issued before any is used: indices clamped, no branch in between -- a conditional load per element
+  //  made this prologue a chain of 2 x 80 dependent round trips, ~25 us of a 67 us launch)
   bf16x8 tb[NK / 2][3];
+  {
+    float tv[NK / 2][8], cv[NK / 2][8];
 #pragma unroll
-  for (int q = 0; q < NK / 2; ++q) {
-    const int ks = KB + q;
-    const int r = ks < K1 ? 0 : (ks < K2 ? 1 : 2);
-    const int kr = ks - (r == 0 ? 0 : (r == 1 ? K1 : K2));
-    const RelDev& R = rp.r[r];
-    float v[8];
+    for (int q = 0; q < NK / 2; ++q) {
+      const int ks = KB + q;
+      const int r = ks < K1 ? 0 : (ks < K2 ? 1 : 2);
+      const int kr = ks - (r == 0 ? 0 : (r == 1 ? K1 : K2));
+      const RelDev& R = rp.r[r];
+      const float* cs = R.colscale ? R.colscale : R.table;      // (any readable address when there is no scale)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int item = kr * 16 + 8 * h + j;
-      float t = 0.f;
-      if (item < R.n_cols) {
-        t = R.table[(size_t)item * D + dcol];
-        if (R.colscale) t *= R.colscale[item];
+      for (int j = 0; j < 8; ++j) {
+        const int item = kr * 16 + 8 * h + j;
+        const int ic = item < R.n_cols ? item : 0;
+        tv[q][j] = R.table[(size_t)ic * D + dcol];
+        cv[q][j] = cs[ic];
       }
-      v[j] = t;
     }
-    split8(v, tb[q][0], tb[q][1], tb[q][2]);
+#pragma unroll
+    for (int q = 0; q < NK / 2; ++q) {
+      const int ks = KB + q;
+      const int r = ks < K1 ? 0 : (ks < K2 ? 1 : 2);
+      const int kr = ks - (r == 0 ? 0 : (r == 1 ? K1 : K2));
+      const RelDev& R = rp.r[r];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int item = kr * 16 + 8 * h + j;
+        const float t = R.colscale ? tv[q][j] * cv[q][j] : tv[q][j];
+        v[j] = item < R.n_cols ? t : 0.f;
+      }
+      split8(v, tb[q][0], tb[q][1], tb[q][2]);
+    }
   }
   constexpr int NF0 = K1, NF1 = K2 - K1, NF2 = NK - K2;             // 16-bit fields per (row, half)
   static_assert(NF0 % 2 == 0 && NF1 % 2 == 0 && NF2 % 2 == 0 && K1 % 2 == 0 && K2 % 2 == 0 && NK % 4 == 0,
