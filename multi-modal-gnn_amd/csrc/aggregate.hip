@@ -904,8 +904,10 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
     if (ACCUM && KH == 0) loadprev(t_beg, prev);
   }
 
-  int par = 0;
-  for (int tile = t_beg; tile < t_end; tile += t_step, par ^= 1) {
+  // The tile body, called once before the loop (peeled): the loop is then entered with the same loads / stores in flight
+  // as on its back edge, so the vmcnt waits the compiler derives (the minimum over both edges) are the steady-state ones
+  // and the stores of a tile are not waited for at the top of the next one.
+  auto tile_body = [&](int tile, int par) {
     const int tn = tile + t_step < t_end ? tile + t_step : tile;
     loadm(tn, mnxt);
     if (h == 0) {
@@ -972,6 +974,11 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
     }
 #pragma unroll
     for (int i = 0; i < NK / 4; ++i) mcur[i] = mnxt[i];
+  };
+  if (t_beg < t_end) {
+    tile_body(t_beg, 0);
+    int par = 1;
+    for (int tile = t_beg + t_step; tile < t_end; tile += t_step, par ^= 1) tile_body(tile, par);
   }
   if (stat_partial) {                    // (a workgroup-uniform branch: both wave halves take it)
     __syncthreads();                     // the exchange tiles are dead
