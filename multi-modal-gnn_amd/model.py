@@ -357,8 +357,9 @@ class _Run:
         # their dropout masks, so with p == 0 (or eval) one pass is computed and BN running stats are
         # advanced twice.
         if self.p > 0:
-            enc0 = self.enc_fwd(0, 1)
-            enc1 = self.enc_fwd(1, 1)
+            first = self.enc_first(2)            # shared by both passes (no dropout before the first BatchNorm)
+            enc0 = self.enc_fwd(0, 1, first)
+            enc1 = self.enc_fwd(1, 1, first)
         else:
             enc0 = enc1 = self.enc_fwd(0, 2)
         init = self.enc_dict(enc0)
@@ -407,8 +408,11 @@ class _Run:
                     tot = gp if gi is None else gp.index_add_(0, gi[0], gi[1])
                 self.enc_bwd(enc0, tot)
             else:
-                self.enc_bwd(enc1, g.get(ROW_TYPE))
-                self.enc_bwd(enc0, dense(gi))
+                d1 = self.enc_bwd(enc1, g.get(ROW_TYPE), defer_first=True)
+                d0 = self.enc_bwd(enc0, dense(gi), defer_first=True)
+                dz1 = d1 if d0 is None else (d0 if d1 is None else d1.add_(d0))
+                if dz1 is not None:
+                    self.enc_bwd_first(enc0, dz1)
             for t, gt in g.items():
                 if t != ROW_TYPE and gt is not None:
                     self.acc(f"embeddings.{t}.weight", gt)
@@ -445,14 +449,22 @@ class _Run:
         return ops.bn_finalize(None, count, mod.weight.detach(), mod.bias.detach(), mod.running_mean, mod.running_var,
                                False, 0)
 
-    def enc_fwd(self, call, n_updates):
+    def enc_first(self, n_updates):
+        """First linear + BatchNorm statistics of patient_transform.  No dropout sits in front of them, so the two
+        encode_nodes passes of a training step (F7) share them bit for bit: computed once, the BatchNorm running
+        statistics advanced n_updates times."""
         pt = self.m.patient_transform
         E = self.W(f"embeddings.{ROW_TYPE}.weight")
-        off = self.plan.row_offset
         # the batch statistics of z1 / z2 come out of the GEMM epilogue (training mode)
         z1, s1 = ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach(), with_stats=True) if self.T else \
             (ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach()), None)
         f1 = self.bn_fold(z1, pt[1], n_updates, sharded=True, sums=s1)
+        return E, z1, f1
+
+    def enc_fwd(self, call, n_updates, first=None):
+        pt = self.m.patient_transform
+        off = self.plan.row_offset
+        E, z1, f1 = first if first is not None else self.enc_first(n_updates)
         pro1 = Pro(f1.scale, f1.shift, True, self.p, self.seed, 2 * call, off, self.seed_dev)
         z2, s2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1, with_stats=True) if self.T else \
             (ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1), None)
@@ -514,15 +526,24 @@ class _Run:
             return ops.linear_fwd(dy, self.W(wname), w_kn=True)          # dX = dY . W, W read in place
         return None
 
-    def enc_bwd(self, enc, g_x0):
+    def enc_bwd(self, enc, g_x0, defer_first=False):
+        """defer_first: stop in front of the first linear and return dz1 (the two passes of a training step share that
+        layer: their dz1 are summed and it is differentiated once, enc_bwd_first)."""
         if g_x0 is None:
-            return
+            return None
         pt = "patient_transform"
         dz3 = ops.l2norm_bwd(g_x0.contiguous(), enc["x0"], enc["rn"])
         g = self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
         dz2 = self.bn_bwd(g, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5", sharded=True)
         g = self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
         dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True)
+        if defer_first:
+            return dz1
+        self.enc_bwd_first(enc, dz1)
+        return None
+
+    def enc_bwd_first(self, enc, dz1):
+        pt = "patient_transform"
         ename = f"embeddings.{ROW_TYPE}.weight"
         need_dE = self.params[ename].requires_grad
         # the second encoder pass (dropout: encode_nodes runs twice, F7) adds its dE inside the GEMM
