@@ -171,13 +171,14 @@ int mmg_affine_act_drop(const float* Y, const mmg_prologue_t* pro, float* out, i
  * pass 2 (apply):  dy = scale * (g_out - c0[k] - xhat*c1[k]),  c0 = sums0/count, c1 = sums1/count
  *                  (eval mode: sums = NULL, c0 = c1 = 0).  `sums` is the (all-reduced, when sharded) output of pass 1
  *                  and inv_count = 1/count; dbeta / dgamma (nullable, [N] float) receive sums0 / sums1, the gradients
- *                  of the BatchNorm bias / weight. */
+ *                  of the BatchNorm bias / weight.  accumulate != 0: dY += (the two encode_nodes passes of a training
+ *                  step share their first layer: the second pass adds its gradient to the first one's). */
 int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
                      const float* rstd, double* sums, int64_t M, int N, void* ws, size_t ws_bytes,
                      void* stream);
 int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
                      const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
-                     float* dY, int64_t M, int N, void* stream);
+                     float* dY, int64_t M, int N, int accumulate, void* stream);
 
 /* Row L2 normalisation, F.normalize(p=2, dim=1, eps): out = z / max(||z||, eps); rnorm = 1/max(..) */
 int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, float eps, void* stream);

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const double* __restrict__ sums, double inv_count,
                                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                      float* __restrict__ dY, int64_t M, int N) {
+                                                      float* __restrict__ dY, int64_t M, int N, int accumulate) {
   pr.resolve();
   const int64_t n4 = M * (int64_t)(N / 4);
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -205,6 +205,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const int64_t r = i / (N / 4);
     const f32x4 g4 = *reinterpret_cast<const f32x4*>(G + (size_t)i * 4);
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
+    f32x4 prev = zero;
+    if (accumulate) prev = *reinterpret_cast<const f32x4*>(dY + (size_t)i * 4);
     f32x4 o, gm = g4;
     if (pr.relu) {
 #pragma unroll
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
         const float xh = (y4[j] - mu[j]) * rs[j];
         g = sc[j] * (g - a0[j] - xh * a1[j]);
       }
-      o[j] = g;
+      o[j] = g + prev[j];
     }
     *reinterpret_cast<f32x4*>(dY + (size_t)i * 4) = o;
   }
@@ -391,13 +393,13 @@ extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prolog
 
 extern "C" int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
                                 const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
-                                float* dY, int64_t M, int N, void* stream) {
+                                float* dY, int64_t M, int N, int accumulate, void* stream) {
   MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0 && 256 % (N / 4) == 0, "bn_bwd_apply: N=%d must be 4*2^k <= 1024", N);
   if (M == 0) return MMG_OK;
   MMG_CHECK_ARG(G && Y && dY, "bn_bwd_apply: null buffer");
   MMG_CHECK_ARG(!pro || !pro->scale || (mean && rstd), "bn_bwd_apply: affine prologue needs mean/rstd");
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, G, Y, mmg_pro_dev(pro),
-                     mean, rstd, sums, inv_count, dbeta, dgamma, dY, M, N);
+                     mean, rstd, sums, inv_count, dbeta, dgamma, dY, M, N, accumulate);
   MMG_CHECK_LAUNCH("bn_bwd_apply");
   return MMG_OK;
 }

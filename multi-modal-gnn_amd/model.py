@@ -409,8 +409,8 @@ class _Run:
                 self.enc_bwd(enc0, tot)
             else:
                 d1 = self.enc_bwd(enc1, g.get(ROW_TYPE), defer_first=True)
-                d0 = self.enc_bwd(enc0, dense(gi), defer_first=True)
-                dz1 = d1 if d0 is None else (d0 if d1 is None else d1.add_(d0))
+                d0 = self.enc_bwd(enc0, dense(gi), defer_first=True, dz1_into=d1)
+                dz1 = d0 if d0 is not None else d1
                 if dz1 is not None:
                     self.enc_bwd_first(enc0, dz1)
             for t, gt in g.items():
@@ -489,19 +489,22 @@ class _Run:
             self.allreduce(sums)
         return sums
 
-    def bn_bwd(self, g, y, pro: Pro, fold: Optional[ops.BNFold], bn_prefix: Optional[str], sharded: bool, sums=None):
-        """grad wrt the pre-BN tensor y of  x' = dropout(relu(BN(y)));  accumulates d gamma / d beta."""
+    def bn_bwd(self, g, y, pro: Pro, fold: Optional[ops.BNFold], bn_prefix: Optional[str], sharded: bool, sums=None,
+               add_into=None):
+        """grad wrt the pre-BN tensor y of  x' = dropout(relu(BN(y)));  accumulates d gamma / d beta.
+        add_into: add the result to this tensor (inside the kernel) instead of returning a new one."""
+        acc = add_into is not None
         if fold is None:        # no batch norm: relu/dropout only
-            return ops.bn_bwd_apply(g, y, pro, None)
+            return ops.bn_bwd_apply(g, y, pro, None, out=add_into, accumulate=acc)
         if sums is None:
             sums = self.bn_bwd_sums(g, y, pro, fold, sharded)
         N = y.shape[1]
         dbg = torch.empty(2, N, device=y.device)       # d beta | d gamma, written by the apply kernel
         if fold.training:
-            dy = ops.bn_bwd_apply(g, y, pro, fold, sums, fold.count, dbg[0], dbg[1])
+            dy = ops.bn_bwd_apply(g, y, pro, fold, sums, fold.count, dbg[0], dbg[1], out=add_into, accumulate=acc)
         else:
             dbg.copy_(sums)
-            dy = ops.bn_bwd_apply(g, y, pro, fold)
+            dy = ops.bn_bwd_apply(g, y, pro, fold, out=add_into, accumulate=acc)
         self.acc(bn_prefix + ".bias", dbg[0])
         self.acc(bn_prefix + ".weight", dbg[1])
         return dy
@@ -526,9 +529,10 @@ class _Run:
             return ops.linear_fwd(dy, self.W(wname), w_kn=True)          # dX = dY . W, W read in place
         return None
 
-    def enc_bwd(self, enc, g_x0, defer_first=False):
+    def enc_bwd(self, enc, g_x0, defer_first=False, dz1_into=None):
         """defer_first: stop in front of the first linear and return dz1 (the two passes of a training step share that
-        layer: their dz1 are summed and it is differentiated once, enc_bwd_first)."""
+        layer: their dz1 are summed -- dz1_into: inside the BatchNorm-backward kernel -- and it is differentiated once,
+        enc_bwd_first)."""
         if g_x0 is None:
             return None
         pt = "patient_transform"
@@ -536,7 +540,7 @@ class _Run:
         g = self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
         dz2 = self.bn_bwd(g, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5", sharded=True)
         g = self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
-        dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True)
+        dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True, add_into=dz1_into)
         if defer_first:
             return dz1
         self.enc_bwd_first(enc, dz1)

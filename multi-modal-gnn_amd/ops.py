@@ -385,17 +385,20 @@ def bn_bwd_stats(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold):
 
 
 def bn_bwd_apply(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFold], sums=None, count: float = 1.0,
-                 dbeta=None, dgamma=None, out: Optional[torch.Tensor] = None):
-    """sums: the fp64 [2,N] output of bn_bwd_stats (None in eval mode); dbeta / dgamma ([N] float) receive its rows."""
+                 dbeta=None, dgamma=None, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """sums: the fp64 [2,N] output of bn_bwd_stats (None in eval mode); dbeta / dgamma ([N] float) receive its rows.
+    accumulate: out += (needs out)."""
     lib = _lib.load()
     M, N = y.shape
+    if accumulate and out is None:
+        raise ValueError("accumulate needs out")
     out = torch.empty_like(y) if out is None else out
     _tok = _pb("bn_bwd_apply")
     check(lib.mmg_bn_bwd_apply(_p(g), _p(y), _pro(pro), _p(fold.mean) if fold else None,
                                _p(fold.rstd) if fold else None, _p(sums, torch.float64), 1.0 / float(count),
-                               _p(dbeta), _p(dgamma), _p(out), M, N, _stream()),
+                               _p(dbeta), _p(dgamma), _p(out), M, N, int(accumulate), _stream()),
           "mmg_bn_bwd_apply")
-    _pe(_tok, "bn_bwd_apply", 12 * M * N, 0)
+    _pe(_tok, "bn_bwd_apply", (16 if accumulate else 12) * M * N, 0)
     return out
 
 

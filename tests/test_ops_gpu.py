@@ -331,6 +331,9 @@ def test_bn_relu_dropout_backward(ops, dev, p):
     dy = ops.bn_bwd_apply(g.to(dev), y.to(dev), pro, fold, sums, M, dbg[0], dbg[1])
     assert rel(dy, yd.grad) <= 2e-5
     assert torch.equal(dbg.double(), sums.float().double())        # d beta / d gamma ride along
+    acc = torch.full((M, N), 0.5, device=dev)                      # accumulate: the result is ADDED to the target
+    ops.bn_bwd_apply(g.to(dev), y.to(dev), pro, fold, sums, M, out=acc, accumulate=True)
+    assert torch.equal(acc, dy + 0.5)
 
 
 @pytest.mark.parametrize("N", [64, 128, 256])
