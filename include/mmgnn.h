@@ -164,6 +164,11 @@ int mmg_bn_finalize(const double* sums, int64_t count, const float* gamma, const
 /* out = dropout(relu(y*scale + shift))  materialised                                */
 int mmg_affine_act_drop(const float* Y, const mmg_prologue_t* pro, float* out, int64_t M, int N,
                         void* stream);
+/* The same for a subset of rows:  out[s, :] = dropout(relu(y[rows[s], :]*scale + shift)),  s < n_sel, the dropout
+ * mask being the one of row rows[s] of the full tensor.  (The tabular head only sees the low-degree patients of the
+ * first encode_nodes pass: everything after its last BatchNorm runs on those rows alone.) */
+int mmg_affine_act_drop_rows(const float* Y, const mmg_prologue_t* pro, const int64_t* rows, int64_t n_sel,
+                             float* out, int N, void* stream);
 
 /* Backward through dropout -> relu -> affine(BN):
  *   g_out = g * keepmask/(1-p) * [y*scale+shift > 0]

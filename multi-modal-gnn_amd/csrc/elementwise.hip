@@ -171,6 +171,23 @@ __global__ __launch_bounds__(256) void k_affine_act_drop(const float* __restrict
   }
 }
 
+__global__ __launch_bounds__(256) void k_affine_act_drop_rows(const float* __restrict__ Y, ProDev pr,
+                                                              const int64_t* __restrict__ rows, int64_t n_sel,
+                                                              float* __restrict__ out, int N) {
+  pr.resolve();
+  const int64_t n4 = n_sel * (int64_t)(N / 4);
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const int64_t s = i / (N / 4);
+  const int c = (int)(i % (N / 4)) * 4;
+  const int64_t r = rows[s];
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (pr.scale) { sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c); }
+  f32x4 v = *reinterpret_cast<const f32x4*>(Y + (size_t)r * N + c);
+  mmg_pro_apply4(pr, v, sc, sh, r, c, N);
+  *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
+}
+
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ Y, ProDev pr,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const double* __restrict__ sums, double inv_count,
@@ -375,6 +392,19 @@ extern "C" int mmg_affine_act_drop(const float* Y, const mmg_prologue_t* pro, fl
   hipLaunchKernelGGL(k_affine_act_drop, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, Y, mmg_pro_dev(pro),
                      out, M, N);
   MMG_CHECK_LAUNCH("affine_act_drop");
+  return MMG_OK;
+}
+
+extern "C" int mmg_affine_act_drop_rows(const float* Y, const mmg_prologue_t* pro, const int64_t* rows, int64_t n_sel,
+                                        float* out, int N, void* stream) {
+  MMG_CHECK_ARG(n_sel >= 0 && N > 0 && N % 4 == 0, "affine_act_drop_rows: N=%d must be a multiple of 4", N);
+  MMG_CHECK_ARG(!pro || !pro->scale || pro->shift, "affine_act_drop_rows: prologue scale without shift");
+  if (n_sel == 0) return MMG_OK;
+  MMG_CHECK_ARG(Y && rows && out, "affine_act_drop_rows: null buffer");
+  const int64_t n4 = n_sel * (int64_t)(N / 4);
+  hipLaunchKernelGGL(k_affine_act_drop_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Y,
+                     mmg_pro_dev(pro), rows, n_sel, out, N);
+  MMG_CHECK_LAUNCH("affine_act_drop_rows");
   return MMG_OK;
 }
 

@@ -358,11 +358,12 @@ class _Run:
         # advanced twice.
         if self.p > 0:
             first = self.enc_first(2)            # shared by both passes (no dropout before the first BatchNorm)
-            enc0 = self.enc_fwd(0, 1, first)
+            enc0 = self.enc_fwd(0, 1, first, rows=self.pairs[4][5])      # feeds the tabular head only: low-degree rows
             enc1 = self.enc_fwd(1, 1, first)
         else:
             enc0 = enc1 = self.enc_fwd(0, 2)
         init = self.enc_dict(enc0)
+        self._init_compact = enc0.get("rows") is not None
         fin, layers = self.layers_fwd(self.enc_dict(enc1))
         pred, hrec = self.heads_fwd(init, fin)
         self.tape["mode"] = ("predict", enc0, enc1, layers, hrec)
@@ -409,7 +410,7 @@ class _Run:
                 self.enc_bwd(enc0, tot)
             else:
                 d1 = self.enc_bwd(enc1, g.get(ROW_TYPE), defer_first=True)
-                d0 = self.enc_bwd(enc0, dense(gi), defer_first=True, dz1_into=d1)
+                d0 = self.enc_bwd(enc0, gi if enc0.get("rows") is not None else dense(gi), defer_first=True, dz1_into=d1)
                 dz1 = d0 if d0 is not None else d1
                 if dz1 is not None:
                     self.enc_bwd_first(enc0, dz1)
@@ -461,7 +462,10 @@ class _Run:
         f1 = self.bn_fold(z1, pt[1], n_updates, sharded=True, sums=s1)
         return E, z1, f1
 
-    def enc_fwd(self, call, n_updates, first=None):
+    def enc_fwd(self, call, n_updates, first=None, rows=None):
+        """rows (int64 ids): everything after the last BatchNorm -- third linear, L2 norm -- is evaluated for these rows
+        only and x0 / rn are compact [len(rows), .] (the first encode_nodes pass of a training step only feeds the
+        tabular head, which only sees the low-degree patients; its BatchNorm statistics still need every row)."""
         pt = self.m.patient_transform
         off = self.plan.row_offset
         E, z1, f1 = first if first is not None else self.enc_first(n_updates)
@@ -470,6 +474,11 @@ class _Run:
             (ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1), None)
         f2 = self.bn_fold(z2, pt[5], n_updates, sharded=True, sums=s2)
         pro2 = Pro(f2.scale, f2.shift, True, self.p, self.seed, 2 * call + 1, off, self.seed_dev)
+        if rows is not None:
+            act = ops.affine_act_drop_rows(z2, pro2, rows)       # the dropout masks of the ORIGINAL rows
+            z3 = ops.linear_fwd(act, pt[8].weight.detach(), pt[8].bias.detach())
+            x0, rn = ops.l2norm_fwd(z3)
+            return dict(E=E, z1=z1, z2=z2, x0=x0, rn=rn, f1=f1, f2=f2, pro1=pro1, pro2=pro2, rows=rows, act=act)
         z3 = ops.linear_fwd(z2, pt[8].weight.detach(), pt[8].bias.detach(), pro=pro2)
         x0, rn = ops.l2norm_fwd(z3)
         return dict(E=E, z1=z1, z2=z2, x0=x0, rn=rn, f1=f1, f2=f2, pro1=pro1, pro2=pro2)
@@ -536,8 +545,15 @@ class _Run:
         if g_x0 is None:
             return None
         pt = "patient_transform"
-        dz3 = ops.l2norm_bwd(g_x0.contiguous(), enc["x0"], enc["rn"])
-        g = self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
+        if enc.get("rows") is not None:      # compact tail: g_x0 = (row ids, gradient rows)
+            rows, g_rows = g_x0
+            dz3 = ops.l2norm_bwd(g_rows.contiguous(), enc["x0"], enc["rn"])
+            g_act = self.lin_bwd(dz3, enc["act"], None, f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
+            g = torch.zeros(self.plan.n_rows, self.D, device=self.dev)
+            g[rows] = g_act
+        else:
+            dz3 = ops.l2norm_bwd(g_x0.contiguous(), enc["x0"], enc["rn"])
+            g = self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
         dz2 = self.bn_bwd(g, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5", sharded=True)
         g = self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
         dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True, add_into=dz1_into)
@@ -841,7 +857,10 @@ class _Run:
         rec = dict(init=init, fin=fin)
         for which, src, want_low in (("edge_predictor", fin, False), ("tabular_mlp", init, True)):
             # tabular_mlp: patient rows, ids and gate of the compacted low-degree patients (gate: all of them are low)
-            xP = src[ROW_TYPE].index_select(0, low_rows) if want_low else src[ROW_TYPE]
+            if want_low and self._init_compact:
+                xP = src[ROW_TYPE]                                   # the first pass was evaluated on these rows only
+            else:
+                xP = src[ROW_TYPE].index_select(0, low_rows) if want_low else src[ROW_TYPE]
             head, w1a, w1b = self.head_tensors(which, xP, src["lab"])
             sel, n_sel, nb = (sel_low, counts[0:1], n_low) if want_low else (sel_high, counts[1:2], n_high)
             ops.pair_head_fwd(head, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr, want_low,

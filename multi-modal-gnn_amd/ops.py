@@ -371,6 +371,18 @@ def affine_act_drop(y: torch.Tensor, pro: Pro, out: Optional[torch.Tensor] = Non
     return out
 
 
+def affine_act_drop_rows(y: torch.Tensor, pro: Pro, rows: torch.Tensor):
+    """dropout(relu(y[rows]*scale+shift)) for the selected rows (int64 ids); the dropout mask is the one the full tensor
+    would get at those rows."""
+    lib = _lib.load()
+    N = y.shape[1]
+    n = rows.numel()
+    out = torch.empty(n, N, dtype=torch.float32, device=y.device)
+    check(lib.mmg_affine_act_drop_rows(_p(y), _pro(pro), _p(rows, torch.int64), n, _p(out), N, _stream()),
+          "mmg_affine_act_drop_rows")
+    return out
+
+
 def bn_bwd_stats(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold):
     lib = _lib.load()
     M, N = y.shape
