@@ -185,6 +185,17 @@ int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, 
                      const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
                      float* dY, int64_t M, int N, int accumulate, void* stream);
 
+/* The same backward for an upstream gradient that is zero outside a short list of rows (G_rows [n_sel, N] holds the rows
+ * rows[s]; masks are those of the ORIGINAL rows):  mmg_bn_bwd_stats_rows gives the sums of pass 1 from the listed rows
+ * alone; mmg_bn_bwd_apply with G = NULL writes the dense part of pass 2; mmg_bn_bwd_apply_rows adds scale * g_out to the
+ * listed rows of dY (rows must be distinct). */
+size_t mmg_bn_bwd_stats_rows_ws_bytes(int N);
+int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
+                          const mmg_prologue_t* pro, const float* mean, const float* rstd, double* sums, int N,
+                          void* ws, size_t ws_bytes, void* stream);
+int mmg_bn_bwd_apply_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
+                          const mmg_prologue_t* pro, float* dY, int N, void* stream);
+
 /* Row L2 normalisation, F.normalize(p=2, dim=1, eps): out = z / max(||z||, eps); rnorm = 1/max(..) */
 int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, float eps, void* stream);
 /* dz = rnorm * (g - out * <out, g>)   (rows whose norm hit eps: dz = g * rnorm)     */

@@ -188,6 +188,83 @@ __global__ __launch_bounds__(256) void k_affine_act_drop_rows(const float* __res
   *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
 }
 
+// BatchNorm backward with an upstream gradient that is zero outside a short row list (the tabular head only reaches the
+// low-degree patients): the column statistics need those rows only, the dense apply pass runs without G, and the listed
+// rows are patched afterwards.  g' = G_rows * [y*scale+shift > 0] * keepmask/(1-p) with the masks of the ORIGINAL rows.
+__device__ __forceinline__ f32x4 bn_rows_gprime(const ProDev& pr, f32x4 g, const f32x4& y, const f32x4& sc, const f32x4& sh,
+                                                int64_t row, int c, int N) {
+  if (pr.relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float act = pr.scale ? fmaf(y[j], sc[j], sh[j]) : y[j];
+      if (!(act > 0.f)) g[j] = 0.f;
+    }
+  }
+  if (pr.p > 0.f) mmg_drop4(g, pr.key, (uint64_t)(pr.row_offset + row) * (uint64_t)N + (uint64_t)c, pr.thr, pr.inv_keep);
+  return g;
+}
+
+// thread = (row lane, column quad); partial[block][0,:] = sum g', partial[block][1,:] = sum g' * xhat over the block's share
+// of the listed rows (dealt round-robin); k_partial_sum adds the blocks in fixed order
+constexpr int BSR_MAX_BLOCKS = 128;
+__global__ __launch_bounds__(256) void k_bn_bwd_stats_rows(const float* __restrict__ Grows, const float* __restrict__ Y,
+                                                           const int64_t* __restrict__ rows, int64_t n_sel, ProDev pr,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           double* __restrict__ partial, int N) {
+  pr.resolve();
+  __shared__ double red[8 * 2 * 256];             // [row lanes <= 8][2][N <= 256]
+  const int cg = N / 4, rl = 256 / cg;
+  const int c4 = threadIdx.x % cg, rr = threadIdx.x / cg, c = c4 * 4;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc = one, sh = zero;
+  if (pr.scale) { sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c); }
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  for (int64_t s = (int64_t)blockIdx.x * rl + rr; s < n_sel; s += (int64_t)gridDim.x * rl) {
+    const int64_t r = rows[s];
+    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + (size_t)r * N + c);
+    const f32x4 g = bn_rows_gprime(pr, *reinterpret_cast<const f32x4*>(Grows + (size_t)s * N + c), y, sc, sh, r, c, N);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s0[j] += (double)g[j];
+      s1[j] += (double)g[j] * (double)((y[j] - mu[j]) * rs[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[(rr * 2 + 0) * N + c + j] = s0[j];
+    red[(rr * 2 + 1) * N + c + j] = s1[j];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * N; i += 256) {
+    double t = 0;
+    for (int q = 0; q < rl; ++q) t += red[q * 2 * N + i];
+    partial[(size_t)blockIdx.x * 2 * N + i] = t;
+  }
+}
+
+// dY[rows[s], :] += scale * g'   (the g' term the G-less apply pass left out)
+__global__ __launch_bounds__(256) void k_bn_bwd_apply_rows(const float* __restrict__ Grows, const float* __restrict__ Y,
+                                                           const int64_t* __restrict__ rows, int64_t n_sel, ProDev pr,
+                                                           float* __restrict__ dY, int N) {
+  pr.resolve();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_sel * (int64_t)(N / 4)) return;
+  const int64_t s = i / (N / 4);
+  const int c = (int)(i % (N / 4)) * 4;
+  const int64_t r = rows[s];
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc = one, sh = zero;
+  if (pr.scale) { sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c); }
+  const f32x4 y = *reinterpret_cast<const f32x4*>(Y + (size_t)r * N + c);
+  const f32x4 g = bn_rows_gprime(pr, *reinterpret_cast<const f32x4*>(Grows + (size_t)s * N + c), y, sc, sh, r, c, N);
+  f32x4* d = reinterpret_cast<f32x4*>(dY + (size_t)r * N + c);
+  f32x4 o = *d;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = fmaf(sc[j], g[j], o[j]);
+  *d = o;
+}
+
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ Y, ProDev pr,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const double* __restrict__ sums, double inv_count,
@@ -220,7 +297,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   }
   for (; i < n4; i += stride) {
     const int64_t r = i / (N / 4);
-    const f32x4 g4 = *reinterpret_cast<const f32x4*>(G + (size_t)i * 4);
+    const f32x4 g4 = G ? *reinterpret_cast<const f32x4*>(G + (size_t)i * 4) : zero;     // no G: an all-zero upstream
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
     f32x4 prev = zero;
     if (accumulate) prev = *reinterpret_cast<const f32x4*>(dY + (size_t)i * 4);
@@ -421,12 +498,46 @@ extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prolog
   return MMG_OK;
 }
 
+extern "C" size_t mmg_bn_bwd_stats_rows_ws_bytes(int N) { return (size_t)BSR_MAX_BLOCKS * 2 * (size_t)(N > 0 ? N : 0) * 8 + 256; }
+
+extern "C" int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
+                                     const mmg_prologue_t* pro, const float* mean, const float* rstd, double* sums, int N,
+                                     void* ws, size_t ws_bytes, void* stream) {
+  MMG_CHECK_ARG(n_sel >= 0 && sums && mean && rstd, "bn_bwd_stats_rows: bad args");
+  MMG_CHECK_ARG(N > 0 && N % 4 == 0 && N <= 256 && 256 % (N / 4) == 0, "bn_bwd_stats_rows: N=%d unsupported", N);
+  hipStream_t st = (hipStream_t)stream;
+  if (n_sel == 0) { hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st); return MMG_OK; }
+  MMG_CHECK_ARG(G_rows && Y && rows && ws, "bn_bwd_stats_rows: null buffer");
+  MMG_CHECK_ARG(ws_bytes >= mmg_bn_bwd_stats_rows_ws_bytes(N), "bn_bwd_stats_rows: workspace too small");
+  double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  const int rl = 256 / (N / 4);
+  int64_t nblk = (n_sel + rl - 1) / rl;
+  if (nblk > BSR_MAX_BLOCKS) nblk = BSR_MAX_BLOCKS;
+  hipLaunchKernelGGL(k_bn_bwd_stats_rows, dim3((unsigned)nblk), dim3(256), 0, st, G_rows, Y, rows, n_sel, mmg_pro_dev(pro),
+                     mean, rstd, partial, N);
+  hipLaunchKernelGGL(k_partial_sum, dim3((2 * N + 3) / 4), dim3(256), 0, st, partial, sums, 2 * N, (int)nblk);
+  MMG_CHECK_LAUNCH("bn_bwd_stats_rows");
+  return MMG_OK;
+}
+
+extern "C" int mmg_bn_bwd_apply_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
+                                     const mmg_prologue_t* pro, float* dY, int N, void* stream) {
+  MMG_CHECK_ARG(n_sel >= 0 && N > 0 && N % 4 == 0, "bn_bwd_apply_rows: bad args");
+  if (n_sel == 0) return MMG_OK;
+  MMG_CHECK_ARG(G_rows && Y && rows && dY, "bn_bwd_apply_rows: null buffer");
+  const int64_t n4 = n_sel * (int64_t)(N / 4);
+  hipLaunchKernelGGL(k_bn_bwd_apply_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, G_rows, Y,
+                     rows, n_sel, mmg_pro_dev(pro), dY, N);
+  MMG_CHECK_LAUNCH("bn_bwd_apply_rows");
+  return MMG_OK;
+}
+
 extern "C" int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
                                 const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
                                 float* dY, int64_t M, int N, int accumulate, void* stream) {
   MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0 && 256 % (N / 4) == 0, "bn_bwd_apply: N=%d must be 4*2^k <= 1024", N);
   if (M == 0) return MMG_OK;
-  MMG_CHECK_ARG(G && Y && dY, "bn_bwd_apply: null buffer");
+  MMG_CHECK_ARG(Y && dY, "bn_bwd_apply: null buffer");          // (G may be NULL: an all-zero upstream gradient)
   MMG_CHECK_ARG(!pro || !pro->scale || (mean && rstd), "bn_bwd_apply: affine prologue needs mean/rstd");
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, G, Y, mmg_pro_dev(pro),
                      mean, rstd, sums, inv_count, dbeta, dgamma, dY, M, N, accumulate);

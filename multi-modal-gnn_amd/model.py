@@ -518,6 +518,19 @@ class _Run:
         self.acc(bn_prefix + ".weight", dbg[1])
         return dy
 
+    def bn_bwd_rows(self, g_rows, rows, y, pro: Pro, fold: ops.BNFold, bn_prefix: str):
+        """bn_bwd (patient axis, training statistics) for an upstream gradient that is zero outside `rows`: statistics
+        from the listed rows alone, a dense apply pass that never reads a gradient tensor, the listed rows patched."""
+        sums = ops.bn_bwd_stats_rows(g_rows, y, rows, pro, fold)
+        if self.comm is not None:
+            self.allreduce(sums)
+        dbg = torch.empty(2, y.shape[1], device=y.device)
+        dy = ops.bn_bwd_apply(None, y, pro, fold, sums, fold.count, dbg[0], dbg[1])
+        ops.bn_bwd_apply_rows(g_rows, y, rows, pro, dy)
+        self.acc(bn_prefix + ".bias", dbg[0])
+        self.acc(bn_prefix + ".weight", dbg[1])
+        return dy
+
     def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False, dx_into=None):
         """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one."""
         gw = self.grads.get(wname)       # a second contribution (the encoder runs twice) accumulates inside the kernel
@@ -549,12 +562,11 @@ class _Run:
             rows, g_rows = g_x0
             dz3 = ops.l2norm_bwd(g_rows.contiguous(), enc["x0"], enc["rn"])
             g_act = self.lin_bwd(dz3, enc["act"], None, f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
-            g = torch.zeros(self.plan.n_rows, self.D, device=self.dev)
-            g[rows] = g_act
+            dz2 = self.bn_bwd_rows(g_act, rows, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5")
         else:
             dz3 = ops.l2norm_bwd(g_x0.contiguous(), enc["x0"], enc["rn"])
             g = self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
-        dz2 = self.bn_bwd(g, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5", sharded=True)
+            dz2 = self.bn_bwd(g, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5", sharded=True)
         g = self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
         dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True, add_into=dz1_into)
         if defer_first:

@@ -396,10 +396,30 @@ def bn_bwd_stats(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold):
     return out
 
 
-def bn_bwd_apply(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFold], sums=None, count: float = 1.0,
+def bn_bwd_stats_rows(g_rows: torch.Tensor, y: torch.Tensor, rows: torch.Tensor, pro: Pro, fold: BNFold):
+    """bn_bwd_stats for an upstream gradient that is zero outside `rows` (g_rows = its rows, in list order)."""
+    lib = _lib.load()
+    N = y.shape[1]
+    out = torch.empty(2, N, dtype=torch.float64, device=y.device)
+    ws = workspace(lib.mmg_bn_bwd_stats_rows_ws_bytes(N), y.device)
+    check(lib.mmg_bn_bwd_stats_rows(_p(g_rows), _p(y), _p(rows, torch.int64), rows.numel(), _pro(pro), _p(fold.mean),
+                                    _p(fold.rstd), _p(out, torch.float64), N, _p(ws, torch.uint8), ws.numel(), _stream()),
+          "mmg_bn_bwd_stats_rows")
+    return out
+
+
+def bn_bwd_apply_rows(g_rows: torch.Tensor, y: torch.Tensor, rows: torch.Tensor, pro: Pro, dy: torch.Tensor):
+    """dy[rows] += scale * g'  -- completes a bn_bwd_apply(None, ...) for the listed (distinct) rows."""
+    lib = _lib.load()
+    check(lib.mmg_bn_bwd_apply_rows(_p(g_rows), _p(y), _p(rows, torch.int64), rows.numel(), _pro(pro), _p(dy),
+                                    y.shape[1], _stream()), "mmg_bn_bwd_apply_rows")
+    return dy
+
+
+def bn_bwd_apply(g: Optional[torch.Tensor], y: torch.Tensor, pro: Pro, fold: Optional[BNFold], sums=None, count: float = 1.0,
                  dbeta=None, dgamma=None, out: Optional[torch.Tensor] = None, accumulate: bool = False):
     """sums: the fp64 [2,N] output of bn_bwd_stats (None in eval mode); dbeta / dgamma ([N] float) receive its rows.
-    accumulate: out += (needs out)."""
+    accumulate: out += (needs out).  g = None: an all-zero upstream gradient (see bn_bwd_apply_rows)."""
     lib = _lib.load()
     M, N = y.shape
     if accumulate and out is None:

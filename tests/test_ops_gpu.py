@@ -336,6 +336,33 @@ def test_bn_relu_dropout_backward(ops, dev, p):
     assert torch.equal(acc, dy + 0.5)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_row_subset_variants_match_the_dense_kernels(ops, dev, p):
+    """affine_act_drop_rows / bn_bwd_stats_rows / bn_bwd_apply(None) + bn_bwd_apply_rows == the dense kernels fed
+    with a gradient that is zero outside the listed rows (dropout masks of the ORIGINAL rows)."""
+    gen = torch.Generator().manual_seed(33)
+    M, N = 2500, 128
+    y = (torch.randn(M, N, generator=gen) * 1.5 + 0.2).to(dev)
+    rows = torch.randperm(M, generator=gen)[:173].sort().values.to(dev)
+    g_rows = torch.randn(rows.numel(), N, generator=gen).to(dev)
+    gamma, beta = (torch.rand(N, generator=gen) + 0.5).to(dev), (torch.randn(N, generator=gen) * 0.2).to(dev)
+    fold = ops.bn_finalize(ops.col_reduce2(y), M, gamma, beta, None, None, True)
+    pro = ops.Pro(fold.scale, fold.shift, True, p, seed=9, site=4, row_offset=11)
+    assert torch.equal(ops.affine_act_drop_rows(y, pro, rows), ops.affine_act_drop(y, pro)[rows])
+    g = torch.zeros(M, N, device=dev)
+    g[rows] = g_rows
+    sums_d = ops.bn_bwd_stats(g, y, pro, fold)
+    sums_r = ops.bn_bwd_stats_rows(g_rows, y, rows, pro, fold)
+    assert rel(sums_r, sums_d.cpu()) <= 1e-12
+    dy_d = ops.bn_bwd_apply(g, y, pro, fold, sums_d, M)
+    dy_r = ops.bn_bwd_apply(None, y, pro, fold, sums_d, M)
+    ops.bn_bwd_apply_rows(g_rows, y, rows, pro, dy_r)
+    assert rel(dy_r, dy_d.cpu()) <= 1e-6
+    empty = rows[:0]
+    assert ops.affine_act_drop_rows(y, pro, empty).shape == (0, N)
+    assert float(ops.bn_bwd_stats_rows(g_rows[:0], y, empty, pro, fold).abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize("N", [64, 128, 256])
 def test_l2norm(ops, dev, N):
     gen = torch.Generator().manual_seed(N)
