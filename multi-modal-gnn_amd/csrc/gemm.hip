@@ -157,6 +157,16 @@ typedef __bf16 xbf16x4 __attribute__((ext_vector_type(4)));
 // once per tile, which is what the first version of this kernel did), and in accumulate mode the old output tile is
 // loaded INTO the accumulator before the next tile is staged, so its latency hides under the split.
 typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
+// cache policy of the streamed operands (aux = 2: the `nt` bit -- X is read once, Y written once: -1.3 % on the step)
+#ifndef MMG_NT_LD
+#define MMG_NT_LD 2
+#endif
+#ifndef MMG_NT_ST
+#define MMG_NT_ST 2
+#endif
+#ifndef MMG_NT_WG
+#define MMG_NT_WG 0
+#endif
 
 template <int K, int WN, bool PRO, bool ACC>   // WN waves along N (32 columns each) over a 32-row tile: 64 * WN threads
 __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_fwd_x6(
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_fwd_x6(
         const_cast<float*>(X) + (size_t)(rows ? tile : 0) * BM * K, 0, rows * K * 4, 0x00020000);
 #pragma unroll
     for (int p = 0; p < NP; ++p)
-      nx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo, p * ROWS_PER_PASS * K * 4, 0));
+      nx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
   };
   auto stage = [&](int64_t tile, int buf, const f32x4* nx) {  // prologue + split + three plane writes
     const int64_t row0 = tile * BM;
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_fwd_x6(
     for (int i = 0; i < 16; ++i) {
       const int r = (i & 3) + 8 * (i >> 2);
       const float v = acc[i] + bv;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, yvo, r * N * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, yvo, r * N * 4, MMG_NT_ST);
       const float vs = r + 4 * h < rows ? v : 0.f;
       t1 += vs; t2 = fmaf(vs, vs, t2);
     }
@@ -591,10 +601,10 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
         const_cast<float*>(X) + (size_t)rb * K + tk0, 0, rows ? (rows * K - tk0) * 4 : 0, 0x00020000);
 #pragma unroll
     for (int u = 0; u < NY; ++u)
-      fy[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ys, yvo, u * RY * N * 4, 0));
+      fy[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ys, yvo, u * RY * N * 4, MMG_NT_WG));
 #pragma unroll
     for (int u = 0; u < NX; ++u)
-      fx[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, xvo, u * RX * K * 4, 0));
+      fx[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, xvo, u * RX * K * 4, MMG_NT_WG));
   };
   auto split_store = [&](f32x4 v, __bf16* plane0, int plane_elems, int off) {
     xbf16x4 q0, q1, q2;
@@ -772,7 +782,7 @@ __global__ __launch_bounds__(512) void k_linear_wgrad_ws(const float* __restrict
           const_cast<float*>(src) + (size_t)(rows ? r0 : 0) * ld + c0, 0, rows ? (rows * ld - c0) * 4 : 0, 0x00020000);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        f[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, j * ld * 4, 0));
+        f[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, j * ld * 4, MMG_NT_WG));
     };
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto stage = [&](int st, int buf, const f32x4* f) {
