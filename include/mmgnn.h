@@ -185,6 +185,16 @@ int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, 
                      const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
                      float* dY, int64_t M, int N, int accumulate, void* stream);
 
+/* Two upstream gradients through the SAME BatchNorm + ReLU, each with its own dropout mask (pro2: only its dropout fields
+ * are used) -- the two encode_nodes passes of a training step share their first layer:
+ * g_out = g_out(G; pro) + g_out(G2; pro2), one statistics pass and one apply pass instead of two of each. */
+int mmg_bn_bwd_stats2(const float* G, const float* G2, const float* Y, const mmg_prologue_t* pro,
+                      const mmg_prologue_t* pro2, const float* mean, const float* rstd, double* sums, int64_t M, int N,
+                      void* ws, size_t ws_bytes, void* stream);
+int mmg_bn_bwd_apply2(const float* G, const float* G2, const float* Y, const mmg_prologue_t* pro,
+                      const mmg_prologue_t* pro2, const float* mean, const float* rstd, const double* sums,
+                      double inv_count, float* dbeta, float* dgamma, float* dY, int64_t M, int N, void* stream);
+
 /* The same backward for an upstream gradient that is zero outside a short list of rows (G_rows [n_sel, N] holds the rows
  * rows[s]; masks are those of the ORIGINAL rows):  mmg_bn_bwd_stats_rows gives the sums of pass 1 from the listed rows
  * alone; mmg_bn_bwd_apply with G = NULL writes the dense part of pass 2; mmg_bn_bwd_apply_rows adds scale * g_out to the

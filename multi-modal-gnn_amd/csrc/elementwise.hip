@@ -31,8 +31,12 @@ template <int MODE, int NT>
 __global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, const float* __restrict__ B,
                                                    ProDev pr, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, double* __restrict__ partial,
-                                                   int64_t M, int N, int64_t rows_per_blk) {
+                                                   int64_t M, int N, int64_t rows_per_blk,
+                                                   const float* __restrict__ A2, ProDev pr2) {
+  // A2 / pr2 (MODE 1, nullable): a second upstream gradient through the SAME BatchNorm + ReLU with its own dropout
+  // mask (the two encode_nodes passes share their first layer): a = g_out(A, Y; pr) + g_out(A2, Y; pr2)
   pr.resolve();
+  if (MODE == 1 && A2) pr2.resolve();
   __shared__ double red[8 * NT];     // [rl][2][N] with rl*N == 4*NT
   const int cg = N / 4, rl = NT / cg;
   const int c4 = threadIdx.x % cg, rr = threadIdx.x / cg;
@@ -50,15 +54,22 @@ __global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, 
   auto body = [&](int64_t r, const f32x4& a_in, const f32x4& b) {
     f32x4 a = a_in;
     if (MODE == 1) {                 // a = upstream grad G, b = pre-BN activation Y: g through relu, then dropout
+      f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
+      if (A2) a2 = *reinterpret_cast<const f32x4*>(A2 + (size_t)r * N + c4 * 4);
       if (pr.relu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float o = pr.scale ? fmaf(b[j], sc[j], sh[j]) : b[j];
-          if (!(o > 0.f)) a[j] = 0.f;
+          if (!(o > 0.f)) { a[j] = 0.f; a2[j] = 0.f; }
         }
       }
       if (pr.p > 0.f)
         mmg_drop4(a, pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)(c4 * 4), pr.thr, pr.inv_keep);
+      if (A2) {
+        if (pr2.p > 0.f)
+          mmg_drop4(a2, pr2.key, (uint64_t)(pr2.row_offset + r) * (uint64_t)N + (uint64_t)(c4 * 4), pr2.thr, pr2.inv_keep);
+        a += a2;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -269,8 +280,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const double* __restrict__ sums, double inv_count,
                                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                      float* __restrict__ dY, int64_t M, int N, int accumulate) {
+                                                      float* __restrict__ dY, int64_t M, int N, int accumulate,
+                                                      const float* __restrict__ G2, ProDev pr2) {
   pr.resolve();
+  if (G2) pr2.resolve();
   const int64_t n4 = M * (int64_t)(N / 4);
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -301,15 +314,21 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
     f32x4 prev = zero;
     if (accumulate) prev = *reinterpret_cast<const f32x4*>(dY + (size_t)i * 4);
-    f32x4 o, gm = g4;
+    f32x4 o, gm = g4, gm2 = zero;
+    if (G2) gm2 = *reinterpret_cast<const f32x4*>(G2 + (size_t)i * 4);      // second upstream gradient (see k_col_reduce)
     if (pr.relu) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float act = pr.scale ? fmaf(y4[j], sc[j], sh[j]) : y4[j];
-        if (!(act > 0.f)) gm[j] = 0.f;
+        if (!(act > 0.f)) { gm[j] = 0.f; gm2[j] = 0.f; }
       }
     }
     if (pr.p > 0.f) mmg_drop4(gm, pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)c, pr.thr, pr.inv_keep);
+    if (G2) {
+      if (pr2.p > 0.f)
+        mmg_drop4(gm2, pr2.key, (uint64_t)(pr2.row_offset + r) * (uint64_t)N + (uint64_t)c, pr2.thr, pr2.inv_keep);
+      gm += gm2;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float g = gm[j];
@@ -403,22 +422,25 @@ inline unsigned ew_grid(int64_t n4) {
 
 template <int MODE>
 int run_col_reduce(const float* A, const float* B, const ProDev& pr, const float* mean, const float* rstd,
-                   double* out, int64_t M, int N, void* ws, size_t ws_bytes, hipStream_t st, const char* what) {
+                   double* out, int64_t M, int N, void* ws, size_t ws_bytes, hipStream_t st, const char* what,
+                   const float* A2 = nullptr, const ProDev* pr2p = nullptr) {
+  const ProDev pr2 = pr2p ? *pr2p : pr;
   ColGeom g;
   MMG_CHECK_ARG(col_geom(M, N, &g), "%s: N=%d unsupported", what, N);
   const size_t need = (size_t)g.nblk * 2 * N * 8 + 256;
   if (ws_bytes < need) { mmg_set_error("%s: workspace %zu < %zu", what, ws_bytes, need); return MMG_E_WS; }
   double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   if (g.nblk == 1) {      // small tables (vocab side): the single workgroup's result IS the answer
-    hipLaunchKernelGGL((k_col_reduce<MODE, 256>), dim3(1), dim3(256), 0, st, A, B, pr, mean, rstd, out, M, N, g.rows_per_blk);
+    hipLaunchKernelGGL((k_col_reduce<MODE, 256>), dim3(1), dim3(256), 0, st, A, B, pr, mean, rstd, out, M, N, g.rows_per_blk, A2,
+                       pr2);
     return MMG_OK;
   }
   if (g.nthr == 1024)
     hipLaunchKernelGGL((k_col_reduce<MODE, 1024>), dim3(g.nblk), dim3(1024), 0, st, A, B, pr, mean, rstd, partial, M, N,
-                       g.rows_per_blk);
+                       g.rows_per_blk, A2, pr2);
   else
     hipLaunchKernelGGL((k_col_reduce<MODE, 256>), dim3(g.nblk), dim3(256), 0, st, A, B, pr, mean, rstd, partial, M, N,
-                       g.rows_per_blk);
+                       g.rows_per_blk, A2, pr2);
   hipLaunchKernelGGL(k_partial_sum, dim3((2 * N + 3) / 4), dim3(256), 0, st, partial, out, 2 * N, g.nblk);
   return MMG_OK;
 }
@@ -498,6 +520,20 @@ extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prolog
   return MMG_OK;
 }
 
+extern "C" int mmg_bn_bwd_stats2(const float* G, const float* G2, const float* Y, const mmg_prologue_t* pro,
+                                 const mmg_prologue_t* pro2, const float* mean, const float* rstd, double* sums, int64_t M,
+                                 int N, void* ws, size_t ws_bytes, void* stream) {
+  MMG_CHECK_ARG(M >= 0 && sums && mean && rstd, "bn_bwd_stats2: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) { hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st); return MMG_OK; }
+  MMG_CHECK_ARG(G && G2 && Y && ws && pro && pro2, "bn_bwd_stats2: null buffer");
+  const ProDev p2 = mmg_pro_dev(pro2);
+  int rc = run_col_reduce<1>(G, Y, mmg_pro_dev(pro), mean, rstd, sums, M, N, ws, ws_bytes, st, "bn_bwd_stats2", G2, &p2);
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("bn_bwd_stats2");
+  return MMG_OK;
+}
+
 extern "C" size_t mmg_bn_bwd_stats_rows_ws_bytes(int N) { return (size_t)BSR_MAX_BLOCKS * 2 * (size_t)(N > 0 ? N : 0) * 8 + 256; }
 
 extern "C" int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
@@ -540,8 +576,21 @@ extern "C" int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prolog
   MMG_CHECK_ARG(Y && dY, "bn_bwd_apply: null buffer");          // (G may be NULL: an all-zero upstream gradient)
   MMG_CHECK_ARG(!pro || !pro->scale || (mean && rstd), "bn_bwd_apply: affine prologue needs mean/rstd");
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, G, Y, mmg_pro_dev(pro),
-                     mean, rstd, sums, inv_count, dbeta, dgamma, dY, M, N, accumulate);
+                     mean, rstd, sums, inv_count, dbeta, dgamma, dY, M, N, accumulate, (const float*)nullptr,
+                     mmg_pro_dev(pro));
   MMG_CHECK_LAUNCH("bn_bwd_apply");
+  return MMG_OK;
+}
+
+extern "C" int mmg_bn_bwd_apply2(const float* G, const float* G2, const float* Y, const mmg_prologue_t* pro,
+                                 const mmg_prologue_t* pro2, const float* mean, const float* rstd, const double* sums,
+                                 double inv_count, float* dbeta, float* dgamma, float* dY, int64_t M, int N, void* stream) {
+  MMG_CHECK_ARG(M >= 0 && N > 0 && N % 4 == 0 && 256 % (N / 4) == 0, "bn_bwd_apply2: N=%d must be 4*2^k <= 1024", N);
+  if (M == 0) return MMG_OK;
+  MMG_CHECK_ARG(G && G2 && Y && dY && pro && pro2 && mean && rstd, "bn_bwd_apply2: null buffer");
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(ew_grid(M * (N / 4))), dim3(256), 0, (hipStream_t)stream, G, Y, mmg_pro_dev(pro),
+                     mean, rstd, sums, inv_count, dbeta, dgamma, dY, M, N, 0, G2, mmg_pro_dev(pro2));
+  MMG_CHECK_LAUNCH("bn_bwd_apply2");
   return MMG_OK;
 }
 

@@ -409,11 +409,9 @@ class _Run:
                     tot = gp if gi is None else gp.index_add_(0, gi[0], gi[1])
                 self.enc_bwd(enc0, tot)
             else:
-                d1 = self.enc_bwd(enc1, g.get(ROW_TYPE), defer_first=True)
-                d0 = self.enc_bwd(enc0, gi if enc0.get("rows") is not None else dense(gi), defer_first=True, dz1_into=d1)
-                dz1 = d0 if d0 is not None else d1
-                if dz1 is not None:
-                    self.enc_bwd_first(enc0, dz1)
+                g1 = self.enc_bwd(enc1, g.get(ROW_TYPE), upto_bn1=True)
+                g0 = self.enc_bwd(enc0, gi if enc0.get("rows") is not None else dense(gi), upto_bn1=True)
+                self.enc_bwd_shared(enc1, g1, enc0, g0)
             for t, gt in g.items():
                 if t != ROW_TYPE and gt is not None:
                     self.acc(f"embeddings.{t}.weight", gt)
@@ -551,10 +549,9 @@ class _Run:
             return ops.linear_fwd(dy, self.W(wname), w_kn=True)          # dX = dY . W, W read in place
         return None
 
-    def enc_bwd(self, enc, g_x0, defer_first=False, dz1_into=None):
-        """defer_first: stop in front of the first linear and return dz1 (the two passes of a training step share that
-        layer: their dz1 are summed -- dz1_into: inside the BatchNorm-backward kernel -- and it is differentiated once,
-        enc_bwd_first)."""
+    def enc_bwd(self, enc, g_x0, upto_bn1=False):
+        """upto_bn1: stop in front of the first BatchNorm and return its upstream gradient (the two passes of a training
+        step share that BatchNorm and the linear in front of it: enc_bwd_shared differentiates them once for both)."""
         if g_x0 is None:
             return None
         pt = "patient_transform"
@@ -568,11 +565,31 @@ class _Run:
             g = self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
             dz2 = self.bn_bwd(g, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5", sharded=True)
         g = self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
-        dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True, add_into=dz1_into)
-        if defer_first:
-            return dz1
+        if upto_bn1:
+            return g
+        dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True)
         self.enc_bwd_first(enc, dz1)
         return None
+
+    def enc_bwd_shared(self, enc_a, g_a, enc_b, g_b):
+        """First BatchNorm + first linear of two passes that share them (same z1, same statistics, own dropout masks):
+        g_out = g_out(g_a; pro1_a) + g_out(g_b; pro1_b) -- one statistics pass, one apply pass, one weight / data gradient."""
+        pt = "patient_transform"
+        if g_a is None and g_b is None:
+            return
+        if g_a is None or g_b is None:
+            enc, g = (enc_a, g_a) if g_b is None else (enc_b, g_b)
+            dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True)
+        else:
+            y, fold = enc_a["z1"], enc_a["f1"]
+            sums = ops.bn_bwd_stats2(g_a, g_b, y, enc_a["pro1"], enc_b["pro1"], fold)
+            if self.comm is not None:
+                self.allreduce(sums)
+            dbg = torch.empty(2, y.shape[1], device=y.device)
+            dz1 = ops.bn_bwd_apply2(g_a, g_b, y, enc_a["pro1"], enc_b["pro1"], fold, sums, fold.count, dbg[0], dbg[1])
+            self.acc(f"{pt}.1.bias", dbg[0])
+            self.acc(f"{pt}.1.weight", dbg[1])
+        self.enc_bwd_first(enc_a, dz1)
 
     def enc_bwd_first(self, enc, dz1):
         pt = "patient_transform"

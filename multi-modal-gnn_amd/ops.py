@@ -396,6 +396,33 @@ def bn_bwd_stats(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold):
     return out
 
 
+def bn_bwd_stats2(g: torch.Tensor, g2: torch.Tensor, y: torch.Tensor, pro: Pro, pro2: Pro, fold: BNFold):
+    """bn_bwd_stats of two upstream gradients through the same BatchNorm + ReLU with their own dropout masks."""
+    lib = _lib.load()
+    M, N = y.shape
+    out = torch.empty(2, N, dtype=torch.float64, device=y.device)
+    nb = lib.mmg_col_reduce2_ws_bytes(M, N)
+    ws = workspace(nb, y.device)
+    _tok = _pb("bn_bwd_stats")
+    check(lib.mmg_bn_bwd_stats2(_p(g), _p(g2), _p(y), _pro(pro), _pro(pro2), _p(fold.mean), _p(fold.rstd),
+                                _p(out, torch.float64), M, N, _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_bn_bwd_stats2")
+    _pe(_tok, "bn_bwd_stats", 12 * M * N, 0)
+    return out
+
+
+def bn_bwd_apply2(g: torch.Tensor, g2: torch.Tensor, y: torch.Tensor, pro: Pro, pro2: Pro, fold: BNFold, sums, count,
+                  dbeta=None, dgamma=None):
+    lib = _lib.load()
+    M, N = y.shape
+    out = torch.empty_like(y)
+    _tok = _pb("bn_bwd_apply")
+    check(lib.mmg_bn_bwd_apply2(_p(g), _p(g2), _p(y), _pro(pro), _pro(pro2), _p(fold.mean), _p(fold.rstd),
+                                _p(sums, torch.float64), 1.0 / float(count), _p(dbeta), _p(dgamma), _p(out), M, N, _stream()),
+          "mmg_bn_bwd_apply2")
+    _pe(_tok, "bn_bwd_apply", 16 * M * N, 0)
+    return out
+
+
 def bn_bwd_stats_rows(g_rows: torch.Tensor, y: torch.Tensor, rows: torch.Tensor, pro: Pro, fold: BNFold):
     """bn_bwd_stats for an upstream gradient that is zero outside `rows` (g_rows = its rows, in list order)."""
     lib = _lib.load()

@@ -363,6 +363,26 @@ def test_row_subset_variants_match_the_dense_kernels(ops, dev, p):
     assert float(ops.bn_bwd_stats_rows(g_rows[:0], y, empty, pro, fold).abs().sum()) == 0.0
 
 
+def test_two_upstream_gradients_through_one_batchnorm(ops, dev):
+    """bn_bwd_stats2 / bn_bwd_apply2 == the sum of two single backward passes (same BN + ReLU, own dropout masks)."""
+    gen = torch.Generator().manual_seed(44)
+    M, N = 40000, 128
+    y = (torch.randn(M, N, generator=gen) * 1.5 + 0.2).to(dev)
+    ga, gb = torch.randn(M, N, generator=gen).to(dev), torch.randn(M, N, generator=gen).to(dev)
+    gamma, beta = (torch.rand(N, generator=gen) + 0.5).to(dev), (torch.randn(N, generator=gen) * 0.2).to(dev)
+    fold = ops.bn_finalize(ops.col_reduce2(y), M, gamma, beta, None, None, True)
+    pa = ops.Pro(fold.scale, fold.shift, True, 0.2, seed=9, site=0, row_offset=5)
+    pb = ops.Pro(fold.scale, fold.shift, True, 0.2, seed=9, site=2, row_offset=5)
+    sa, sb = ops.bn_bwd_stats(ga, y, pa, fold), ops.bn_bwd_stats(gb, y, pb, fold)
+    s2 = ops.bn_bwd_stats2(ga, gb, y, pa, pb, fold)
+    assert rel(s2, (sa + sb).cpu()) <= 1e-6        # (the two masked gradients are added in fp32 before the fp64 sums)
+    ref = ops.bn_bwd_apply(ga, y, pa, fold, sa, M) + ops.bn_bwd_apply(gb, y, pb, fold, sb, M)
+    dbg = torch.empty(2, N, device=dev)
+    dy = ops.bn_bwd_apply2(ga, gb, y, pa, pb, fold, s2, M, dbg[0], dbg[1])
+    assert rel(dy, ref.cpu()) <= 1e-5
+    assert torch.equal(dbg.double(), s2.float().double())
+
+
 @pytest.mark.parametrize("N", [64, 128, 256])
 def test_l2norm(ops, dev, N):
     gen = torch.Generator().manual_seed(N)
