@@ -152,6 +152,37 @@ def test_train_step_matches_oracle_with_injected_dropout(dev, p):
             assert rel_err(b.cpu(), obufs[k]) <= TOL, k
 
 
+@pytest.mark.parametrize("thr", [0, 10 ** 6])
+def test_degree_gate_extremes_in_training(dev, thr):
+    """No low-degree patient at all (the first encoder pass then has an EMPTY row list behind its last BatchNorm) and
+    only low-degree patients (the list is every row): the degree gate of model.py:312 at its two ends, with dropout."""
+    from mmgnn import ops
+    n, hidden, p = (500, 20, 25, 18), 128, 0.2
+    model, g, gd, gv, sd, ei, ea = make(dev, n, hidden, dropout=p)
+    model.degree_threshold = thr
+    tr, va, te = ot.edge_splits(ei.shape[1], 0.7, 0.15, 0.15, 42)
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    w = ot.lab_weights(li, y, gv.num_nodes["lab"])
+    sup = ot.supervision_mask(int(tr.sum()), 0.2, torch.Generator().manual_seed(7))
+    seed = 777
+    model._dropout_seed = seed
+    model.train()
+    pred = model.predict_lab_values(gd, pi.to(dev), li.to(dev))
+    loss = ((pred[sup.to(dev)] - y[sup].to(dev)).abs() * w[li[sup]].to(dev)).mean()
+    loss.backward()
+    masks = _oracle_masks(ops, dev, seed, p, gv, pi.numel(), hidden)
+    oloss, opred, ograds, obufs = ot.train_step_grads(sd, gv, pi, li, y, w, sup, p=p, masks=masks, degree_threshold=thr)
+    assert rel_err(pred.detach().cpu(), opred) <= TOL
+    gmax = max(float(v.abs().max()) for v in ograds.values())
+    for k, pm in model.named_parameters():
+        gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
+        ref = ograds[k]
+        assert float((gr - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6 * gmax, k
+    for k, b in model.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            assert rel_err(b.cpu(), obufs[k]) <= TOL, k
+
+
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_train_step_with_side_stream_overlap(dev, p, monkeypatch):
     """The vocab-side work of every layer on a side stream (on by default only above 16 k patients): same results."""
