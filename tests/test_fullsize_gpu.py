@@ -1,0 +1,172 @@
+"""Full-size checks (BASELINE.json config 3: the eICU shape x100 -- 183,400 patients, 6,148,400 has_lab edges): the CPU
+oracle cannot run at this size in test time, so parity is carried by size-independent properties of the path
+  * CSR construction: permutation, sortedness, stability, bincount -- bit-exact;
+  * aggregates: gather and scatter are each other's transpose (<G(T), X> == <T, S(X)>), scatter is linear, and both
+    match a torch index_add_ reference on the device (fp32, same inputs);
+  * dense layers: sampled rows against an fp64 reference;
+  * a training step through the whole path: finite, reproducible with a fixed dropout seed (up to the float atomics of
+    the pair heads), different with another seed; eval predictions do not depend on the order of the pairs.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SCALE = 100
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import mmgnn  # noqa: F401
+    from mmgnn import ops
+    from mmgnn.data import LAB_EDGE, build_plan
+    from mmgnn.synth import make_graph
+    dev = torch.device("cuda:0")
+    g = make_graph(SCALE, seed=0, device=dev)
+    plan = build_plan(g, dev)
+    return dict(dev=dev, g=g, plan=plan, ops=ops, LAB=LAB_EDGE)
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_csr_properties_at_full_size(env):
+    ops, g, dev = env["ops"], env["g"], env["dev"]
+    ei = g[env["LAB"]].edge_index
+    P, E = int(g["patient"].num_nodes), ei.shape[1]
+    assert P == 1834 * SCALE and E == 61484 * SCALE
+    rowptr, col, perm = ops.csr_build(ei, P, 0)
+    p64 = perm.long()
+    assert torch.equal(torch.sort(p64).values, torch.arange(E, device=dev))                  # a permutation
+    rows = ei[0][p64]
+    assert bool((rows[1:] >= rows[:-1]).all())                                               # sorted by patient
+    same = rows[1:] == rows[:-1]
+    assert bool((p64[1:][same] > p64[:-1][same]).all())                                      # stable inside a row
+    assert torch.equal(col.long(), ei[1][p64])
+    assert torch.equal(rowptr.long(), torch.cat([torch.zeros(1, dtype=torch.long, device=dev),
+                                                 torch.bincount(ei[0], minlength=P).cumsum(0)]))
+
+
+def _rels(env, D, with_tables):
+    """The three relations into / from the patient rows with their bit planes, as the model builds them."""
+    ops, plan, dev = env["ops"], env["plan"], env["dev"]
+    gen = torch.Generator(device=dev).manual_seed(5)
+    rin = plan.rels_into_patient()
+    tabs = [torch.randn(r.n_cols, D, generator=gen, device=dev) for r in rin]
+    return rin, tabs
+
+
+def test_gather_and_scatter_are_transposes_and_match_index_add(env):
+    ops, plan, dev = env["ops"], env["plan"], env["dev"]
+    P, D = plan.n_rows, 128
+    gen = torch.Generator(device=dev).manual_seed(6)
+    rin, tabs = _rels(env, D, True)
+    # gather: out[p] = sum_r (1/deg_r(p)) sum_{v in N_r(p)} T_r[v]
+    out = torch.zeros(P, D, device=dev)
+    ops.gather_rows([ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=t, simple=r.simple, mask_r=r.mask_r)
+                     for r, t in zip(rin, tabs)], P, D, out, accumulate=False)
+    ref = torch.zeros(P, D, device=dev)
+    for r, t in zip(rin, tabs):
+        rows = torch.repeat_interleave(torch.arange(P, device=dev), (r.rowptr[1:] - r.rowptr[:-1]).long())
+        ref.index_add_(0, rows, t[r.col.long()] * r.inv_row[rows][:, None])
+    assert rel(out, ref) <= 1e-5
+    # scatter with the same weights is the transpose: <G(T), X> == sum_r <T_r, S_r(X)>
+    X = torch.randn(P, D, generator=gen, device=dev)
+    outs = [torch.empty(r.n_cols, D, device=dev) for r in rin]
+    ops.scatter_rows([ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=o, simple=r.simple, mask_t=r.mask_t)
+                      for r, o in zip(rin, outs)], P, D, X)
+    lhs = float((out.double() * X.double()).sum())
+    rhs = float(sum((t.double() * o.double()).sum() for t, o in zip(tabs, outs)))
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0) + 1e-3
+    # linearity of the scatter
+    Y = torch.randn(P, D, generator=gen, device=dev)
+    outs2 = [torch.empty(r.n_cols, D, device=dev) for r in rin]
+    ops.scatter_rows([ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=o, simple=r.simple, mask_t=r.mask_t)
+                      for r, o in zip(rin, outs2)], P, D, Y)
+    outs3 = [torch.empty(r.n_cols, D, device=dev) for r in rin]
+    ops.scatter_rows([ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, out=o, simple=r.simple, mask_t=r.mask_t)
+                      for r, o in zip(rin, outs3)], P, D, 2.0 * X - 0.5 * Y)
+    for a, b, c in zip(outs, outs2, outs3):
+        assert rel(c, 2.0 * a.double() - 0.5 * b.double()) <= 1e-5
+
+
+def test_dense_layers_on_sampled_rows(env):
+    ops, dev = env["ops"], env["dev"]
+    M, N, K = env["plan"].n_rows, 128, 128
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(M, K, generator=gen, device=dev)
+    W = torch.randn(N, K, generator=gen, device=dev) / K ** 0.5
+    b = torch.randn(N, generator=gen, device=dev)
+    y, sums = ops.linear_fwd(x, W, b, with_stats=True)
+    idx = torch.randint(0, M, (4096,), generator=gen, device=dev)
+    ref = x[idx].double() @ W.double().t() + b.double()
+    assert rel(y[idx], ref) <= 2e-6
+    assert rel(sums[0], y.double().sum(0)) <= 1e-7 and rel(sums[1], (y.double() ** 2).sum(0)) <= 1e-7   # 16 rows in fp32, then fp64
+    dy = torch.randn(M, N, generator=gen, device=dev)
+    dW, db = ops.linear_wgrad(dy, x, with_bias=True)
+    assert rel(dW, dy.double().t() @ x.double()) <= 1e-5
+    assert rel(db, dy.double().sum(0)) <= 1e-6
+    dx = ops.linear_fwd(dy, W, w_kn=True)
+    assert rel(dx[idx], dy[idx].double() @ W.double()) <= 2e-6
+
+
+def _workload(env, dropout):
+    from mmgnn.model import build_model
+    g, dev, plan = env["g"], env["dev"], env["plan"]
+    cfg = {"model": {"architecture": "RGCN", "hidden_dim": 128, "num_layers": 2, "dropout": dropout,
+                     "use_batch_norm": True, "activation": "relu"}}
+    torch.manual_seed(42)
+    model = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
+    model._init_embeddings(g)
+    ei = g[env["LAB"]].edge_index
+    gen = torch.Generator(device=dev).manual_seed(42)
+    tr = torch.randperm(ei.shape[1], generator=gen, device=dev)[: int(0.7 * ei.shape[1])].sort().values
+    pi, li = ei[0][tr].contiguous(), ei[1][tr].contiguous()
+    y = g[env["LAB"]].edge_attr[tr].squeeze(-1).contiguous()
+    sup = (torch.rand(tr.numel(), generator=torch.Generator(device=dev).manual_seed(1234), device=dev) < 0.2).float()
+    return model, plan, pi, li, y, sup
+
+
+def test_training_step_is_finite_and_reproducible(env):
+    ops = env["ops"]
+    model, plan, pi, li, y, sup = _workload(env, 0.2)
+    w = torch.ones_like(y)
+
+    def step(seed):
+        model._dropout_seed = seed
+        model.train()
+        model.zero_grad(set_to_none=True)
+        pred = model.predict_lab_values(plan, pi, li)
+        loss = ops.weighted_pair_loss(pred, y, w, sup, 1.0 / float(sup.sum()), "mae")
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        return pred.detach().clone(), float(loss.detach()), grads
+
+    rm0 = model.patient_transform[1].running_mean.clone()
+    p1, l1, g1 = step(123)
+    assert torch.isfinite(p1).all() and l1 == l1 and len(g1) >= 60
+    assert all(torch.isfinite(v).all() for v in g1.values())
+    assert not torch.equal(model.patient_transform[1].running_mean, rm0)          # BatchNorm buffers advanced
+    p2, l2, g2 = step(123)                                # same dropout seed: the same step
+    assert rel(p2, p1) <= 1e-6 and abs(l2 - l1) <= 1e-6 * abs(l1)                 # (float atomics in the pair heads)
+    gmax = max(float(v.abs().max()) for v in g1.values())
+    for k in g1:      # (a bias in front of a BatchNorm has a zero gradient: only rounding noise there, hence the floor)
+        assert float((g1[k] - g2[k]).abs().max()) <= 1e-4 * float(g1[k].abs().max()) + 1e-6 * gmax, k
+    p3, l3, _ = step(124)                                 # another seed: other masks
+    assert rel(p3, p1) > 1e-3
+
+
+def test_eval_predictions_do_not_depend_on_pair_order(env):
+    model, plan, pi, li, y, sup = _workload(env, 0.0)
+    model.eval()
+    n = 500_000
+    with torch.no_grad():
+        a = model.predict_lab_values(plan, pi[:n].contiguous(), li[:n].contiguous())
+        perm = torch.randperm(n, generator=torch.Generator(device=env["dev"]).manual_seed(3), device=env["dev"])
+        b = model.predict_lab_values(plan, pi[:n][perm].contiguous(), li[:n][perm].contiguous())
+    assert torch.equal(b, a[perm])
