@@ -169,7 +169,7 @@ typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 template <int K, int WN, bool PRO, bool ACC>   // WN waves along N (32 columns each) over a 32-row tile: 64 * WN threads
-__global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_fwd_x6(
+__global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_linear_fwd_x6(
     const float* __restrict__ X, ProDev pr, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, int64_t M, int N, int flags, double* __restrict__ stat_partial) {
   if (PRO) pr.resolve();
@@ -334,10 +334,12 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_fwd_x6(
   }
 }
 
-inline int64_t fwd_x6_rows(int64_t M, int N, int BN) {      // grid.y of the bf16-split forward (= partial stat rows)
+inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y of the bf16-split forward (= partial stat rows)
   const int n_slices = N / BN;
   const int64_t n_tiles = (M + 31) / 32;
-  int64_t gy = 512 / n_slices;               // persistent workgroups, 52 KB of LDS each: two per CU
+  // persistent workgroups: two per CU (52 KB of LDS, <= 256 registers) up to K = 128; K = 256 keeps 192 registers of
+  // W pieces per wave and 101 KB of planes: one per CU
+  int64_t gy = (K <= 128 ? 512 : 256) / n_slices;
   if (gy < 1) gy = 1;
   if (gy > n_tiles) gy = n_tiles;
   return gy;
@@ -348,7 +350,7 @@ int launch_fwd_x6_v(const float* X, const ProDev& pr, const float* W, const floa
                     int flags, hipStream_t st, double* stat_partial) {
   constexpr int BN = 32 * WN;
   const int n_slices = N / BN;
-  const int64_t gy = fwd_x6_rows(M, N, BN);
+  const int64_t gy = fwd_x6_rows(M, N, BN, K);
   const size_t lds = (size_t)2 * 3 * 32 * (K + 8) * 2;
   (void)hipFuncSetAttribute((const void*)k_linear_fwd_x6<K, WN, PRO, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
@@ -1031,17 +1033,19 @@ extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, c
     if (K == 64) launch_small<64>(X, pr, W, bias, Y, M, N, accumulate, st);
     else if (K == 128) launch_small<128>(X, pr, W, bias, Y, M, N, accumulate, st);
     else launch_small<256>(X, pr, W, bias, Y, M, N, accumulate, st);
-  } else if (K <= 128 && !fp32_mfma()) {
+  } else if ((K <= 128 || N % 128 == 0) && !fp32_mfma()) {
     // exact-product 6-term bf16 split on the bf16 matrix cores (MMG_LINEAR_FP32=1: the fp32-MFMA kernels below)
     if (K == 64) {
       if (N % 128 == 0) launch_fwd_x6<64, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
       else launch_fwd_x6<64, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
-    } else {
+    } else if (K == 128) {
       if (N % 128 == 0) launch_fwd_x6<128, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
       else launch_fwd_x6<128, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+    } else {
+      launch_fwd_x6<256, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
     }
     if (col_sums) {     // partial[gy][2][N] -> col_sums[2][N]
-      const int rows = (int)fwd_x6_rows(M, N, N % 128 == 0 ? 128 : 64);
+      const int rows = (int)fwd_x6_rows(M, N, N % 128 == 0 ? 128 : 64, K);
       int rc2 = mmg_partial_sum(partial, col_sums, 2 * N, rows, stream);
       if (rc2) return rc2;
       stats_done = true;
