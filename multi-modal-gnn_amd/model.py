@@ -358,8 +358,13 @@ class _Run:
         # advanced twice.
         if self.p > 0:
             first = self.enc_first(2)            # shared by both passes (no dropout before the first BatchNorm)
-            enc0 = self.enc_fwd(0, 1, first, rows=self.pairs[4][5])      # feeds the tabular head only: low-degree rows
-            enc1 = self.enc_fwd(1, 1, first)
+            m0, m1 = self.enc_mid(0, first), self.enc_mid(1, first)
+            if self.comm is not None and self.T:     # sharded: the statistics of both passes in ONE all-reduce
+                both = torch.stack([m0[2], m1[2]])
+                self.allreduce(both)
+                m0[2], m1[2], m0[3], m1[3] = both[0], both[1], True, True
+            enc0 = self.enc_fwd(0, 1, first, rows=self.pairs[4][5], mid=m0)   # feeds the tabular head only: low-degree rows
+            enc1 = self.enc_fwd(1, 1, first, mid=m1)
         else:
             enc0 = enc1 = self.enc_fwd(0, 2)
         init = self.enc_dict(enc0)
@@ -409,9 +414,17 @@ class _Run:
                     tot = gp if gi is None else gp.index_add_(0, gi[0], gi[1])
                 self.enc_bwd(enc0, tot)
             else:
-                g1 = self.enc_bwd(enc1, g.get(ROW_TYPE), upto_bn1=True)
-                g0 = self.enc_bwd(enc0, gi if enc0.get("rows") is not None else dense(gi), upto_bn1=True)
-                self.enc_bwd_shared(enc1, g1, enc0, g0)
+                a1 = self.enc_bwd_a(enc1, g.get(ROW_TYPE))
+                a0 = self.enc_bwd_a(enc0, gi if enc0.get("rows") is not None else dense(gi))
+                if self.comm is not None:        # sharded: the BatchNorm statistics of both passes in ONE all-reduce
+                    live = [a for a in (a1, a0) if a is not None]
+                    if len(live) == 2:
+                        both = torch.stack([a1[1], a0[1]])
+                        self.allreduce(both)
+                        a1, a0 = (a1[0], both[0]), (a0[0], both[1])
+                    elif live:
+                        self.allreduce(live[0][1])
+                self.enc_bwd_shared(enc1, self.enc_bwd_b(enc1, a1), enc0, self.enc_bwd_b(enc0, a0))
             for t, gt in g.items():
                 if t != ROW_TYPE and gt is not None:
                     self.acc(f"embeddings.{t}.weight", gt)
@@ -428,15 +441,16 @@ class _Run:
         return out
 
     # ======================================================================== encode_nodes
-    def bn_fold(self, y, mod: nn.BatchNorm1d, n_updates=1, sharded=False, sums=None) -> ops.BNFold:
+    def bn_fold(self, y, mod: nn.BatchNorm1d, n_updates=1, sharded=False, sums=None, reduced=False) -> ops.BNFold:
         """Batch statistics (train) or running statistics (eval) folded to scale/shift.  sums: the column sums of
-        y and y^2 when the producing kernel already took them."""
+        y and y^2 when the producing kernel already took them (reduced: already summed over the shards)."""
         count = y.shape[0]
         if self.T:
             if sums is None:
                 sums = ops.col_reduce2(y)
             if sharded and self.comm is not None:
-                self.allreduce(sums)
+                if not reduced:
+                    self.allreduce(sums)
                 count = self.plan.n_rows_global
             if count <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size {list(y.shape)}")
@@ -460,17 +474,26 @@ class _Run:
         f1 = self.bn_fold(z1, pt[1], n_updates, sharded=True, sums=s1)
         return E, z1, f1
 
-    def enc_fwd(self, call, n_updates, first=None, rows=None):
+    def enc_mid(self, call, first):
+        """Second linear of pass `call` with the BatchNorm statistics of its output (not yet summed over the shards)."""
+        pt = self.m.patient_transform
+        E, z1, f1 = first
+        pro1 = Pro(f1.scale, f1.shift, True, self.p, self.seed, 2 * call, self.plan.row_offset, self.seed_dev)
+        z2, s2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1, with_stats=True) if self.T else \
+            (ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1), None)
+        return [pro1, z2, s2, False]
+
+    def enc_fwd(self, call, n_updates, first=None, rows=None, mid=None):
         """rows (int64 ids): everything after the last BatchNorm -- third linear, L2 norm -- is evaluated for these rows
         only and x0 / rn are compact [len(rows), .] (the first encode_nodes pass of a training step only feeds the
         tabular head, which only sees the low-degree patients; its BatchNorm statistics still need every row)."""
         pt = self.m.patient_transform
         off = self.plan.row_offset
-        E, z1, f1 = first if first is not None else self.enc_first(n_updates)
-        pro1 = Pro(f1.scale, f1.shift, True, self.p, self.seed, 2 * call, off, self.seed_dev)
-        z2, s2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1, with_stats=True) if self.T else \
-            (ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1), None)
-        f2 = self.bn_fold(z2, pt[5], n_updates, sharded=True, sums=s2)
+        if first is None:
+            first = self.enc_first(n_updates)
+        E, z1, f1 = first
+        pro1, z2, s2, reduced = mid if mid is not None else self.enc_mid(call, first)
+        f2 = self.bn_fold(z2, pt[5], n_updates, sharded=True, sums=s2, reduced=reduced)
         pro2 = Pro(f2.scale, f2.shift, True, self.p, self.seed, 2 * call + 1, off, self.seed_dev)
         if rows is not None:
             act = ops.affine_act_drop_rows(z2, pro2, rows)       # the dropout masks of the ORIGINAL rows
@@ -516,19 +539,6 @@ class _Run:
         self.acc(bn_prefix + ".weight", dbg[1])
         return dy
 
-    def bn_bwd_rows(self, g_rows, rows, y, pro: Pro, fold: ops.BNFold, bn_prefix: str):
-        """bn_bwd (patient axis, training statistics) for an upstream gradient that is zero outside `rows`: statistics
-        from the listed rows alone, a dense apply pass that never reads a gradient tensor, the listed rows patched."""
-        sums = ops.bn_bwd_stats_rows(g_rows, y, rows, pro, fold)
-        if self.comm is not None:
-            self.allreduce(sums)
-        dbg = torch.empty(2, y.shape[1], device=y.device)
-        dy = ops.bn_bwd_apply(None, y, pro, fold, sums, fold.count, dbg[0], dbg[1])
-        ops.bn_bwd_apply_rows(g_rows, y, rows, pro, dy)
-        self.acc(bn_prefix + ".bias", dbg[0])
-        self.acc(bn_prefix + ".weight", dbg[1])
-        return dy
-
     def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False, dx_into=None):
         """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one."""
         gw = self.grads.get(wname)       # a second contribution (the encoder runs twice) accumulates inside the kernel
@@ -549,24 +559,54 @@ class _Run:
             return ops.linear_fwd(dy, self.W(wname), w_kn=True)          # dX = dY . W, W read in place
         return None
 
-    def enc_bwd(self, enc, g_x0, upto_bn1=False):
-        """upto_bn1: stop in front of the first BatchNorm and return its upstream gradient (the two passes of a training
-        step share that BatchNorm and the linear in front of it: enc_bwd_shared differentiates them once for both)."""
+    def enc_bwd_a(self, enc, g_x0):
+        """Backward of one encoder pass down to the statistics of its last BatchNorm (local sums, not yet all-reduced):
+        -> (upstream gradient of that BatchNorm [dense, or the listed rows], fp64 sums) or None."""
         if g_x0 is None:
             return None
         pt = "patient_transform"
         if enc.get("rows") is not None:      # compact tail: g_x0 = (row ids, gradient rows)
             rows, g_rows = g_x0
             dz3 = ops.l2norm_bwd(g_rows.contiguous(), enc["x0"], enc["rn"])
-            g_act = self.lin_bwd(dz3, enc["act"], None, f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
-            dz2 = self.bn_bwd_rows(g_act, rows, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5")
+            g = self.lin_bwd(dz3, enc["act"], None, f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
+            sums = ops.bn_bwd_stats_rows(g, enc["z2"], rows, enc["pro2"], enc["f2"])
         else:
             dz3 = ops.l2norm_bwd(g_x0.contiguous(), enc["x0"], enc["rn"])
             g = self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
-            dz2 = self.bn_bwd(g, enc["z2"], enc["pro2"], enc["f2"], f"{pt}.5", sharded=True)
-        g = self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
+            sums = ops.bn_bwd_stats(g, enc["z2"], enc["pro2"], enc["f2"])
+        return g, sums
+
+    def enc_bwd_b(self, enc, state):
+        """...and from the (all-reduced) statistics on to the upstream gradient of the first BatchNorm."""
+        if state is None:
+            return None
+        pt = "patient_transform"
+        g, sums = state
+        y, pro, fold = enc["z2"], enc["pro2"], enc["f2"]
+        if enc.get("rows") is not None:
+            # an upstream gradient that is zero outside the listed rows (training statistics): the dense apply pass never
+            # reads a gradient tensor, the listed rows are patched afterwards
+            dbg = torch.empty(2, y.shape[1], device=y.device)   # d beta | d gamma, written by the apply kernel
+            dz2 = ops.bn_bwd_apply(None, y, pro, fold, sums, fold.count, dbg[0], dbg[1])
+            ops.bn_bwd_apply_rows(g, y, enc["rows"], pro, dz2)
+            self.acc(f"{pt}.5.bias", dbg[0])
+            self.acc(f"{pt}.5.weight", dbg[1])
+        else:
+            dz2 = self.bn_bwd(g, y, pro, fold, f"{pt}.5", sharded=True, sums=sums)
+        return self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
+
+    def enc_bwd(self, enc, g_x0, upto_bn1=False):
+        """upto_bn1: stop in front of the first BatchNorm and return its upstream gradient (the two passes of a training
+        step share that BatchNorm and the linear in front of it: enc_bwd_shared differentiates them once for both)."""
+        state = self.enc_bwd_a(enc, g_x0)
+        if state is None:
+            return None
+        if self.comm is not None:
+            self.allreduce(state[1])
+        g = self.enc_bwd_b(enc, state)
         if upto_bn1:
             return g
+        pt = "patient_transform"
         dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True)
         self.enc_bwd_first(enc, dz1)
         return None
@@ -909,34 +949,47 @@ class _Run:
         # exactly nothing: visit only the others, split by head
         dsorted = torch.empty_like(dps)          # dpred in sorted pair order: the one random pass, made by the selection
         bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps, io_perm=perm, dpred_sorted=dsorted)
-        for which, src, want_low in (("edge_predictor", rec["fin"], False), ("tabular_mlp", rec["init"], True)):
-            head, w1a, w1b, xP = rec[which]
-            small = [head.B, head.W2, head.b2, head.W3, head.b3]          # one zero-fill for the five small gradients
-            flat = torch.zeros(sum(t.numel() for t in small), device=self.dev)
-            views, o = [], 0
-            for t in small:
-                views.append(flat[o:o + t.numel()].view(t.shape))
+        order = (("edge_predictor", rec["fin"], False), ("tabular_mlp", rec["init"], True))
+        # one zero-fill for the small gradients of BOTH heads; the two lab-side tables dB sit first and adjacent, so that
+        # a sharded run sums them over the ranks with ONE all-reduce
+        smalls = {w: [rec[w][0].B, rec[w][0].W2, rec[w][0].b2, rec[w][0].W3, rec[w][0].b3] for w, _, _ in order}
+        n_b = sum(smalls[w][0].numel() for w, _, _ in order)
+        flat = torch.zeros(sum(t.numel() for w, _, _ in order for t in smalls[w]), device=self.dev)
+        views, ob, o = {}, 0, n_b
+        for w, _, _ in order:
+            tB = smalls[w][0]
+            v = [flat[ob:ob + tB.numel()].view(tB.shape)]
+            ob += tB.numel()
+            for t in smalls[w][1:]:
+                v.append(flat[o:o + t.numel()].view(t.shape))
                 o += t.numel()
-            g = ops.Head(torch.zeros_like(head.A), *views)
+            views[w] = v
+        gs = {}
+        for which, src, want_low in order:
+            head, w1a, w1b, xP = rec[which]
+            g = ops.Head(torch.zeros_like(head.A), *views[which])
             sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
             ops.pair_head_bwd(head, g, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr,
                               want_low, n_lab, self.p, self.seed, ids, dsorted,
                               self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb)
-            self.allreduce(g.B)                  # lab-side partials from sharded pairs
+            gs[which] = g
             self.acc(f"{which}.mlp.3.weight", g.W2, partial=True)
             self.acc(f"{which}.mlp.3.bias", g.b2, partial=True)
             self.acc(f"{which}.mlp.6.weight", g.W3.reshape(1, -1), partial=True)
             self.acc(f"{which}.mlp.6.bias", g.b3, partial=True)
-            xlab = src["lab"]
+            # first-layer weight / bias gradients from this shard's pairs only (the LOCAL dA and dB): per-shard partial
+            # sums like every other parameter gradient, summed by the one bucket at the end of the backward
             if xP.shape[0]:
                 dW1a = ops.linear_wgrad(g.A, xP)
             else:
                 dW1a = torch.zeros(w1a.shape, device=self.dev)
-            dW1b, db1 = ops.linear_wgrad(g.B, xlab, with_bias=True)
-            if self.comm is not None:
-                self.allreduce(dW1a)             # so that the concatenated weight grad is uniformly "full"
-            self.acc(f"{which}.mlp.0.weight", torch.cat([dW1a, dW1b], dim=1))
-            self.acc(f"{which}.mlp.0.bias", db1)
+            dW1b, db1 = ops.linear_wgrad(g.B, src["lab"], with_bias=True)
+            self.acc(f"{which}.mlp.0.weight", torch.cat([dW1a, dW1b], dim=1), partial=True)
+            self.acc(f"{which}.mlp.0.bias", db1, partial=True)
+        self.allreduce(flat[:n_b])               # lab-side partials dB of both heads from the sharded pairs
+        for which, src, want_low in order:
+            head, w1a, w1b, xP = rec[which]
+            g = gs[which]
             glab = ops.linear_fwd(g.B, w1b, w_kn=True)
             if want_low:                         # gradient rows of the low-degree patients only: (row ids, rows)
                 gP = (low_rows, ops.linear_fwd(g.A, w1a, w_kn=True)) if xP.shape[0] else None
