@@ -241,6 +241,7 @@ def main():
     prof = ops.OpProfiler(only=[dominant])
     if gstep is None:
         ops.set_profiler(prof)           # eager: the dominant op carries HIP events inside the timed region
+        ops.probe_arm(1 << 16)           # ... and its kernel launches their own start / stop events
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -253,12 +254,18 @@ def main():
     ops.set_profiler(None)
     loss_value = float(loss.detach())
     if gstep is not None:
-        # graph replays cannot carry per-kernel events: time the SAME kernels in K eager steps right after
+        # graph replays cannot carry per-kernel events: time the SAME kernels in K eager steps right after.  Each step is
+        # queued behind a ~10 ms spin on the device, so that the host (≈25 us of Python per launch) runs ahead and the
+        # kernels execute back to back: an event pair then brackets the kernel, not the host's gap before its launch.
         w["model"]._seed_dev = None
         ops.set_profiler(prof)
+        ops.probe_arm(1 << 16)
         for _ in range(args.steps):
+            torch.cuda._sleep(20_000_000)
             train_step(w)
+        torch.cuda.synchronize()
         ops.set_profiler(None)
+    probed = ops.probe_read()            # (ms, M, N, K, flags) per launch of the bf16-split dense forward
     dom = prof.summary()[dominant]
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     edges = torch.tensor([float(w["E"])], device=dev, dtype=torch.float64)
@@ -274,9 +281,27 @@ def main():
         # linear_fwd also serves the tiny vocab-side tables with a different kernel: those do not dilute the figure)
         shape = max(dom["shapes"].values(), key=lambda d: d["ms"])
         launches = shape["calls"]
-        avg_ms = shape["ms"] / launches
+        avg_ms = bracket_ms = shape["ms"] / launches
         bytes_per_launch = shape["bytes"]
         flops_per_launch = shape["flops"]
+        timing = ("HIP events on the launch stream, eager re-run of the same kernels right after the graph-replay timed "
+                  "region" if gstep is not None else "HIP events on the launch stream inside the timed region")
+        if dominant == "linear_fwd" and probed:
+            # the same launches timed by the event pair that hipExtLaunchKernelGGL attaches to the kernel itself (its
+            # begin / end timestamps, what rocprofv3 reports); the bracketing event pair above also contains the two
+            # extra queue entries and the dispatch latency of the kernel
+            groups = {}
+            for ms_, M_, N_, K_, fl_ in probed:
+                b_ = 4 * (M_ * K_ + N_ * K_ + M_ * N_ * (2 if fl_ & 1 else 1))
+                g_ = groups.setdefault((b_, 2 * M_ * N_ * K_), [0, 0.0])
+                g_[0] += 1
+                g_[1] += ms_
+            key = (bytes_per_launch, flops_per_launch)
+            if key in groups:
+                launches, avg_ms = groups[key][0], groups[key][1] / groups[key][0]
+                timing = "HIP start/stop events attached to each kernel launch (hipExtLaunchKernelGGL) on its stream, " + \
+                         ("eager re-run of the same kernels right after the graph-replay timed region"
+                          if gstep is not None else "inside the timed region")
         mfma_peak = MFMA_PEAK_BY_OP.get(dominant, MFMA_F32_PEAK_TF)
         hbm_frac = (bytes_per_launch / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS
         mfma_frac = (flops_per_launch / (avg_ms * 1e-3) / 1e12) / mfma_peak
@@ -295,10 +320,8 @@ def main():
         except Exception:
             roof["traffic"] = None
         roof.update({"kernel": dominant, "op_ms_per_step": dom["ms"] / max(args.steps, 1),
-                     "avg_launch_ms": avg_ms, "launches_timed": launches,
-                     "timing": ("HIP events on the launch stream, eager re-run of the same kernels right after the "
-                                "graph-replay timed region" if gstep is not None else
-                                "HIP events on the launch stream inside the timed region"),
+                     "avg_launch_ms": avg_ms, "launches_timed": launches, "timing": timing,
+                     "avg_launch_ms_bracketing_events": bracket_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch})
         P_loc = int(w["plan"].n_rows)
         out = {

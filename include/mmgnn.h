@@ -206,6 +206,13 @@ int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const int64_t* ro
 int mmg_bn_bwd_apply_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
                           const mmg_prologue_t* pro, float* dY, int N, void* stream);
 
+/* Measurement hook (bench.py): after mmg_probe_arm(n) the next n launches of the bf16-split dense forward carry a HIP
+ * start / stop event pair on the kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps on its
+ * stream); mmg_probe_read waits for them and returns how many (ms, M, N, K, flags: 1 = accumulate, 4 = prologue) entries
+ * it wrote (<= cap), disarming the hook.  Not thread-safe; never armed by the product path. */
+int mmg_probe_arm(int n_launches);
+int mmg_probe_read(float* ms, int64_t* M, int* N, int* K, int* flags, int cap);
+
 /* Row L2 normalisation, F.normalize(p=2, dim=1, eps): out = z / max(||z||, eps); rnorm = 1/max(..) */
 int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, float eps, void* stream);
 /* dz = rnorm * (g - out * <out, g>)   (rows whose norm hit eps: dz = g * rnorm)     */

@@ -10,7 +10,9 @@
 //              register tile (operands are read column-wise: consecutive lanes, consecutive floats),
 //              writes one partial slab; a second kernel sums the slabs in fixed order.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace {
 
@@ -345,6 +347,13 @@ inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y 
   return gy;
 }
 
+// Measurement hook (bench.py): while armed, every launch of the bf16-split forward is issued through
+// hipExtLaunchKernelGGL with a start / stop event pair, i.e. the events take the kernel's own begin / end timestamps
+// (what rocprofv3 reports) instead of bracketing it with two more queue entries.
+struct ProbeEntry { hipEvent_t e0, e1; int64_t M; int N, K, flags; };
+static std::vector<ProbeEntry> g_probe;
+static int g_probe_left = 0;
+
 template <int K, int WN, bool PRO, bool ACC>
 int launch_fwd_x6_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                     int flags, hipStream_t st, double* stat_partial) {
@@ -354,6 +363,16 @@ int launch_fwd_x6_v(const float* X, const ProDev& pr, const float* W, const floa
   const size_t lds = (size_t)2 * 3 * 32 * (K + 8) * 2;
   (void)hipFuncSetAttribute((const void*)k_linear_fwd_x6<K, WN, PRO, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds);
+  if (g_probe_left > 0) {
+    ProbeEntry e{nullptr, nullptr, M, N, K, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0)};
+    if (hipEventCreate(&e.e0) == hipSuccess && hipEventCreate(&e.e1) == hipSuccess) {
+      hipExtLaunchKernelGGL((k_linear_fwd_x6<K, WN, PRO, ACC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds,
+                            st, e.e0, e.e1, 0, X, pr, W, bias, Y, M, N, flags, stat_partial);
+      g_probe.push_back(e);
+      --g_probe_left;
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((k_linear_fwd_x6<K, WN, PRO, ACC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds, st, X,
                      pr, W, bias, Y, M, N, flags, stat_partial);
   return 0;
@@ -993,6 +1012,30 @@ int launch_small(const float* X, const ProDev& pr, const float* W, const float* 
 extern "C" int mmg_col_reduce2(const float* A, const float* B, double* out, int64_t M, int N, void* ws, size_t ws_bytes,
                                void* stream);
 extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream);
+
+extern "C" int mmg_probe_arm(int n_launches) {
+  for (auto& e : g_probe) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+  g_probe.clear();
+  g_probe_left = n_launches > 0 ? n_launches : 0;
+  return MMG_OK;
+}
+
+extern "C" int mmg_probe_read(float* ms, int64_t* M, int* N, int* K, int* flags, int cap) {
+  g_probe_left = 0;
+  int n = 0;
+  for (auto& e : g_probe) {
+    if (n < cap) {
+      float t = 0.f;
+      if (hipEventSynchronize(e.e1) == hipSuccess && hipEventElapsedTime(&t, e.e0, e.e1) == hipSuccess) {
+        ms[n] = t; M[n] = e.M; N[n] = e.N; K[n] = e.K; flags[n] = e.flags;
+        ++n;
+      }
+    }
+    (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1);
+  }
+  g_probe.clear();
+  return n;
+}
 
 extern "C" size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N) {
   if (M < 0 || N <= 0) return 0;

@@ -87,6 +87,20 @@ def _pe(tok, name, nbytes=0, flops=0):
     _PROF.rows.append((name, tok, e, int(nbytes), int(flops)))
 
 
+def probe_arm(n: int):
+    """Measurement hook: the next n launches of the bf16-split dense forward carry their own HIP event pair."""
+    check(_lib.load().mmg_probe_arm(int(n)), "mmg_probe_arm")
+
+
+def probe_read(cap: int = 65536):
+    """-> list of (ms, M, N, K, flags) of the probed launches (flags: 1 = accumulate, 4 = prologue)."""
+    import numpy as np
+    ms = np.zeros(cap, np.float32); M = np.zeros(cap, np.int64)
+    N = np.zeros(cap, np.int32); K = np.zeros(cap, np.int32); fl = np.zeros(cap, np.int32)
+    n = _lib.load().mmg_probe_read(ms.ctypes.data, M.ctypes.data, N.ctypes.data, K.ctypes.data, fl.ctypes.data, cap)
+    return [(float(ms[i]), int(M[i]), int(N[i]), int(K[i]), int(fl[i])) for i in range(n)]
+
+
 _WS = {}
 
 
