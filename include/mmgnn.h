@@ -165,8 +165,9 @@ int mmg_bn_finalize(const double* sums, int64_t count, const float* gamma, const
 int mmg_affine_act_drop(const float* Y, const mmg_prologue_t* pro, float* out, int64_t M, int N,
                         void* stream);
 /* The same for a subset of rows:  out[s, :] = dropout(relu(y[rows[s], :]*scale + shift)),  s < n_sel, the dropout
- * mask being the one of row rows[s] of the full tensor.  (The tabular head only sees the low-degree patients of the
- * first encode_nodes pass: everything after its last BatchNorm runs on those rows alone.) */
+ * mask being the one of row rows[s] of the full tensor.  (src/model.py:294 runs encode_nodes a first time only to feed
+ * tabular_mlp, which model.py:312-322 applies to the low-degree patients: everything after the last BatchNorm of that
+ * pass -- model.py:99-103 -- runs on those rows alone.) */
 int mmg_affine_act_drop_rows(const float* Y, const mmg_prologue_t* pro, const int64_t* rows, int64_t n_sel,
                              float* out, int N, void* stream);
 
@@ -186,7 +187,8 @@ int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, 
                      float* dY, int64_t M, int N, int accumulate, void* stream);
 
 /* Two upstream gradients through the SAME BatchNorm + ReLU, each with its own dropout mask (pro2: only its dropout fields
- * are used) -- the two encode_nodes passes of a training step share their first layer:
+ * are used) -- the two encode_nodes passes of a training step (src/model.py:294 and :301 -> :251) see the same
+ * Linear + BatchNorm1d in front of their first Dropout (model.py:93-96), i.e. they share that layer:
  * g_out = g_out(G; pro) + g_out(G2; pro2), one statistics pass and one apply pass instead of two of each. */
 int mmg_bn_bwd_stats2(const float* G, const float* G2, const float* Y, const mmg_prologue_t* pro,
                       const mmg_prologue_t* pro2, const float* mean, const float* rstd, double* sums, int64_t M, int N,
