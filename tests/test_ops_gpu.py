@@ -519,6 +519,36 @@ def test_weighted_pair_loss(ops, dev, loss_type):
     assert abs(float(l2) - float(r2)) <= 1e-6 * abs(float(r2))
 
 
+def test_c_abi_error_behaviour(ops, dev):
+    """Bad arguments come back as an error code + message (MmgError), never as a crash or a silent fallback."""
+    import ctypes as C
+    from mmgnn import _lib
+    lib = _lib.load()
+    x = torch.zeros(8, 96, device=dev)
+    with pytest.raises(_lib.MmgError, match="K=96"):                       # unsupported inner dimension
+        ops.linear_fwd(x, torch.zeros(64, 96, device=dev))
+    with pytest.raises(_lib.MmgError, match="multiple of 64"):             # unsupported output width
+        ops.linear_fwd(torch.zeros(8, 64, device=dev), torch.zeros(48, 64, device=dev))
+    with pytest.raises(ValueError):                                         # shape mismatch caught by the wrapper
+        ops.linear_fwd(torch.zeros(8, 64, device=dev), torch.zeros(64, 128, device=dev))
+    with pytest.raises(ValueError, match="contiguous"):
+        ops.linear_fwd(torch.zeros(64, 8, device=dev).t(), torch.zeros(64, 64, device=dev))
+    with pytest.raises(TypeError):
+        ops.linear_fwd(torch.zeros(8, 64, device=dev, dtype=torch.float64), torch.zeros(64, 64, device=dev))
+    # a workspace that is too small is refused with MMG_E_WS, not overrun
+    dy, xx, dW = torch.zeros(4096, 128, device=dev), torch.zeros(4096, 128, device=dev), torch.zeros(128, 128, device=dev)
+    ws = torch.zeros(256, dtype=torch.uint8, device=dev)
+    rc = lib.mmg_linear_wgrad(C.c_void_p(dy.data_ptr()), C.c_void_p(xx.data_ptr()), None, C.c_void_p(dW.data_ptr()), None,
+                              4096, 128, 128, 0, C.c_void_p(ws.data_ptr()), ws.numel(), None)
+    assert rc != 0 and b"workspace" in lib.mmg_last_error()
+    # null buffers
+    rc = lib.mmg_linear_fwd(None, None, C.c_void_p(dW.data_ptr()), None, C.c_void_p(dy.data_ptr()), 16, 128, 128, 0, None)
+    assert rc != 0 and b"null" in lib.mmg_last_error()
+    # empty problems are fine
+    assert ops.linear_fwd(torch.zeros(0, 64, device=dev), torch.zeros(64, 64, device=dev)).shape == (0, 64)
+    torch.cuda.synchronize()
+
+
 def test_ops_reject_cpu_tensors(ops):
     with pytest.raises(Exception):
         ops.linear_fwd(torch.zeros(4, 64), torch.zeros(64, 64))
