@@ -10,7 +10,9 @@ One process per GPU (N>1: launched by torch.distributed.run, RCCL).  Workload at
                   N=1, scale=100 is BASELINE.json configs[2].
   --strong      : ONE global x<scale> graph, patient-sharded over the N GPUs.
 Prints ONE JSON line (rank 0) with the whole-job rate, the roofline of the dominant kernel (HIP events
-on the launch stream) and a CPU baseline (the oracle restatement, timed on this host's cores, N=1 only).
+on the launch stream: the start / stop events hipExtLaunchKernelGGL attaches to each launch of that
+kernel, read back through mmg_probe_*; an eager re-run of the same kernels when the timed region was a
+hipGraph replay) and a CPU baseline (the oracle restatement, timed on this host's cores, N=1 only).
 """
 import argparse
 import json
