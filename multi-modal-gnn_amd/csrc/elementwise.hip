@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_affine_act_drop(const float* __restrict
   if (pr.scale) { sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c); }
   for (; i < n4; i += stride) {
     const int64_t r = i / (N / 4);
-    f32x4 v = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
+    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y + (size_t)i * 4));   // (next read: the backward)
     mmg_pro_apply4(pr, v, sc, sh, r, c, N);
     *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
   }
@@ -310,8 +310,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
   }
   for (; i < n4; i += stride) {
     const int64_t r = i / (N / 4);
-    const f32x4 g4 = G ? *reinterpret_cast<const f32x4*>(G + (size_t)i * 4) : zero;     // no G: an all-zero upstream
-    const f32x4 y4 = *reinterpret_cast<const f32x4*>(Y + (size_t)i * 4);
+    // (G and Y are read for the last time here: non-temporal loads leave the cache to dY, which the next kernels read)
+    const f32x4 g4 = G ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + (size_t)i * 4)) : zero;   // no G: zero upstream
+    const f32x4 y4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Y + (size_t)i * 4));
     f32x4 prev = zero;
     if (accumulate) prev = *reinterpret_cast<const f32x4*>(dY + (size_t)i * 4);
     f32x4 o, gm = g4, gm2 = zero;
