@@ -42,6 +42,8 @@ const char* mmg_last_error(void);
  * src/graph_build.py:476-586).  Stable sort of edge ids by edge_index[sort_row]:
  *   rowptr[n_rows+1], col[E] = edge_index[1-sort_row][perm], perm[E] = original edge id.
  * Bit-exact with torch.sort(stable=True) + bincount + cumsum.
+ * A key outside [0, n_rows) is never used as an address: it sorts behind the last row and is not counted, so
+ * rowptr[n_rows] < n_edges tells the caller that the input was invalid (graph_build.py:618-633 validates up front).
  * ------------------------------------------------------------------------------------- */
 size_t mmg_csr_build_ws_bytes(int64_t n_edges, int64_t n_rows);
 int mmg_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_rows, int sort_row,
@@ -107,7 +109,8 @@ int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
                      const float* x, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * Dense layers on fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replace torch.nn.Linear /
+ * Dense layers: fp32 products as an exact six-term bf16 split on the bf16 matrix cores
+ * (v_mfma_f32_32x32x16_bf16, fp32 accumulation; 2e-6 of an fp64 reference).  Replace torch.nn.Linear /
  * BatchNorm1d / ReLU / Dropout / F.normalize of src/model.py:93-105,229-232,258-269 and the
  * lin_l / lin_r of SAGEConv.
  *
@@ -208,12 +211,27 @@ int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const int64_t* ro
 int mmg_bn_bwd_apply_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
                           const mmg_prologue_t* pro, float* dY, int N, void* stream);
 
-/* Measurement hook (bench.py): after mmg_probe_arm(n) the next n launches of the bf16-split dense forward carry a HIP
- * start / stop event pair on the kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps on its
- * stream); mmg_probe_read waits for them and returns how many (ms, M, N, K, flags: 1 = accumulate, 4 = prologue) entries
- * it wrote (<= cap), disarming the hook.  Not thread-safe; never armed by the product path. */
+/* Measurement hook (bench.py).  After mmg_probe_arm(n) the next n launches of the big kernels made BY THE CALLING THREAD
+ * carry a HIP start / stop event pair on the kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end
+ * timestamps on its stream -- what rocprofv3 reports -- not a pair of extra queue entries around it).  mmg_probe_read
+ * waits for them, disarms the hook and returns how many entries it wrote (<= cap):
+ *   ms = kernel duration, tag = MMG_PROBE_* family, (M, N, K) = the launch's shape: rows / output width / inner width for
+ *   the dense kernels; patient rows / D / total vocab rows of the fused relations for the aggregates; pairs / 0 / 0 for
+ *   the heads;  flags: 1 = accumulate, 4 = prologue, 8 = rowscale.
+ * State is per thread (like mmg_last_error); the product path never arms it. */
+#define MMG_PROBE_LINEAR_FWD 1
+#define MMG_PROBE_LINEAR_WGRAD 2
+#define MMG_PROBE_LINEAR_WGRAD_REDUCE 3
+#define MMG_PROBE_GATHER 4
+#define MMG_PROBE_SCATTER 5
+#define MMG_PROBE_SCATTER_REDUCE 6
+#define MMG_PROBE_PAIR_FWD 7
+#define MMG_PROBE_PAIR_BWD 8
+#define MMG_PROBE_BN_BWD_STATS 9
+#define MMG_PROBE_BN_BWD_APPLY 10
+#define MMG_PROBE_ELEMENTWISE 11
 int mmg_probe_arm(int n_launches);
-int mmg_probe_read(float* ms, int64_t* M, int* N, int* K, int* flags, int cap);
+int mmg_probe_read(float* ms, int* tag, int64_t* M, int* N, int* K, int* flags, int cap);
 
 /* Row L2 normalisation, F.normalize(p=2, dim=1, eps): out = z / max(||z||, eps); rnorm = 1/max(..) */
 int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, float eps, void* stream);
@@ -225,10 +243,14 @@ int mmg_l2norm_bwd(const float* G, const float* out, const float* rnorm, float* 
  * (src/train.py:366-386 of the reference: mean(|p - y| * w[lab]) over the supervision subset):
  *   loss = inv_den * sum_k sup[k] * w[k] * (|p_k - y_k|  or  (p_k - y_k)^2)        (fp64 accumulation)
  *   dpred[k] = inv_den * sup[k] * w[k] * (sign(p_k - y_k)  or  2 (p_k - y_k))
- * sup / w may be NULL (= 1).  loss_type 0 = mae, 1 = mse.  `loss` is ONE double on the device. */
+ * sup / w may be NULL (= 1).  loss_type 0 = mae, 1 = mse.  `loss` is ONE double on the device.
+ * inv_den_ptr (nullable, DEVICE): when non-NULL the normaliser is read from it at run time instead of `inv_den` -- the
+ * reference divides by the size of the per-epoch supervision subset (.mean() over pred[mask], train.py:366-386), which
+ * changes every epoch while a captured hipGraph keeps its launch arguments. */
 size_t mmg_pair_loss_ws_bytes(int64_t n);
 int mmg_pair_loss(const float* pred, const float* y, const float* w, const float* sup, int64_t n, double inv_den,
-                  int loss_type, float* dpred, double* loss, void* ws, size_t ws_bytes, void* stream);
+                  const double* inv_den_ptr, int loss_type, float* dpred, double* loss, void* ws, size_t ws_bytes,
+                  void* stream);
 
 /* keep-mask of the dropout RNG, for injected-mask parity tests: mask[i] in {0,1}     */
 int mmg_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_t site, int64_t first_elem, int64_t n_elems,

@@ -71,7 +71,7 @@ SIGNATURES = {
     "mmg_affine_act_drop": (C.c_int, [_vp, _P(PrologueT), _vp, _i64, _i32, _vp]),
     "mmg_affine_act_drop_rows": (C.c_int, [_vp, _P(PrologueT), _vp, _i64, _vp, _i32, _vp]),
     "mmg_probe_arm": (C.c_int, [_i32]),
-    "mmg_probe_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32]),
+    "mmg_probe_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "mmg_bn_bwd_stats2": (C.c_int, [_vp, _vp, _vp, _P(PrologueT), _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _vp, C.c_size_t, _vp]),
     "mmg_bn_bwd_apply2": (C.c_int, [_vp, _vp, _vp, _P(PrologueT), _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _i64,
                                     _i32, _vp]),
@@ -83,7 +83,7 @@ SIGNATURES = {
     "mmg_l2norm_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmg_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmg_pair_loss_ws_bytes": (_sz, [_i64]),
-    "mmg_pair_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_double, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mmg_pair_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_double, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "mmg_dropout_mask": (C.c_int, [_u64, _vp, _u32, _i64, _i64, _f32, _vp, _vp]),
     "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libmmgnn (gfx950 only; wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -25,6 +26,39 @@ void mmg_set_error(const char* fmt, ...);
       mmg_set_error("%s: %s", what, hipGetErrorString(e__));                      \
       return MMG_E_LAUNCH;                                                        \
     }                                                                             \
+  } while (0)
+
+// every HIP runtime call that returns an error code goes through this
+#define MMG_CHECK_HIP(expr, what)                                                 \
+  do {                                                                            \
+    hipError_t e__ = (expr);                                                      \
+    if (e__ != hipSuccess) {                                                      \
+      mmg_set_error("%s: %s", what, hipGetErrorString(e__));                      \
+      return MMG_E_LAUNCH;                                                        \
+    }                                                                             \
+  } while (0)
+
+// Dynamic-LDS limit of a kernel, raised ONCE per process (a function-local static: thread-safe, immutable afterwards).
+template <auto Kernel, int Bytes>
+struct MmgMaxLds {
+  static hipError_t set() {
+    static const hipError_t rc =
+        hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Bytes);
+    return rc;
+  }
+};
+
+// Measurement hook (mmg_probe_arm / mmg_probe_read, include/mmgnn.h; state is thread-local, like mmg_last_error):
+// while the calling thread has armed it, a launch made through MMG_LAUNCH carries a HIP start / stop event pair on the
+// kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps on its stream).
+bool mmg_probe_take(int tag, int64_t M, int N, int K, int flags, hipEvent_t* e0, hipEvent_t* e1);
+#define MMG_LAUNCH(tag, pM, pN, pK, pflags, kernel, grid, block, lds, st, ...)                         \
+  do {                                                                                                \
+    hipEvent_t e0__, e1__;                                                                            \
+    if (mmg_probe_take(tag, pM, pN, pK, pflags, &e0__, &e1__))                                        \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0__, e1__, 0, __VA_ARGS__);                \
+    else                                                                                              \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                  \
   } while (0)
 
 static inline int mmg_valid_D(int D) { return D == 64 || D == 128 || D == 256; }

@@ -394,10 +394,11 @@ __global__ __launch_bounds__(256) void k_dropout_mask(uint64_t seed, const uint6
 constexpr int PL_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void k_pair_loss(const float* __restrict__ pred, const float* __restrict__ y,
                                                    const float* __restrict__ w, const float* __restrict__ sup, int64_t n,
-                                                   double inv_den, int loss_type, float* __restrict__ dpred,
-                                                   double* __restrict__ partial) {
+                                                   double inv_den, const double* __restrict__ inv_den_ptr, int loss_type,
+                                                   float* __restrict__ dpred, double* __restrict__ partial) {
   __shared__ double red[4];
   double s = 0;
+  if (inv_den_ptr) inv_den = *inv_den_ptr;          // device-resident normaliser (hipGraph replays with a new mask)
   const float invf = (float)inv_den;
   for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
     const float d = pred[k] - y[k];
@@ -465,7 +466,7 @@ extern "C" int mmg_col_reduce2(const float* A, const float* B, double* out, int6
                                void* stream) {
   MMG_CHECK_ARG(M >= 0 && out, "col_reduce2: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (M == 0) { hipMemsetAsync(out, 0, (size_t)2 * N * 8, st); return MMG_OK; }
+  if (M == 0) { MMG_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)2 * N * 8, st), "col_reduce2(memset)"); return MMG_OK; }
   MMG_CHECK_ARG(A && ws, "col_reduce2: null buffer");
   int rc = run_col_reduce<0>(A, B, mmg_pro_dev(nullptr), nullptr, nullptr, out, M, N, ws, ws_bytes, st, "col_reduce2");
   if (rc) return rc;
@@ -513,7 +514,7 @@ extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prolog
                                 void* stream) {
   MMG_CHECK_ARG(M >= 0 && sums && mean && rstd, "bn_bwd_stats: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (M == 0) { hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st); return MMG_OK; }
+  if (M == 0) { MMG_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st), "bn_bwd_stats(memset)"); return MMG_OK; }
   MMG_CHECK_ARG(G && Y && ws, "bn_bwd_stats: null buffer");
   int rc = run_col_reduce<1>(G, Y, mmg_pro_dev(pro), mean, rstd, sums, M, N, ws, ws_bytes, st, "bn_bwd_stats");
   if (rc) return rc;
@@ -526,7 +527,7 @@ extern "C" int mmg_bn_bwd_stats2(const float* G, const float* G2, const float* Y
                                  int N, void* ws, size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(M >= 0 && sums && mean && rstd, "bn_bwd_stats2: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (M == 0) { hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st); return MMG_OK; }
+  if (M == 0) { MMG_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st), "bn_bwd_stats(memset)"); return MMG_OK; }
   MMG_CHECK_ARG(G && G2 && Y && ws && pro && pro2, "bn_bwd_stats2: null buffer");
   const ProDev p2 = mmg_pro_dev(pro2);
   int rc = run_col_reduce<1>(G, Y, mmg_pro_dev(pro), mean, rstd, sums, M, N, ws, ws_bytes, st, "bn_bwd_stats2", G2, &p2);
@@ -543,7 +544,7 @@ extern "C" int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const 
   MMG_CHECK_ARG(n_sel >= 0 && sums && mean && rstd, "bn_bwd_stats_rows: bad args");
   MMG_CHECK_ARG(N > 0 && N % 4 == 0 && N <= 256 && 256 % (N / 4) == 0, "bn_bwd_stats_rows: N=%d unsupported", N);
   hipStream_t st = (hipStream_t)stream;
-  if (n_sel == 0) { hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st); return MMG_OK; }
+  if (n_sel == 0) { MMG_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st), "bn_bwd_stats_rows(memset)"); return MMG_OK; }
   MMG_CHECK_ARG(G_rows && Y && rows && ws, "bn_bwd_stats_rows: null buffer");
   MMG_CHECK_ARG(ws_bytes >= mmg_bn_bwd_stats_rows_ws_bytes(N), "bn_bwd_stats_rows: workspace too small");
   double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
@@ -637,7 +638,8 @@ extern "C" int mmg_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_
 extern "C" size_t mmg_pair_loss_ws_bytes(int64_t n) { return n < 0 ? 0 : (size_t)PL_BLOCKS * 8 + 256; }
 
 extern "C" int mmg_pair_loss(const float* pred, const float* y, const float* w, const float* sup, int64_t n, double inv_den,
-                             int loss_type, float* dpred, double* loss, void* ws, size_t ws_bytes, void* stream) {
+                             const double* inv_den_ptr, int loss_type, float* dpred, double* loss, void* ws,
+                             size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(n >= 0 && loss && ws, "pair_loss: bad args");
   MMG_CHECK_ARG(loss_type == 0 || loss_type == 1, "pair_loss: loss_type must be 0 (mae) or 1 (mse)");
   MMG_CHECK_ARG(n == 0 || (pred && y), "pair_loss: null buffer");
@@ -647,7 +649,7 @@ extern "C" int mmg_pair_loss(const float* pred, const float* y, const float* w, 
   int64_t nb = (n + 255) / 256;
   if (nb > PL_BLOCKS) nb = PL_BLOCKS;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(k_pair_loss, dim3((unsigned)nb), dim3(256), 0, st, pred, y, w, sup, n, inv_den, loss_type, dpred, partial);
+  hipLaunchKernelGGL(k_pair_loss, dim3((unsigned)nb), dim3(256), 0, st, pred, y, w, sup, n, inv_den, inv_den_ptr, loss_type, dpred, partial);
   hipLaunchKernelGGL(k_partial_sum, dim3(1), dim3(256), 0, st, partial, loss, 1, (int)nb);
   MMG_CHECK_LAUNCH("pair_loss");
   return MMG_OK;

@@ -1,18 +1,19 @@
-// Dense layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32; exact fp32, 256 FLOP/clk/CU).
-// Replaces nn.Linear (+ the BatchNorm/ReLU/Dropout in front of it) of src/model.py:93-105 and the
+// Dense layers.  Replaces nn.Linear (+ the BatchNorm/ReLU/Dropout in front of it) of src/model.py:93-105 and the
 // lin_l / lin_r of PyG SAGEConv (call site src/model.py:125-131).
 //
-// linear_fwd : Y[M,N] = prologue(X)[M,K] . W[N,K]^T + b.  The W fragments stay resident in registers;
-//              a workgroup (4 waves as 2(M) x 2(N)) streams 64-row X tiles through LDS.  The k axis is
-//              split between the two lane halves (lane>>5 takes k in [h*K/2,(h+1)*K/2)), so every
-//              A fragment read is a contiguous ds_read_b128 (4 MFMA steps per read).
-// linear_wgrad: dW[N,K] = dY^T . prologue(X): each workgroup reduces a row chunk into a [TN,TK]
-//              register tile (operands are read column-wise: consecutive lanes, consecutive floats),
-//              writes one partial slab; a second kernel sums the slabs in fixed order.
+// fp32 products on the bf16 matrix cores, exactly: an fp32 value is the sum of three bf16 pieces (8 significant bits
+// each) and x.w = x1w1 + (x1w2 + x2w1) + (x2w2 + x1w3 + x3w1) + O(2^-24 |x||w|) -- six v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation per product tile (k_linear_fwd_x6, k_linear_wgrad_x6, k_linear_wgrad_ws).
+// 6/16 of the fp32 matrix time turns the [P,128] x [128,128] layers from matrix-bound into HBM-bound.
+//
+// linear_fwd : Y[M,N] = prologue(X)[M,K] . W[N,K]^T + b.  The W pieces stay resident in registers; X tiles are
+//              prologue'd and split ONCE while staged to three bf16 LDS planes (double-buffered, one barrier per
+//              32-row tile).  k_linear_small serves the vocab-side tables (M <= 512); k_linear_fwd (fp32 MFMA,
+//              v_mfma_f32_32x32x2_f32) remains for the one shape the split kernel has no instance for (K = 256, N = 64).
+// linear_wgrad: dW[N,K] = dY^T . prologue(X): contraction over the rows; every workgroup reduces a set of 32-row
+//              stages into a [TN,TK] register tile, writes one partial slab, a second kernel sums the slabs in
+//              fixed order (bitwise reproducible).  The bias gradient (column sums of dY) rides in the same pass.
 #include "common.h"
-#include <hip/hip_ext.h>
-#include <stdlib.h>
-#include <vector>
 
 namespace {
 
@@ -347,34 +348,17 @@ inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y 
   return gy;
 }
 
-// Measurement hook (bench.py): while armed, every launch of the bf16-split forward is issued through
-// hipExtLaunchKernelGGL with a start / stop event pair, i.e. the events take the kernel's own begin / end timestamps
-// (what rocprofv3 reports) instead of bracketing it with two more queue entries.
-struct ProbeEntry { hipEvent_t e0, e1; int64_t M; int N, K, flags; };
-static std::vector<ProbeEntry> g_probe;
-static int g_probe_left = 0;
-
 template <int K, int WN, bool PRO, bool ACC>
 int launch_fwd_x6_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                     int flags, hipStream_t st, double* stat_partial) {
   constexpr int BN = 32 * WN;
   const int n_slices = N / BN;
   const int64_t gy = fwd_x6_rows(M, N, BN, K);
-  const size_t lds = (size_t)2 * 3 * 32 * (K + 8) * 2;
-  (void)hipFuncSetAttribute((const void*)k_linear_fwd_x6<K, WN, PRO, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  if (g_probe_left > 0) {
-    ProbeEntry e{nullptr, nullptr, M, N, K, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0)};
-    if (hipEventCreate(&e.e0) == hipSuccess && hipEventCreate(&e.e1) == hipSuccess) {
-      hipExtLaunchKernelGGL((k_linear_fwd_x6<K, WN, PRO, ACC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds,
-                            st, e.e0, e.e1, 0, X, pr, W, bias, Y, M, N, flags, stat_partial);
-      g_probe.push_back(e);
-      --g_probe_left;
-      return 0;
-    }
-  }
-  hipLaunchKernelGGL((k_linear_fwd_x6<K, WN, PRO, ACC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds, st, X,
-                     pr, W, bias, Y, M, N, flags, stat_partial);
+  constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_x6<K, WN, PRO, ACC>, lds>::set()), "linear_fwd(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0),
+             (k_linear_fwd_x6<K, WN, PRO, ACC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds, st, X,
+             pr, W, bias, Y, M, N, flags, stat_partial);
   return 0;
 }
 
@@ -456,100 +440,6 @@ __global__ __launch_bounds__(256) void k_linear_small(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------- wgrad
 constexpr int WG_ROWS = 32;   // rows reduced per LDS stage
-
-template <int TN, int TK>
-__global__ __launch_bounds__(256) void k_linear_wgrad(const float* __restrict__ dY, const float* __restrict__ X,
-                                                      ProDev pr, float* __restrict__ slab, int64_t M, int N, int K,
-                                                      int64_t rows_per_split, int direct_accumulate) {
-  pr.resolve();
-  // grid: x = output tile (tn-major over N/TN x K/TK), y = row split
-  constexpr int MT = TN / 64, KT = TK / 64;   // 32x32 tiles per wave along n and k
-  __shared__ __attribute__((aligned(16))) float Ys[WG_ROWS][TN];
-  __shared__ __attribute__((aligned(16))) float Xs[WG_ROWS][TK];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wn = wid >> 1, wk = wid & 1;
-  const int tiles_k = K / TK;
-  const int tn0 = (blockIdx.x / tiles_k) * TN, tk0 = (blockIdx.x % tiles_k) * TK;
-  const int64_t r_beg = (int64_t)blockIdx.y * rows_per_split;
-  const int64_t r_end = min(M, r_beg + rows_per_split);
-
-  f32x16 acc[MT][KT];
-#pragma unroll
-  for (int a = 0; a < MT; ++a)
-#pragma unroll
-    for (int b = 0; b < KT; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-
-  const int h = lane >> 5, l31 = lane & 31;
-  constexpr int NY = WG_ROWS * (TN / 4) / 256, NX = WG_ROWS * (TK / 4) / 256;   // 16-B loads per thread per stage
-  f32x4 ny[NY], nxr[NX];
-  auto fetch = [&](int64_t r0) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < NY; ++u) {
-      const int i = tid + u * 256, r = i / (TN / 4), c4 = i - r * (TN / 4);
-      ny[u] = (r0 + r < r_end) ? *reinterpret_cast<const f32x4*>(dY + (size_t)(r0 + r) * N + tn0 + c4 * 4) : z;
-    }
-#pragma unroll
-    for (int u = 0; u < NX; ++u) {
-      const int i = tid + u * 256, r = i / (TK / 4), c4 = i - r * (TK / 4);
-      nxr[u] = (r0 + r < r_end) ? *reinterpret_cast<const f32x4*>(X + (size_t)(r0 + r) * K + tk0 + c4 * 4) : z;
-    }
-  };
-  if (r_beg < r_end) fetch(r_beg);
-  for (int64_t r0 = r_beg; r0 < r_end; r0 += WG_ROWS) {
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < NY; ++u) {
-      const int i = tid + u * 256, r = i / (TN / 4), c4 = i - r * (TN / 4);
-      *reinterpret_cast<f32x4*>(&Ys[r][c4 * 4]) = ny[u];
-    }
-#pragma unroll
-    for (int u = 0; u < NX; ++u) {
-      const int i = tid + u * 256, r = i / (TK / 4), c4 = i - r * (TK / 4);
-      f32x4 v = nxr[u];
-      const int64_t gr = r0 + r;
-      if (gr < r_end && (pr.scale || pr.relu || pr.p > 0.f)) {
-        const int k = tk0 + c4 * 4;
-        f32x4 s4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-        if (pr.scale) { s4 = *reinterpret_cast<const f32x4*>(pr.scale + k); sh4 = *reinterpret_cast<const f32x4*>(pr.shift + k); }
-        mmg_pro_apply4(pr, v, s4, sh4, gr, k, K);
-      }
-      *reinterpret_cast<f32x4*>(&Xs[r][c4 * 4]) = v;
-    }
-    __syncthreads();
-    if (r0 + WG_ROWS < r_end) fetch(r0 + WG_ROWS);
-    // A[i=n][k=m] = dY[m][n],  B[k=m][j=kk] = X[m][kk];  lane half h takes m = h*16 + s
-#pragma unroll 4
-    for (int s = 0; s < WG_ROWS / 2; ++s) {
-      const int m = h * (WG_ROWS / 2) + s;
-      float a[MT], b[KT];
-#pragma unroll
-      for (int x = 0; x < MT; ++x) a[x] = Ys[m][wn * (TN / 2) + x * 32 + l31];
-#pragma unroll
-      for (int x = 0; x < KT; ++x) b[x] = Xs[m][wk * (TK / 2) + x * 32 + l31];
-#pragma unroll
-      for (int x = 0; x < MT; ++x)
-#pragma unroll
-        for (int y = 0; y < KT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[x], b[y], acc[x][y], 0, 0, 0);
-    }
-  }
-  // slab[split][N][K]; with a single split `slab` is dW itself (direct_accumulate: 1 = overwrite, 2 = add)
-  float* dst = slab + (size_t)blockIdx.y * N * K;
-#pragma unroll
-  for (int x = 0; x < MT; ++x)
-#pragma unroll
-    for (int y = 0; y < KT; ++y)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = tn0 + wn * (TN / 2) + x * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const int k = tk0 + wk * (TK / 2) + y * 32 + l31;
-        float v = acc[x][y][i];
-        if (direct_accumulate == 2) v += dst[(size_t)n * K + k];
-        dst[(size_t)n * K + k] = v;
-      }
-}
 
 // wgrad on the bf16 matrix cores: dW[n, k] = sum_m dY[m, n] * pro(X)[m, k] with the same exact 6-term split.  Both
 // operands are contracted over their ROW index, so the fragments are column slices of the row-major tiles: the
@@ -923,30 +813,31 @@ __global__ __launch_bounds__(512) void k_linear_wgrad_ws(const float* __restrict
   }
 }
 
-void launch_wgrad_ws(dim3 grid, hipStream_t st, const float* dY, const float* X, float* target, int64_t M, int N, int K,
-                     int direct, int64_t slab_stride, float* dbias) {
-  const size_t lds = (size_t)2 * 2 * 3 * 4 * 128 * 8 * 2;      // two stages of fragment-ordered planes: 96 KB
-  (void)hipFuncSetAttribute((const void*)k_linear_wgrad_ws, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_linear_wgrad_ws, grid, dim3(512), lds, st, dY, X, target, M, N, K, direct, slab_stride, dbias);
+int launch_wgrad_ws(dim3 grid, hipStream_t st, const float* dY, const float* X, float* target, int64_t M, int N, int K,
+                    int direct, int64_t slab_stride, float* dbias) {
+  constexpr int lds = 2 * 2 * 3 * 4 * 128 * 8 * 2;             // two stages of fragment-ordered planes: 96 KB
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_wgrad_ws, lds>::set()), "linear_wgrad(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_WGRAD, M, N, K, 0, k_linear_wgrad_ws, grid, dim3(512), lds, st, dY, X, target, M, N, K,
+             direct, slab_stride, dbias);
+  return MMG_OK;
 }
 
 template <int TN, int TK, int WNN, int WNK, bool PRO>
-void launch_wgrad_x6_v(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
-                       int N, int K, int64_t rps, int direct, int64_t slab_stride, float* dbias) {
-  const size_t lds = (size_t)2 * 3 * WG_ROWS * ((TN + 32) + (TK + 32)) * 2;
-  (void)hipFuncSetAttribute((const void*)k_linear_wgrad_x6<TN, TK, WNN, WNK, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
-  hipLaunchKernelGGL((k_linear_wgrad_x6<TN, TK, WNN, WNK, PRO>), grid, dim3(64 * WNN * WNK), lds, st, dY, X, pr, target, M, N,
-                     K, rps, direct, slab_stride, dbias);
+int launch_wgrad_x6_v(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
+                      int N, int K, int64_t rps, int direct, int64_t slab_stride, float* dbias) {
+  constexpr int lds = 2 * 3 * WG_ROWS * ((TN + 32) + (TK + 32)) * 2;
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_wgrad_x6<TN, TK, WNN, WNK, PRO>, lds>::set()), "linear_wgrad(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_WGRAD, M, N, K, PRO ? 4 : 0, (k_linear_wgrad_x6<TN, TK, WNN, WNK, PRO>), grid,
+             dim3(64 * WNN * WNK), lds, st, dY, X, pr, target, M, N, K, rps, direct, slab_stride, dbias);
+  return MMG_OK;
 }
 
 template <int TN, int TK, int WNN, int WNK>
-void launch_wgrad_x6(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
-                     int N, int K, int64_t rps, int direct, int64_t slab_stride, float* dbias) {
+int launch_wgrad_x6(dim3 grid, hipStream_t st, const float* dY, const float* X, const ProDev& pr, float* target, int64_t M,
+                    int N, int K, int64_t rps, int direct, int64_t slab_stride, float* dbias) {
   if (pr.scale || pr.relu || pr.p > 0.f)
-    launch_wgrad_x6_v<TN, TK, WNN, WNK, true>(grid, st, dY, X, pr, target, M, N, K, rps, direct, slab_stride, dbias);
-  else
-    launch_wgrad_x6_v<TN, TK, WNN, WNK, false>(grid, st, dY, X, pr, target, M, N, K, rps, direct, slab_stride, dbias);
+    return launch_wgrad_x6_v<TN, TK, WNN, WNK, true>(grid, st, dY, X, pr, target, M, N, K, rps, direct, slab_stride, dbias);
+  return launch_wgrad_x6_v<TN, TK, WNN, WNK, false>(grid, st, dY, X, pr, target, M, N, K, rps, direct, slab_stride, dbias);
 }
 
 struct EpiStore {
@@ -966,8 +857,7 @@ WgradPlan plan_wgrad(int64_t M, int N, int K) {
   p.n_tiles = (N / p.TN) * (K / p.TK);
   int64_t max_split = (M + WG_ROWS - 1) / WG_ROWS;
   if (max_split < 1) max_split = 1;
-  static const int wg_target = [] { const char* e = getenv("MMG_WGRAD_WGS"); return e ? atoi(e) : 256; }();
-  int64_t want = wg_target / p.n_tiles;
+  int64_t want = 256 / p.n_tiles;         // one workgroup per CU
   if (want < 1) want = 1;
   p.n_split = (int)(want < max_split ? want : max_split);
   if (M <= 256) p.n_split = 1;            // vocab-side tables: one workgroup per output tile, direct write
@@ -994,11 +884,6 @@ int launch_fwd(const float* X, const ProDev& pr, const float* W, const float* bi
   return 0;
 }
 
-inline bool fp32_mfma() {
-  static const int v = [] { const char* e = getenv("MMG_LINEAR_FP32"); return e ? atoi(e) : 0; }();
-  return v != 0;
-}
-
 template <int K>
 int launch_small(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                  int accumulate, hipStream_t st) {
@@ -1012,30 +897,6 @@ int launch_small(const float* X, const ProDev& pr, const float* W, const float* 
 extern "C" int mmg_col_reduce2(const float* A, const float* B, double* out, int64_t M, int N, void* ws, size_t ws_bytes,
                                void* stream);
 extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream);
-
-extern "C" int mmg_probe_arm(int n_launches) {
-  for (auto& e : g_probe) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
-  g_probe.clear();
-  g_probe_left = n_launches > 0 ? n_launches : 0;
-  return MMG_OK;
-}
-
-extern "C" int mmg_probe_read(float* ms, int64_t* M, int* N, int* K, int* flags, int cap) {
-  g_probe_left = 0;
-  int n = 0;
-  for (auto& e : g_probe) {
-    if (n < cap) {
-      float t = 0.f;
-      if (hipEventSynchronize(e.e1) == hipSuccess && hipEventElapsedTime(&t, e.e0, e.e1) == hipSuccess) {
-        ms[n] = t; M[n] = e.M; N[n] = e.N; K[n] = e.K; flags[n] = e.flags;
-        ++n;
-      }
-    }
-    (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1);
-  }
-  g_probe.clear();
-  return n;
-}
 
 extern "C" size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N) {
   if (M < 0 || N <= 0) return 0;
@@ -1076,35 +937,27 @@ extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, c
     if (K == 64) launch_small<64>(X, pr, W, bias, Y, M, N, accumulate, st);
     else if (K == 128) launch_small<128>(X, pr, W, bias, Y, M, N, accumulate, st);
     else launch_small<256>(X, pr, W, bias, Y, M, N, accumulate, st);
-  } else if ((K <= 128 || N % 128 == 0) && !fp32_mfma()) {
-    // exact-product 6-term bf16 split on the bf16 matrix cores (MMG_LINEAR_FP32=1: the fp32-MFMA kernels below)
+  } else if (K <= 128 || N % 128 == 0) {
+    // exact-product 6-term bf16 split on the bf16 matrix cores
+    int rc = 0;
     if (K == 64) {
-      if (N % 128 == 0) launch_fwd_x6<64, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
-      else launch_fwd_x6<64, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+      if (N % 128 == 0) rc = launch_fwd_x6<64, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+      else rc = launch_fwd_x6<64, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
     } else if (K == 128) {
-      if (N % 128 == 0) launch_fwd_x6<128, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
-      else launch_fwd_x6<128, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+      if (N % 128 == 0) rc = launch_fwd_x6<128, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+      else rc = launch_fwd_x6<128, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
     } else {
-      launch_fwd_x6<256, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+      rc = launch_fwd_x6<256, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
     }
+    if (rc) return rc;
     if (col_sums) {     // partial[gy][2][N] -> col_sums[2][N]
       const int rows = (int)fwd_x6_rows(M, N, N % 128 == 0 ? 128 : 64, K);
       int rc2 = mmg_partial_sum(partial, col_sums, 2 * N, rows, stream);
       if (rc2) return rc2;
       stats_done = true;
     }
-  } else if (K == 64) {
-    if (N % 128 == 0) launch_fwd<64, 2, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
-    else launch_fwd<64, 1, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
-  } else if (K == 128) {
-    // MMG_LINEAR_WIDE (A/B knob, measured within 1 % of each other at x100): 2 = 128-wide slices, two workgroups
-    // per CU, no register prefetch (default); 1 = 128-wide, one workgroup per CU, X prefetched one tile ahead
-    // (~300 VGPRs); 0 = 64-wide slices, two per CU, X read twice.
-    static const int wide = [] { const char* e = getenv("MMG_LINEAR_WIDE"); return e ? atoi(e) : 2; }();
-    if (N % 128 == 0 && wide == 2) launch_fwd<128, 2, 2, 0>(X, pr, W, bias, Y, M, N, accumulate, st);
-    else if (N % 128 == 0 && wide) launch_fwd<128, 2, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
-    else launch_fwd<128, 1, 2, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
   } else {
+    // K = 256 with a 64-wide output (the heads' first layer at 256-d): fp32 matrix cores, one workgroup per CU
     launch_fwd<256, 1, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
   }
   MMG_CHECK_LAUNCH("linear_fwd");
@@ -1126,13 +979,12 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
     if (!accumulate) {
-      hipMemsetAsync(dW, 0, (size_t)N * K * 4, st);
-      if (dbias) hipMemsetAsync(dbias, 0, (size_t)N * 4, st);
+      MMG_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)N * K * 4, st), "linear_wgrad(memset)");
+      if (dbias) MMG_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)N * 4, st), "linear_wgrad(memset)");
     }
     return MMG_OK;
   }
   MMG_CHECK_ARG(dY && X && ws, "linear_wgrad: null buffer");
-  MMG_CHECK_ARG(!dbias || !fp32_mfma(), "linear_wgrad: the bias sums are produced by the bf16-split kernel only");
   const size_t need = mmg_linear_wgrad_ws_bytes(M, N, K);
   if (ws_bytes < need) {
     mmg_set_error("linear_wgrad: workspace %zu < %zu", ws_bytes, need);
@@ -1145,29 +997,24 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
   const int direct = p.n_split == 1 ? (accumulate ? 2 : 1) : 0;     // small M: no slab, no reduce launch
   float* target = direct ? dW : slab;
   const int64_t stride = (int64_t)N * K + (dbias ? N : 0);
-  if (!fp32_mfma()) {
+  {
     // eight waves (two per SIMD: one stages while the other multiplies) wherever the tile has 8 sub-tiles
     const int64_t rps = p.rows_per_split;
-    // role-specialised kernel for the plain 128 x 128 case (MMG_WGRAD_ROLES=0: the symmetric kernel everywhere); with a
-    // prologue the X stagers would also carry the dropout hashes and the symmetric kernel is faster (53 vs 64 us)
-    static const int ws_roles = [] { const char* e = getenv("MMG_WGRAD_ROLES"); return e ? atoi(e) : 1; }();
+    // role-specialised kernel for the plain 128 x 128 case; with a prologue the X stagers would also carry the dropout
+    // hashes and the symmetric kernel is faster (53 vs 64 us)
     const bool has_pro = pr.scale || pr.relu || pr.p > 0.f;
-    if (p.TN == 128 && p.TK == 128 && ws_roles && !has_pro) launch_wgrad_ws(grid, st, dY, X, target, M, N, K, direct, stride, dbias);
-    else if (p.TN == 128 && p.TK == 128) launch_wgrad_x6<128, 128, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
-    else if (p.TN == 128) launch_wgrad_x6<128, 64, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
-    else if (p.TK == 128) launch_wgrad_x6<64, 128, 2, 4>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
-    else launch_wgrad_x6<64, 64, 2, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
-  } else if (p.TN == 128 && p.TK == 128)
-    hipLaunchKernelGGL((k_linear_wgrad<128, 128>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
-  else if (p.TN == 128)
-    hipLaunchKernelGGL((k_linear_wgrad<128, 64>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
-  else if (p.TK == 128)
-    hipLaunchKernelGGL((k_linear_wgrad<64, 128>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
-  else
-    hipLaunchKernelGGL((k_linear_wgrad<64, 64>), grid, dim3(256), 0, st, dY, X, pr, target, M, N, K, p.rows_per_split, direct);
+    int rc = 0;
+    if (p.TN == 128 && p.TK == 128 && !has_pro) rc = launch_wgrad_ws(grid, st, dY, X, target, M, N, K, direct, stride, dbias);
+    else if (p.TN == 128 && p.TK == 128) rc = launch_wgrad_x6<128, 128, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
+    else if (p.TN == 128) rc = launch_wgrad_x6<128, 64, 4, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
+    else if (p.TK == 128) rc = launch_wgrad_x6<64, 128, 2, 4>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
+    else rc = launch_wgrad_x6<64, 64, 2, 2>(grid, st, dY, X, pr, target, M, N, K, rps, direct, stride, dbias);
+    if (rc) return rc;
+  }
   if (!direct) {
-    hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiStore>), dim3((unsigned)((stride / 4 + 15) / 16)), dim3(256), 0, st, slab,
-                       stride / 4, p.n_split, EpiStore{dW, accumulate, dbias, (int64_t)N * K / 4});
+    MMG_LAUNCH(MMG_PROBE_LINEAR_WGRAD_REDUCE, M, N, K, 0, (mmg_k_reduce_slabs<EpiStore>),
+               dim3((unsigned)((stride / 4 + 15) / 16)), dim3(256), 0, st, slab, stride / 4, p.n_split,
+               EpiStore{dW, accumulate, dbias, (int64_t)N * K / 4});
   }
   MMG_CHECK_LAUNCH("linear_wgrad");
   return MMG_OK;

@@ -2,12 +2,11 @@
 // reference).  The first Linear(2D,64) is applied per NODE by mmg_linear_fwd (A = x_P.W1[:, :D]^T,
 // B = x_lab.W1[:, D:]^T + b1), so the per-pair work is a 64-wide gather-add + a 64x32 and a 32x1 layer.
 //
-// One launch serves ONE head; the gate (deg[pi] < threshold) is evaluated per pair and lanes whose
-// pair belongs to the other head are predicated off.  Thread-per-pair on the vector ALUs (fp32);
-// weights are broadcast from LDS.  Backward recomputes the forward (nothing per-pair is stored) and
-// reduces   dW2 through transposed LDS tiles,   dW3/db2/db3 through wave reductions,
-//           dA[pi] by run-length pre-reduction + one 256-B atomic per run (pairs sorted by patient
-//           collapse to ~1 atomic per patient),   dB[li] in LDS accumulators.
+// One launch serves ONE head over a compacted, patient-sorted list of pair positions (mmg_pair_select).
+// k_pair_fwd_mfma / k_pair_bwd_mfma: one wave per 32-pair tile on the matrix cores (the 64x32 layer as the exact
+// six-term bf16 split in the forward; four chained products in the backward, which recomputes the forward -- nothing
+// per pair is stored), node rows and indices through a software pipeline of unconditional buffer loads.
+// k_pair_bwd (thread-per-pair on the vector ALUs, LDS accumulators for dB) remains for lab vocabularies > 128 rows.
 #include "common.h"
 
 namespace {
@@ -909,15 +908,15 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   const size_t lds = (size_t)n_labs_lds * PF_LDB * sizeof(float);
   MMG_CHECK_ARG(n_pairs < (1ll << 29), "pair_head_fwd: %lld pairs exceed the 32-bit buffer descriptors", (long long)n_pairs);
   if (n_labs_lds) {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)k_pair_fwd_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_pair_fwd_mfma<true>, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, H, pi, li, deg,
-                       degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel,
-                       io_perm, n_labs_lds);
+    constexpr int lds_max = 256 * PF_LDB * (int)sizeof(float);
+    MMG_CHECK_HIP((MmgMaxLds<&k_pair_fwd_mfma<true>, lds_max>::set()), "pair_head_fwd(attr)");
+    MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, want_low ? 2 : 0, k_pair_fwd_mfma<true>, dim3((unsigned)g), dim3(256),
+               lds, (hipStream_t)stream, H, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed,
+               seed_ptr, pair_id, pred, sel, n_sel, io_perm, n_labs_lds);
   } else {
-    hipLaunchKernelGGL(k_pair_fwd_mfma<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, H, pi, li, deg,
-                       degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed, seed_ptr, pair_id, pred, sel, n_sel,
-                       io_perm, 0);
+    MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, want_low ? 2 : 0, k_pair_fwd_mfma<false>, dim3((unsigned)g), dim3(256),
+               0, (hipStream_t)stream, H, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed,
+               seed_ptr, pair_id, pred, sel, n_sel, io_perm, 0);
   }
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;
@@ -947,9 +946,9 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
                                          // global atomics in the final flush (512 -> 256: -0.6 % on the step)
     if (g < 1) g = 1;
 #define MMG_LAUNCH_PBWD(LT_, AUX_)                                                                                    \
-  hipLaunchKernelGGL((k_pair_bwd_mfma<LT_, AUX_>), dim3((unsigned)g), dim3(256), 0, st, H, G, pi, li, deg,              \
-                     degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed, seed_ptr, pair_id, dpred, sel,  \
-                     n_sel, io_perm)
+  MMG_LAUNCH(MMG_PROBE_PAIR_BWD, n_pairs, 0, 0, want_low ? 2 : 0, (k_pair_bwd_mfma<LT_, AUX_>), dim3((unsigned)g),      \
+             dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed,    \
+             seed_ptr, pair_id, dpred, sel, n_sel, io_perm)
     const bool aux = pair_id != nullptr || io_perm != nullptr;
     if (n_labs <= 64) { if (aux) MMG_LAUNCH_PBWD(2, true); else MMG_LAUNCH_PBWD(2, false); }
     else { if (aux) MMG_LAUNCH_PBWD(4, true); else MMG_LAUNCH_PBWD(4, false); }
@@ -958,11 +957,7 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     size_t lds = BWD_LDS_FIXED;
     int lds_db = 0;
     if (lds + (size_t)n_labs * 64 * 4 <= BWD_LDS_MAX) { lds += (size_t)n_labs * 64 * 4; lds_db = 1; }
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute((const void*)k_pair_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_MAX);
-      attr = true;
-    }
+    MMG_CHECK_HIP((MmgMaxLds<&k_pair_bwd, (int)BWD_LDS_MAX>::set()), "pair_head_bwd(attr)");
     int64_t g = (n_pairs + PT - 1) / PT;
     if (g > 512) g = 512;
     hipLaunchKernelGGL(k_pair_bwd, dim3((unsigned)g), dim3(PT), lds, st, H, G, pi, li, deg, degree_threshold,
@@ -984,10 +979,7 @@ extern "C" int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree
   MMG_CHECK_ARG(counts, "pair_select: counts is null");
   hipStream_t st = (hipStream_t)stream;
   if (n_pairs == 0) {
-    if (hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st) != hipSuccess) {
-      mmg_set_error("pair_select: memset failed");
-      return MMG_E_LAUNCH;
-    }
+    MMG_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st), "pair_select(memset)");
     return MMG_OK;
   }
   MMG_CHECK_ARG(pi && deg && sel_low && sel_high, "pair_select: null buffer");

@@ -153,14 +153,25 @@ def _plan_key(data) -> tuple:
     return tuple(k)
 
 
-_PLAN_CACHE: Dict[tuple, GraphPlan] = {}
+# key -> (plan, the edge_index tensors the key was derived from).  The entry HOLDS those tensors: a key is built from
+# their data_ptr(), and the caching allocator hands a freed address to the next graph of the same size -- without the
+# reference a stale plan (CSR, masks, degrees of the old graph) would be returned for it.
+_PLAN_CACHE: Dict[tuple, tuple] = {}
+
+
+def drop_cached_plan(plan: "GraphPlan"):
+    """Remove `plan` from the cache (dist.shard_plan rewrites it in place: a later unsharded use of the same graph must
+    not get the sharded plan)."""
+    ent = _PLAN_CACHE.get(plan.key)
+    if ent is not None and ent[0] is plan:
+        del _PLAN_CACHE[plan.key]
 
 
 def build_plan(data, device=None, validate: bool = True, use_cache: bool = True) -> GraphPlan:
     """CSR-by-patient for every relation of ``data`` (a PyG HeteroData or a HeteroGraph)."""
     key = _plan_key(data)
     if use_cache and key in _PLAN_CACHE:
-        return _PLAN_CACHE[key]
+        return _PLAN_CACHE[key][0]
     node_types = list(data.node_types)
     edge_types = [tuple(e) for e in data.edge_types]
     num_nodes = {t: int(data[t].num_nodes) for t in node_types}
@@ -219,5 +230,5 @@ def build_plan(data, device=None, validate: bool = True, use_cache: bool = True)
     if use_cache:
         if len(_PLAN_CACHE) > 8:
             _PLAN_CACHE.clear()
-        _PLAN_CACHE[key] = plan
+        _PLAN_CACHE[key] = (plan, [data[et].edge_index for et in data.edge_types])
     return plan

@@ -128,7 +128,8 @@ def shard_pairs(pi: torch.Tensor, li: torch.Tensor, lo: int, hi: int):
 def shard_plan(plan: GraphPlan, comm: ShardComm, row_offset: int, n_rows_global: int) -> GraphPlan:
     """Turn a rank-local plan into a shard of the global graph: vocab in-degrees become global
     (one all-reduce of the [sum V_t] counts at setup), rows get their global offset."""
-    from . import ops  # noqa: F401
+    from .data import drop_cached_plan
+    drop_cached_plan(plan)               # rewritten in place below: the cache must not hand it to an unsharded caller
     done = set()
     for et, rel in plan.rels.items():
         if id(rel.col_cnt) in done:

@@ -992,7 +992,15 @@ class _Run:
             g = gs[which]
             glab = ops.linear_fwd(g.B, w1b, w_kn=True)
             if want_low:                         # gradient rows of the low-degree patients only: (row ids, rows)
-                gP = (low_rows, ops.linear_fwd(g.A, w1a, w_kn=True)) if xP.shape[0] else None
+                if xP.shape[0]:
+                    gP = (low_rows, ops.linear_fwd(g.A, w1a, w_kn=True))
+                elif self.comm is not None:
+                    # a shard without a low-degree patient still takes part in the backward of the first encoder pass:
+                    # its BatchNorm backward needs the GLOBAL sums (rows with a zero upstream gradient get a non-zero
+                    # dz2 once any other shard has one), and every rank must issue the same sequence of collectives
+                    gP = (low_rows, torch.zeros(0, D, device=self.dev))
+                else:
+                    gP = None                    # single GPU, no such row anywhere: the whole pass contributes exactly 0
             else:
                 gP = ops.linear_fwd(g.A, w1a, w_kn=True)
             gsets[which] = {ROW_TYPE: gP, "lab": glab}

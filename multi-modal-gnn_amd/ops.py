@@ -7,7 +7,6 @@ fp32 (indices int32 unless stated); violations raise instead of silently copying
 from __future__ import annotations
 
 import ctypes as C
-import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -87,18 +86,25 @@ def _pe(tok, name, nbytes=0, flops=0):
     _PROF.rows.append((name, tok, e, int(nbytes), int(flops)))
 
 
+PROBE_TAGS = {1: "linear_fwd", 2: "linear_wgrad", 3: "linear_wgrad_reduce", 4: "gather_rows", 5: "scatter_rows",
+              6: "scatter_reduce", 7: "pair_head_fwd", 8: "pair_head_bwd", 9: "bn_bwd_stats", 10: "bn_bwd_apply",
+              11: "elementwise"}
+
+
 def probe_arm(n: int):
-    """Measurement hook: the next n launches of the bf16-split dense forward carry their own HIP event pair."""
+    """Measurement hook: the next n big-kernel launches of this thread carry their own HIP start / stop event pair."""
     check(_lib.load().mmg_probe_arm(int(n)), "mmg_probe_arm")
 
 
-def probe_read(cap: int = 65536):
-    """-> list of (ms, M, N, K, flags) of the probed launches (flags: 1 = accumulate, 4 = prologue)."""
+def probe_read(cap: int = 1 << 18):
+    """-> list of (ms, family name, M, N, K, flags) of the probed launches (flags: 1 accumulate, 4 prologue, 8 rowscale)."""
     import numpy as np
-    ms = np.zeros(cap, np.float32); M = np.zeros(cap, np.int64)
+    ms = np.zeros(cap, np.float32); tag = np.zeros(cap, np.int32); M = np.zeros(cap, np.int64)
     N = np.zeros(cap, np.int32); K = np.zeros(cap, np.int32); fl = np.zeros(cap, np.int32)
-    n = _lib.load().mmg_probe_read(ms.ctypes.data, M.ctypes.data, N.ctypes.data, K.ctypes.data, fl.ctypes.data, cap)
-    return [(float(ms[i]), int(M[i]), int(N[i]), int(K[i]), int(fl[i])) for i in range(n)]
+    n = _lib.load().mmg_probe_read(ms.ctypes.data, tag.ctypes.data, M.ctypes.data, N.ctypes.data, K.ctypes.data,
+                                   fl.ctypes.data, cap)
+    return [(float(ms[i]), PROBE_TAGS.get(int(tag[i]), str(int(tag[i]))), int(M[i]), int(N[i]), int(K[i]), int(fl[i]))
+            for i in range(n)]
 
 
 _WS = {}
@@ -306,9 +312,6 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
     return (out, sums) if with_stats else out
 
 
-_WGRAD_BIAS = os.environ.get("MMG_LINEAR_FP32", "0") in ("", "0")     # the bf16-split kernel produces the bias sums
-
-
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, out: Optional[torch.Tensor] = None,
                  accumulate: bool = False, with_bias: bool = False, bias_out: Optional[torch.Tensor] = None):
     """out[N,K] (+)= dy[M,N]^T @ pro(x)[M,K].  with_bias: also return the column sums of dy ([N] float, the bias
@@ -322,7 +325,7 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, o
         out = torch.empty(N, K, dtype=torch.float32, device=x.device)
         accumulate = False
     dbias = None
-    if with_bias and _WGRAD_BIAS:
+    if with_bias:
         dbias = bias_out if (bias_out is not None and accumulate) else torch.empty(N, dtype=torch.float32, device=x.device)
     nb = lib.mmg_linear_wgrad_ws_bytes(M, N, K)
     ws = workspace(nb, x.device)
@@ -330,13 +333,7 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, o
     check(lib.mmg_linear_wgrad(_p(dy), _p(x), _pro(pro), _p(out), _p(dbias), M, N, K, int(accumulate),
                                _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_linear_wgrad")
     _pe(_tok, "linear_wgrad", 4 * (M * N + M * K + N * K), 2 * M * N * K)
-    if with_bias:
-        if dbias is None:
-            dbias = col_reduce2(dy)[0].float()
-            if bias_out is not None and accumulate:
-                dbias = bias_out.add_(dbias)
-        return out, dbias
-    return out
+    return (out, dbias) if with_bias else out
 
 
 def col_reduce2(a: torch.Tensor, b: Optional[torch.Tensor] = None):
@@ -576,8 +573,9 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
 
 
 # ------------------------------------------------------------------------------------------ loss
-def pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae"):
-    """-> (loss fp64 scalar tensor, dpred [n]) in one pass (mmg_pair_loss)."""
+def pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae", inv_den_dev=None):
+    """-> (loss fp64 scalar tensor, dpred [n]) in one pass (mmg_pair_loss).  inv_den_dev: fp64 [1] device tensor that
+    overrides inv_den at run time (a captured step whose supervision subset changes size between replays)."""
     lib = _lib.load()
     n = pred.numel()
     dpred = torch.empty_like(pred)
@@ -585,7 +583,8 @@ def pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = 
     ws = workspace(lib.mmg_pair_loss_ws_bytes(n), pred.device)
     lt = {"mae": 0, "mse": 1}[loss_type]
     _tok = _pb("pair_loss")
-    check(lib.mmg_pair_loss(_p(pred), _p(y), _p(w), _p(sup), n, float(inv_den), lt, _p(dpred), _p(loss, torch.float64),
+    check(lib.mmg_pair_loss(_p(pred), _p(y), _p(w), _p(sup), n, float(inv_den), _p(inv_den_dev, torch.float64), lt,
+                            _p(dpred), _p(loss, torch.float64),
                             _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_pair_loss")
     _pe(_tok, "pair_loss", 20 * n)
     return loss, dpred
@@ -593,17 +592,17 @@ def pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = 
 
 class _PairLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, y, w, sup, inv_den, loss_type):
-        loss, dpred = pair_loss(pred.detach().contiguous(), y, w, sup, inv_den, loss_type)
+    def forward(ctx, pred, y, w, sup, inv_den, loss_type, inv_den_dev=None):
+        loss, dpred = pair_loss(pred.detach().contiguous(), y, w, sup, inv_den, loss_type, inv_den_dev)
         ctx.save_for_backward(dpred)
         return loss.float()
 
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return dpred * g, None, None, None, None, None
+        return dpred * g, None, None, None, None, None, None
 
 
-def weighted_pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae"):
+def weighted_pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae", inv_den_dev=None):
     """Differentiable fused loss: inv_den * sum sup*w*|pred-y| (or squared); w/sup are per-pair float vectors."""
-    return _PairLossFn.apply(pred, y, w, sup, inv_den, loss_type)
+    return _PairLossFn.apply(pred, y, w, sup, inv_den, loss_type, inv_den_dev)

@@ -63,6 +63,16 @@ class EdgeMasker:
         dev = self.edge_index.device
         return tuple(m.to(dev) for m in masks)
 
+    def to(self, data, device):
+        """Follow the graph to `device` (Trainer.__init__ moves it after the masker was built, train.py:605-622)."""
+        self.data = data
+        self.edge_index = data[self.edge_type].edge_index
+        self.edge_attr = data[self.edge_type].edge_attr
+        self.train_mask, self.val_mask, self.test_mask = (m.to(device) for m in (self.train_mask, self.val_mask,
+                                                                                self.test_mask))
+        self._cache = {}
+        return self
+
     def get_masked_data(self, split: str = "train"):
         if split == "train":
             mask = self.train_mask
@@ -95,6 +105,10 @@ class Trainer:
         self.model = model.to(device)
         self.data = data.to(device)
         self.masker = masker
+        # The reference builds the masker from the CPU graph BEFORE Trainer moves the graph (train.py:605-622):
+        # re-point it at the moved tensors, or its pairs / masks / lab weights would stay on the host.
+        if hasattr(masker, "to"):
+            masker.to(self.data, device)
         self.config = config
         self.device = device
         tc = config["train"]
@@ -231,6 +245,60 @@ class Trainer:
         logging.info(f"Loaded best model from epoch {ck['epoch']} (val_loss: {ck['val_loss']:.4f})")
 
 
+def _snapshot_training_state(model, optimizer):
+    """Copies of everything a training step mutates: parameters, BatchNorm buffers, optimizer state tensors."""
+    snap = {"model": {k: v.detach().clone() for k, v in model.state_dict().items()}, "opt": {}}
+    for p_, st in optimizer.state.items():
+        snap["opt"][p_] = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+    return snap
+
+
+def _restore_training_state(model, optimizer, snap):
+    """Undo the warm-up / capture steps IN PLACE (the captured graphs hold the addresses): recording a step must not
+    train the model.  Optimizer state that did not exist before (created lazily by the first step) is zeroed."""
+    with torch.no_grad():
+        cur = model.state_dict()
+        for k, v in snap["model"].items():
+            cur[k].copy_(v)
+        for p_, st in optimizer.state.items():
+            old = snap["opt"].get(p_)
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    if old is not None and torch.is_tensor(old.get(k)):
+                        v.copy_(old[k])
+                    else:
+                        v.zero_()
+                elif old is not None and k in old:
+                    st[k] = old[k]
+                elif isinstance(v, (int, float)):
+                    st[k] = type(v)(0)
+
+
+class _SupervisionState:
+    """Supervision subset of a captured step: the float mask and the normaliser 1 / n_sup both live on the device and
+    are updated in place, so a replay with a new per-epoch mask (train.py:150-176 of the reference) divides by the size
+    of THAT subset, exactly like the reference's .mean() over pred[mask] (train.py:366-386)."""
+
+    def __init__(self, sup_mask, comm, n_sup_global):
+        self.comm = comm
+        self.sup = sup_mask.to(torch.float32).contiguous()
+        self.inv_den = torch.ones(1, dtype=torch.float64, device=self.sup.device)
+        self._set_den(n_sup_global)
+
+    def _set_den(self, n_sup_global=None):
+        if n_sup_global is not None:
+            self.inv_den.fill_(1.0 / max(float(n_sup_global), 1.0))
+            return
+        n = self.sup.sum(dtype=torch.float64).reshape(1)
+        if self.comm is not None:
+            self.comm.raw_all_reduce(n)          # outside any capture: set_mask runs between replays
+        torch.reciprocal(n.clamp_(min=1.0), out=self.inv_den)
+
+    def set_mask(self, sup_mask, n_sup_global=None):
+        self.sup.copy_(sup_mask.to(torch.float32))
+        self._set_den(n_sup_global)
+
+
 class GraphedTrainStep:
     """One whole training step -- zero_grad, predict_lab_values, weighted loss, backward, optimizer.step --
     captured ONCE into a hipGraph and replayed per epoch (the eICU-scale graph is launch-bound: ~250 kernel
@@ -247,15 +315,17 @@ class GraphedTrainStep:
         dev = pi.device
         self.pi, self.li, self.y = pi, li, y
         self.wl = lab_weights[li].contiguous()
-        self.sup = sup_mask.to(torch.float32).contiguous()          # update in place: set_mask()
-        self._n_sup = float(self.sup.sum())                          # baked into the graph: see set_mask()
-        self.n_sup_global = n_sup_global
+        self._sv = _SupervisionState(sup_mask, None, n_sup_global)   # mask + 1/n_sup on the device: set_mask()
+        self.sup = self._sv.sup
         self.loss_fn = loss_fn
         if loss_fn not in ("mae", "mse"):
             raise ValueError(f"GraphedTrainStep supports 'mae'/'mse', got {loss_fn}")
         model._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss = torch.zeros((), device=dev)
         model.train()
+        if len(model.embeddings) == 0:
+            model._init_embeddings(data)
+        snap = _snapshot_training_state(model, optimizer)           # warm-up and capture run REAL steps: undone below
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -265,25 +335,22 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._body()
+        torch.cuda.synchronize()
+        _restore_training_state(model, optimizer, snap)
 
     def _body(self):
         from . import ops
         # every parameter, the (frozen, F5) embedding tables included: their .grad is then adopted, not accumulated
         self.model.zero_grad(set_to_none=True)
         pred = self.model.predict_lab_values(self.data, self.pi, self.li)
-        if self.n_sup_global is None:
-            inv_den = 1.0 / max(float(self._n_sup), 1.0)
-        else:
-            inv_den = 1.0 / float(self.n_sup_global)
-        loss = ops.weighted_pair_loss(pred, self.y, self.wl, self.sup, inv_den, self.loss_fn)
+        loss = ops.weighted_pair_loss(pred, self.y, self.wl, self.sup, 1.0, self.loss_fn, self._sv.inv_den)
         loss.backward()
         self.opt.step()
         self.loss.copy_(loss.detach())
 
-    def set_mask(self, sup_mask):
-        """New supervision subset.  The normaliser 1/n_sup is a graph constant: callers that change the COUNT must
-        pass n_sup_global at construction (or rebuild); the reference's Bernoulli(0.2) mask varies it by ~0.2 %."""
-        self.sup.copy_(sup_mask.to(torch.float32))
+    def set_mask(self, sup_mask, n_sup_global=None):
+        """New supervision subset; the normaliser 1 / n_sup follows it (device scalar read by the captured loss)."""
+        self._sv.set_mask(sup_mask, n_sup_global)
 
     def step(self) -> torch.Tensor:
         self.model._seed_dev.random_(0, 2 ** 62)     # fresh dropout masks for this replay
@@ -314,8 +381,8 @@ class PiecewiseGraphedTrainStep:
         self.model, self.plan, self.opt, self.comm = model, plan, optimizer, comm
         self.pi, self.li, self.y = pi, li, y
         self.wl = lab_weights[li].contiguous()
-        self.sup = sup_mask.to(torch.float32).contiguous()
-        self.inv_den = 1.0 / (float(n_sup_global) if n_sup_global is not None else max(float(self.sup.sum()), 1.0))
+        self._sv = _SupervisionState(sup_mask, comm, n_sup_global)
+        self.sup = self._sv.sup
         self.loss_fn = loss_fn
         self._ops, self._Run = ops, _Run
         dev = pi.device
@@ -325,6 +392,7 @@ class PiecewiseGraphedTrainStep:
         model.train()
         self.items = []
         self._cur = None
+        snap = _snapshot_training_state(model, optimizer)           # warm-up and capture run REAL steps: undone below
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -343,6 +411,7 @@ class PiecewiseGraphedTrainStep:
                 self._end()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _restore_training_state(model, optimizer, snap)
 
     # ---- recording
     def _begin(self):
@@ -373,7 +442,7 @@ class PiecewiseGraphedTrainStep:
             run.n_pairs = self.pi.numel()
             run.need_grad = True
             (pred,) = run.run_forward("predict")
-            loss, dpred = ops.pair_loss(pred, self.y, self.wl, self.sup, self.inv_den, self.loss_fn)
+            loss, dpred = ops.pair_loss(pred, self.y, self.wl, self.sup, 1.0, self.loss_fn, self._sv.inv_den)
             grads = run.run_backward((dpred,))
             for p, g in zip(self.params, grads):
                 if g is not None:
@@ -382,8 +451,9 @@ class PiecewiseGraphedTrainStep:
             self.loss.copy_(loss.float())
 
     # ---- replay
-    def set_mask(self, sup_mask):
-        self.sup.copy_(sup_mask.to(torch.float32))
+    def set_mask(self, sup_mask, n_sup_global=None):
+        """New supervision subset; 1 / n_sup (summed over the shards) follows it on the device."""
+        self._sv.set_mask(sup_mask, n_sup_global)
 
     def step(self) -> torch.Tensor:
         self.model._seed_dev.random_(0, 2 ** 62)

@@ -46,32 +46,24 @@ class ThreadComm:
             off += x.numel()
 
 
-@pytest.mark.parametrize("overlap", ["1", "2"])      # "2": vocab-side work on a side stream whatever the graph size
-@pytest.mark.parametrize("dropout", [0.0, 0.2])
-def test_two_virtual_shards_match_unsharded(dropout, overlap, monkeypatch):
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    monkeypatch.setenv("MMG_OVERLAP", overlap)
+def _virtual_shards_vs_unsharded(n, hidden, dropout, bounds=None, world=2, seed=778):
+    """Run the unsharded HIP model and `world` patient shards (host threads, thread-barrier all-reduce) on the same
+    inputs; compare predictions, gradients and Sync-BN buffers.  bounds: explicit shard boundaries (else nnz-balanced)."""
     import mmgnn  # noqa: F401
     from mmgnn import dist as md
     from mmgnn.data import build_plan
     from mmgnn.model import build_model
     dev = torch.device("cuda:0")
-    world = 2
-    g = fx.graph_from_frames(fx.det_frames(700, 20, 25, 18))
+    g = fx.graph_from_frames(fx.det_frames(*n))
     gv = om.GraphView(g)
-    sd = fx.det_state(gv.num_nodes, 128)
-    cfg = {"model": dict(CFG["model"], dropout=dropout)}
+    sd = fx.det_state(gv.num_nodes, hidden)
+    cfg = {"model": dict(CFG["model"], dropout=dropout, hidden_dim=hidden)}
     ei, ea = g["patient", "has_lab", "lab"].edge_index, g["patient", "has_lab", "lab"].edge_attr
     tr, _, _ = ot.edge_splits(ei.shape[1])
     pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
     w = ot.lab_weights(li, y, gv.num_nodes["lab"]).to(dev)
     sup = ot.supervision_mask(int(tr.sum()), 0.2, torch.Generator().manual_seed(5))
     n_sup = float(sup.sum())
-    # seed chosen so that no ReLU pre-activation of the 64x32 head layer sits within fp32 rounding of 0 for a
-    # supervised pair (seed 777 has one at 1e-7: its gradient flips with the summation order -- an inherent
-    # kink tie, not a sharding effect; the whole gradient is a sum over only ~1.3k supervised pairs)
-    seed = 778
 
     def loss_of(pred, sup_d, y_d, li_d):
         return ((pred[sup_d] - y_d[sup_d]).abs() * w[li_d[sup_d]]).sum() / n_sup
@@ -86,8 +78,9 @@ def test_two_virtual_shards_match_unsharded(dropout, overlap, monkeypatch):
     pred_ref = ref.predict_lab_values(gd, pi.to(dev), li.to(dev))
     loss_of(pred_ref, sup.to(dev), y.to(dev), li.to(dev)).backward()
 
-    # ---- two shards, two threads
-    b = md.partition_rows(md.patient_weights(g), world)
+    # ---- the shards, one host thread each
+    b = list(bounds) if bounds is not None else md.partition_rows(md.patient_weights(g), world)
+    world = len(b) - 1
     shared = {"slots": [None] * world, "bar": threading.Barrier(world)}
     out = [None] * world
     errs = []
@@ -117,7 +110,7 @@ def test_two_virtual_shards_match_unsharded(dropout, overlap, monkeypatch):
             grads = m._last_run.run_backward((dpred,))
             for (_, p_), g_ in zip(m.named_parameters(), grads):
                 p_.grad = g_
-            out[rank] = (m, pred.detach(), ids, lo, hi)
+            out[rank] = (m, pred.detach(), ids, lo, hi, comm.n_calls, int((plan.lab_deg < 6).sum()))
         except Exception:  # pragma: no cover
             import traceback
             errs.append(traceback.format_exc())
@@ -127,14 +120,15 @@ def test_two_virtual_shards_match_unsharded(dropout, overlap, monkeypatch):
     for t in ths:
         t.start()
     for t in ths:
-        t.join(timeout=120)
+        t.join(timeout=180)
     assert not errs, errs[0]
     torch.cuda.synchronize()
 
     pmax = float(pred_ref.detach().abs().max())
     gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    assert len({o[5] for o in out}) == 1, "every rank must issue the same number of collectives"
     for rank in range(world):
-        m, pred, ids, lo, hi = out[rank]
+        m, pred, ids, lo, hi = out[rank][:5]
         assert float((pred - pred_ref.detach()[ids.to(dev)]).abs().max()) <= 1e-4 * pmax
         for (k, p), (_, pr_) in zip(m.named_parameters(), ref.named_parameters()):
             gref = pr_.grad if pr_.grad is not None else torch.zeros_like(pr_)
@@ -148,6 +142,39 @@ def test_two_virtual_shards_match_unsharded(dropout, overlap, monkeypatch):
                 assert int(bf) == int(br), k
             else:
                 assert float((bf - br).abs().max()) <= 1e-4 * float(br.abs().max()), k
+    return out
+
+
+@pytest.mark.parametrize("overlap", ["1", "2"])      # "2": vocab-side work on a side stream whatever the graph size
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_two_virtual_shards_match_unsharded(dropout, overlap, monkeypatch):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    monkeypatch.setenv("MMG_OVERLAP", overlap)
+    # seed chosen so that no ReLU pre-activation of the 64x32 head layer sits within fp32 rounding of 0 for a
+    # supervised pair (seed 777 has one at 1e-7: its gradient flips with the summation order -- an inherent
+    # kink tie, not a sharding effect; the whole gradient is a sum over only ~1.3k supervised pairs)
+    _virtual_shards_vs_unsharded((700, 20, 25, 18), 128, dropout, seed=778)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_shard_without_low_degree_patient(dropout):
+    """A shard whose patients all have >= 6 labs (x1 over 8 GPUs leaves ~3 low-degree rows per shard: zero is likely)
+    must still issue every collective of the first encoder pass's backward and apply its BatchNorm backward with the
+    GLOBAL sums.  det_frames puts the low-degree patients at ids 5, 7, 60, 102, 113, ...: shard [8, 60) has none."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    out = _virtual_shards_vs_unsharded((700, 20, 25, 18), 128, dropout, bounds=[0, 8, 60, 700])
+    assert out[1][6] == 0 and out[0][6] > 0 and out[2][6] > 0
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_two_virtual_shards_256d_eicu_vocabulary(dropout):
+    """BASELINE config 4's shape class: the eICU vocabulary (50 / 114 / 100) at 256-d, patient-sharded -- the bit-plane
+    aggregates with two feature chunks and the K = 256 dense kernels, end to end."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _virtual_shards_vs_unsharded((1834, 50, 114, 100), 256, dropout)
 
 
 class SoloComm:
