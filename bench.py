@@ -2,19 +2,31 @@
 """Benchmark of the hot path: has_lab edges/s for one full training step
 (fwd + weighted-MAE loss + bwd + Adam) of ``predict_lab_values`` on a synthetic eICU-shape hetero-graph.
 
-    python bench.py --gpus N --steps K --warmup W [--scale S] [--dim D] [--strong]
+    python bench.py --gpus N --steps K --warmup W [--scale S] [--dim D] [--strong] [--no-strong-x1000]
 
 One process per GPU (N>1: launched by torch.distributed.run, RCCL).  Workload at N GPUs:
-  default (weak): every GPU holds an  x<scale>  eICU-shape shard (1,834*scale patients, 61,484*scale
-                  has_lab edges, 128-d) of ONE global graph of N shards; vocab nodes shared.
-                  N=1, scale=100 is BASELINE.json configs[2].
-  --strong      : ONE global x<scale> graph, patient-sharded over the N GPUs.
-Prints ONE JSON line (rank 0) with the whole-job rate, the roofline of the dominant kernel (HIP events
-on the launch stream: the start / stop events hipExtLaunchKernelGGL attaches to each launch of that
-kernel, read back through mmg_probe_*; an eager re-run of the same kernels when the timed region was a
-hipGraph replay) and a CPU baseline (the oracle restatement, timed on this host's cores, N=1 only).
+  headline (weak) : every GPU holds an  x<scale>  eICU-shape shard (1,834*scale patients, 61,484*scale
+                    has_lab edges, 128-d) of ONE global graph of N shards; vocab nodes shared.
+                    N=1, scale=100 is BASELINE.json configs[2].
+  --strong        : ONE global x<scale> graph, patient-sharded over the N GPUs (headline becomes the strong run).
+  strong_x1000    : in the same invocation, unless --no-strong-x1000: BASELINE.json's north-star split -- ONE x1000
+                    graph (1.83 M patients, 61.5 M has_lab edges), patient-sharded over the N GPUs, RCCL all-reduces
+                    on the shared vocab-side sums / gradients.  Reported as the "strong_x1000" object of the same JSON
+                    line, so the per-N lines of a 1/2/4/8 sweep give BOTH curves.
+Prints ONE JSON line (rank 0):
+  value / ms_per_step : the timed region (K steps, barrier + synchronize on both sides, max over ranks);
+  roofline            : the kernel family with the most kernel time per step.  Kernel durations are the HIP start /
+                        stop events that hipExtLaunchKernelGGL attaches to each launch (mmg_probe_*: the kernel's own
+                        begin / end timestamps on its stream -- never a pair of events bracketing a launch, which on a
+                        forked stream also measures the wait behind other kernels), taken in eager steps of the same
+                        kernels right after the timed region (graph replays cannot carry per-kernel events);
+  kernels             : the same figures for the kernels north_star grades -- the per-relation gather and scatter
+                        (scatter = matrix kernel + its fixed-order slab sum) -- and the other big kernel families;
+  cpu_baseline        : the oracle (CPU restatement of the reference) timed on this host's cores, N=1 only, on bounded
+                        samples of the same workload.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -32,13 +44,15 @@ from mmgnn.model import build_model  # noqa: E402
 from mmgnn.synth import make_graph  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
-MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA (the pair-head kernels)
+MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 # the dense layers and the aggregates compute fp32 products as exact bf16 pieces on the bf16 matrix cores: 6 matrix
 # FLOP per algorithmic fp32 FLOP (linear layers), 3 (0/1-indicator aggregates)
 MFMA_PEAK_BY_OP = {"linear_fwd": MFMA_BF16_PEAK_TF / 6, "linear_wgrad": MFMA_BF16_PEAK_TF / 6,
                    "gather_rows": MFMA_BF16_PEAK_TF / 3, "scatter_rows": MFMA_BF16_PEAK_TF / 3}
 LAB = ("patient", "has_lab", "lab")
+# kernels that belong to ONE op: the fixed-order slab sums are part of the scatter / weight-gradient they finish
+FOLLOWERS = {"scatter_reduce": "scatter_rows", "linear_wgrad_reduce": "linear_wgrad"}
 
 
 def parse():
@@ -50,10 +64,13 @@ def parse():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--strong", action="store_true")
+    ap.add_argument("--no-strong-x1000", action="store_true", help="skip the x1000 patient-sharded sub-record")
+    ap.add_argument("--strong-scale", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-scale", type=int, default=10)
-    ap.add_argument("--profile-ops", action="store_true", help="print the per-op time table to stderr")
+    ap.add_argument("--cpu-scale", type=int, default=10, help="largest CPU sample (x1 is always timed as well)")
+    ap.add_argument("--profile-ops", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replays")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel probe pass (profiler runs)")
     return ap.parse_args()
 
 
@@ -81,26 +98,26 @@ def setup_dist(args):
     return world, rank, torch.device("cuda", local)
 
 
-def build_workload(args, world, rank, dev):
+def build_workload(args, world, rank, dev, scale, strong):
     cfg = {"model": {"architecture": "RGCN", "hidden_dim": args.dim, "num_layers": 2, "dropout": args.dropout,
                      "use_batch_norm": True, "activation": "relu"}}
     comm = mdist.ShardComm() if world > 1 else None
-    if args.strong and world > 1:
-        g_all = make_graph(args.scale, seed=0, device=dev)
+    if strong and world > 1:
+        g_all = make_graph(scale, seed=0, device=dev)
         w = mdist.patient_weights(g_all)
         b = mdist.partition_rows(w, world)
         lo, hi = b[rank], b[rank + 1]
         g = mdist.shard_graph(g_all, lo, hi)
         n_global = int(g_all["patient"].num_nodes)
-        del g_all
+        del g_all, w
     else:
-        g = make_graph(args.scale, seed=1000 * rank, device=dev)     # this rank's shard of the global graph
+        g = make_graph(scale, seed=(0 if strong else 1000 * rank), device=dev)   # this rank's shard of the global graph
         P = int(g["patient"].num_nodes)
         lo, hi, n_global = rank * P, (rank + 1) * P, world * P
     torch.manual_seed(42)
     model = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
     model._init_embeddings(g)
-    plan = build_plan(g, dev)
+    plan = build_plan(g, dev, use_cache=False)
     if comm is not None:
         mdist.shard_plan(plan, comm, lo, n_global)
         mdist.shard_model(model, comm)
@@ -113,6 +130,7 @@ def build_workload(args, world, rank, dev):
     gen = torch.Generator(device=dev).manual_seed(42 + rank)
     perm = torch.randperm(E, generator=gen, device=dev)
     tr = perm[: int(0.7 * E)].sort().values
+    del perm
     pi, li = ei[0][tr].contiguous(), ei[1][tr].contiguous()
     y = g[LAB].edge_attr[tr].squeeze(-1).contiguous()
     sup = torch.rand(tr.numel(), generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev) < 0.2
@@ -124,8 +142,7 @@ def build_workload(args, world, rank, dev):
     if comm is not None:
         torch.distributed.all_reduce(n_sup_global)
     return dict(model=model, plan=plan, g=g, pi=pi, li=li, y=y, sup=sup, supf=sup.float(), wpair=wlab[li].contiguous(),
-                wlab=wlab, opt=opt, E=E,
-                n_sup=float(n_sup_global), comm=comm)
+                wlab=wlab, opt=opt, E=E, n_sup=float(n_sup_global), comm=comm)
 
 
 def train_step(w):
@@ -152,10 +169,19 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference) on a bounded sample of the same workload."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_sample(args, s, n_warm, n_timed, cores):
+    """The oracle's training step (fwd + weighted-MAE loss + bwd; no optimizer) on the x<s> eICU-shape graph."""
     from oracle import model as om, train as ot
-    s = max(1, min(args.cpu_scale, args.scale))
     g = make_graph(s, seed=0, device="cpu")
     gv = om.GraphView(g)
     sd = om.init_state(gv.num_nodes, gv.edge_types, args.dim, 2, seed=42)
@@ -165,185 +191,290 @@ def cpu_baseline(args):
     pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
     sup = torch.rand(tr.numel(), generator=torch.Generator().manual_seed(1234)) < 0.2
     wl = torch.ones(gv.num_nodes["lab"])
-    cores = host_cores()
     torch.set_num_threads(cores)
     times = []
-    n_steps = 4 if s <= 1 else 3
-    for i in range(n_steps):
+    for i in range(n_warm + n_timed):
         t0 = time.perf_counter()
         ot.train_step_grads(sd, gv, pi, li, y, wl, sup, p=args.dropout)
         times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": E / t, "unit": "has_lab edges/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (pure PyTorch CPU restatement) fwd+loss+bwd on the x{s} eICU-shape graph "
-                      f"({E} has_lab edges, {args.dim}-d, dropout {args.dropout}), median of {len(times) - 1} steps "
-                      f"after 1 warm-up, {cores} threads"}
+    t = sorted(times[n_warm:])[n_timed // 2]
+    return dict(scale=s, has_lab_edges=E, s_per_step=t, edges_per_s=E / t, warmup=n_warm, timed=n_timed)
 
 
-def main():
-    args = parse()
-    world, rank, dev = setup_dist(args)
-    w = build_workload(args, world, rank, dev)
+def cpu_baseline(args):
+    """the CPU restatement beside the GPU figure -- x1 (the reference's own CPU-runnable case,
+    2 warm-up + 5 timed steps) and a bounded sample of the x100 workload (x<cpu-scale>; the full x100 step takes ~1 min
+    and ~40 GB on 16 cores, so it is run explicitly with --cpu-scale 100 and recorded in profiles/)."""
+    cores = host_cores()
+    s_big = max(1, min(args.cpu_scale, args.scale))
+    x1 = cpu_sample(args, 1, 2, 5, cores)
+    big = cpu_sample(args, s_big, 1 if s_big > 1 else 2, 3 if s_big > 1 else 5, cores) if s_big > 1 else x1
+    return {"value": big["edges_per_s"], "unit": "has_lab edges/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model_name(),
+            "sample": f"oracle (pure PyTorch CPU restatement of the reference) fwd + weighted-MAE loss + bwd, no optimizer "
+                      f"step (the GPU step includes Adam), on the x{big['scale']} eICU-shape graph "
+                      f"({big['has_lab_edges']} has_lab edges, {args.dim}-d, dropout {args.dropout}): median of "
+                      f"{big['timed']} steps after {big['warmup']} warm-up, {cores} threads",
+            "x1": {"value": x1["edges_per_s"], "s_per_step": x1["s_per_step"], "has_lab_edges": x1["has_lab_edges"],
+                   "warmup": 2, "timed": 5},
+            "s_per_step": big["s_per_step"]}
+
+
+# ------------------------------------------------------------------------------------------------ kernel table
+def alg_of(tag, M, N, K, fl, extra):
+    """Algorithmic (compulsory) bytes and flops of one launch of a probed kernel family."""
+    if tag == "linear_fwd":
+        return 4 * (M * K + N * K + M * N * (2 if fl & 1 else 1)), 2 * M * N * K
+    if tag == "linear_wgrad":
+        return 4 * (M * N + M * K + N * K), 2 * M * N * K
+    if tag in ("gather_rows", "scatter_rows"):
+        # every index once, every distinct feature row once: 4 E + 4 (P + 1) per relation + the tables + the patient
+        # tensor (read and written when the gather accumulates); E comes from the workload (extra)
+        e = extra.get((tag, K, fl & (1 if tag == "gather_rows" else 8)), None)
+        return (e if e is not None else 0), 0
+    return 0, 0
+
+
+def kernel_table(rows, n_steps, extra):
+    """probe rows -> {family: {shape key: stats}}; followers (slab sums) are folded into the op they finish."""
+    groups = {}
+    for ms, tag, M, N, K, fl in rows:
+        g = groups.setdefault((tag, M, N, K, fl), [0, 0.0])
+        g[0] += 1
+        g[1] += ms
+    table = []
+    for (tag, M, N, K, fl), (cnt, tot) in groups.items():
+        b, f = alg_of(tag, M, N, K, fl, extra)
+        table.append(dict(kernel=tag, M=M, N=N, K=K, flags=fl, launches_per_step=cnt / n_steps, avg_ms=tot / cnt,
+                          ms_per_step=tot / n_steps, alg_bytes=b, alg_flops=f))
+    return table
+
+
+def op_summary(table, op, flags_mask=None, flags_val=None):
+    """The biggest launch shape of `op` (by kernel time), with its follower kernel's time added per launch."""
+    cand = [t for t in table if t["kernel"] == op and (flags_mask is None or (t["flags"] & flags_mask) == flags_val)]
+    if not cand:
+        return None
+    big = max(cand, key=lambda t: t["ms_per_step"])
+    out = dict(big)
+    fol = [t for t in table if FOLLOWERS.get(t["kernel"]) == op and t["M"] == big["M"] and t["N"] == big["N"]]
+    if fol:
+        # the follower serves every launch of the op with this (M, N): average per launch
+        n_op = sum(t["launches_per_step"] for t in cand if t["M"] == big["M"] and t["N"] == big["N"])
+        f_ms = sum(t["ms_per_step"] for t in fol) / max(n_op, 1e-9)
+        out["follower_avg_ms"] = f_ms
+        out["avg_ms_with_follower"] = big["avg_ms"] + f_ms
+    t_ms = out.get("avg_ms_with_follower", out["avg_ms"])
+    out["hbm_frac"] = (big["alg_bytes"] / (t_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if big["alg_bytes"] else None
+    mf = MFMA_PEAK_BY_OP.get(op)
+    out["mfma_frac"] = (big["alg_flops"] / (big["avg_ms"] * 1e-3) / 1e12) / mf if (mf and big["alg_flops"]) else None
+    return out
+
+
+def agg_extra(w, D):
+    """Algorithmic bytes of the fused aggregate launches of this workload (ops._agg_bytes: every index once, every distinct
+    feature row once, the patient tensor ONCE for the fused relations), keyed like the probe rows: (family, K, flags) with
+    K = total (gather) / total 32-padded (scatter) vocab rows of the fused relations; flags: 1 accumulate, 8 rowscale."""
+    plan = w["plan"]
+    P = plan.n_rows
+    extra = {}
+    rin = plan.rels_into_patient()
+
+    def rel_bytes(rels, rowscale, colscale):
+        return sum(4 * r.n_edges + 4 * (P + 1) + 4 * D * r.n_cols + (4 * P if rowscale else 0) +
+                   (4 * r.n_cols if colscale else 0) for r in rels)
+
+    if rin:
+        sets = [rin] + [[r] for r in rin]
+        for rels in sets:
+            kg, ks = sum(r.n_cols for r in rels), sum((r.n_cols + 31) // 32 * 32 for r in rels)
+            for acc in (0, 1):
+                extra[("gather_rows", kg, acc)] = rel_bytes(rels, True, False) + 4 * D * P * (2 if acc else 1)
+            extra[("scatter_rows", ks, 0)] = rel_bytes(rels, False, True) + 4 * D * P
+            extra[("scatter_rows", ks, 8)] = rel_bytes(rels, True, False) + 4 * D * P
+    return extra
+
+
+def load_traffic(args, scale, strong):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload (never guessed); attached to a
+    kernel only when its algorithmic bytes match the profiled launch shape."""
+    if scale != 100 or args.dim != 128 or strong:
+        return {}, None
+    for name in ("r2_traffic_x100.json", "r1_traffic_x100.json"):
+        path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(path):
+            try:
+                return json.load(open(path))["per_kernel"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2*FETCH+WRITE)"
+            except Exception:
+                pass
+    return {}, None
+
+
+def measure(args, world, rank, dev, scale, strong, steps, warmup, want_kernels):
+    w = build_workload(args, world, rank, dev, scale, strong)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # ---- one eager step, profiled per op, finds the dominant kernel (and warms every cache)
     train_step(w)                      # cold: code objects load, plans and pair lists are built
-    prof = ops.OpProfiler()
-    ops.set_profiler(prof)
     train_step(w)
-    table = prof.summary()
-    ops.set_profiler(None)
-    dominant = max(table.items(), key=lambda kv: kv[1]["ms"])[0]
-    if args.profile_ops and rank == 0:
-        tot = sum(v["ms"] for v in table.values())
-        for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
-            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
-            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
-            print(f"  {k:18s} calls {v['calls']:3d}  {v['ms']:9.3f} ms ({100 * v['ms'] / tot:5.1f}%)  "
-                  f"{gbs:8.1f} GB/s alg  {tf:6.2f} TFLOP/s", file=sys.stderr)
-
-    # ---- the whole step as ONE hipGraph (single GPU): launch overhead leaves the timed region
     gstep = None
-    if world == 1 and not args.no_graph:
-        try:
-            from mmgnn.train import PiecewiseGraphedTrainStep
-            gstep = PiecewiseGraphedTrainStep(w["model"], w["plan"], w["pi"], w["li"], w["y"], w["wlab"], w["opt"], w["sup"],
-                                              None, n_sup_global=w["n_sup"], warmup=2)
-        except Exception as e:   # capture is an optimisation, never a requirement
-            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            w["model"]._seed_dev = None
-            gstep = None
-    elif world > 1 and not args.no_graph:
-        # sharded: a chain of hipGraph segments with the all-reduces between them (nothing RCCL-specific is captured)
+    if not args.no_graph:
+        # one hipGraph on a single GPU; sharded: a chain of hipGraph segments with the all-reduces between them
         ok = torch.ones(1, device=dev)
         try:
             from mmgnn.train import PiecewiseGraphedTrainStep
-            gstep = PiecewiseGraphedTrainStep(w["model"], w["plan"], w["pi"], w["li"], w["y"], w["wlab"], w["opt"], w["sup"],
-                                              w["comm"], n_sup_global=w["n_sup"], warmup=1)
-        except Exception as e:
-            print(f"[bench] rank {rank}: piecewise capture unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+            gstep = PiecewiseGraphedTrainStep(w["model"], w["plan"], w["pi"], w["li"], w["y"], w["wlab"], w["opt"],
+                                              w["sup"], w["comm"], n_sup_global=w["n_sup"], warmup=2 if world == 1 else 1)
+        except Exception as e:   # capture is an optimisation, never a requirement
+            print(f"[bench] rank {rank}: hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches",
+                  file=sys.stderr)
             ok.zero_()
             gstep = None
-        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)     # all ranks or none
+        if world > 1:
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)     # all ranks or none
         if float(ok) == 0.0:
             w["model"]._seed_dev = None
             gstep = None
     step_fn = (lambda: gstep.step()) if gstep is not None else (lambda: train_step(w))
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         step_fn()
-    if os.environ.get("MMG_BENCH_DEBUG"):
-        torch.cuda.synchronize()
-        print("[debug] loss after warm-up", float(step_fn().detach()) if gstep is None else float(gstep.loss), file=sys.stderr)
 
     # ---- timed region: exactly K steps
-    prof = ops.OpProfiler(only=[dominant])
-    if gstep is None:
-        ops.set_profiler(prof)           # eager: the dominant op carries HIP events inside the timed region
-        ops.probe_arm(1 << 16)           # ... and its kernel launches their own start / stop events
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step_fn()
-        if os.environ.get("MMG_BENCH_DEBUG"):
-            torch.cuda.synchronize()
-            print("[debug] step loss", float(loss.detach()), "seed", int(w["model"]._seed_dev) if w["model"]._seed_dev is not None else None, file=sys.stderr)
     barrier()
     dt = time.perf_counter() - t0
-    ops.set_profiler(None)
     loss_value = float(loss.detach())
-    if gstep is not None:
-        # graph replays cannot carry per-kernel events: time the SAME kernels in K eager steps right after.  Each step is
-        # queued behind a ~10 ms spin on the device, so that the host (≈25 us of Python per launch) runs ahead and the
-        # kernels execute back to back: an event pair then brackets the kernel, not the host's gap before its launch.
+
+    # ---- per-kernel durations: eager steps of the same kernels, every big launch with its own HIP event pair.  Each
+    # step is queued behind a ~10 ms spin on the device, so that the host (~25 us of Python per launch) runs ahead and the
+    # kernels execute back to back, as they do inside the graph.
+    rows, n_probe = [], 0
+    if want_kernels:
         w["model"]._seed_dev = None
-        ops.set_profiler(prof)
+        n_probe = max(1, min(steps, 5))
         ops.probe_arm(1 << 16)
-        for _ in range(args.steps):
+        for _ in range(n_probe):
             torch.cuda._sleep(20_000_000)
             train_step(w)
         torch.cuda.synchronize()
-        ops.set_profiler(None)
-    probed = ops.probe_read()            # (ms, M, N, K, flags) per launch of the bf16-split dense forward
-    dom = prof.summary()[dominant]
+        rows = ops.probe_read()
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     edges = torch.tensor([float(w["E"])], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(edges)
-    dt = float(tmax)
-    total_edges = float(edges)
+    launch = ("eager" if gstep is None else "hipGraph replay" if world == 1 else
+              f"{sum(1 for k, _ in gstep.items if k == 'graph')} hipGraph segments + "
+              f"{sum(1 for k, _ in gstep.items if k == 'all_reduce')} all-reduces per step")
+    rec = dict(dt=float(tmax), edges=float(edges), loss=loss_value, rows=rows, n_probe=n_probe, launch=launch,
+               P_loc=int(w["plan"].n_rows), pairs=int(w["pi"].numel()), extra=agg_extra(w, args.dim))
+    del w, gstep, step_fn
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    args = parse()
+    world, rank, dev = setup_dist(args)
+    head = measure(args, world, rank, dev, args.scale, args.strong, args.steps, args.warmup, not args.no_kernels)
+    strong_rec = None
+    if not args.no_strong_x1000 and not (args.strong and args.scale == args.strong_scale):
+        s_steps = max(3, min(args.steps, 10))
+        strong_rec = measure(args, world, rank, dev, args.strong_scale, True, s_steps, min(args.warmup, 2), False)
+        strong_rec["steps"] = s_steps
 
     if rank == 0:
-        value = total_edges * args.steps / dt
-        # the dominant KERNEL = the launch shape of the dominant op that takes the most time (an op such as
-        # linear_fwd also serves the tiny vocab-side tables with a different kernel: those do not dilute the figure)
-        shape = max(dom["shapes"].values(), key=lambda d: d["ms"])
-        launches = shape["calls"]
-        avg_ms = bracket_ms = shape["ms"] / launches
-        bytes_per_launch = shape["bytes"]
-        flops_per_launch = shape["flops"]
-        timing = ("HIP events on the launch stream, eager re-run of the same kernels right after the graph-replay timed "
-                  "region" if gstep is not None else "HIP events on the launch stream inside the timed region")
-        if dominant == "linear_fwd" and probed:
-            # the same launches timed by the event pair that hipExtLaunchKernelGGL attaches to the kernel itself (its
-            # begin / end timestamps, what rocprofv3 reports); the bracketing event pair above also contains the two
-            # extra queue entries and the dispatch latency of the kernel
-            groups = {}
-            for ms_, M_, N_, K_, fl_ in probed:
-                b_ = 4 * (M_ * K_ + N_ * K_ + M_ * N_ * (2 if fl_ & 1 else 1))
-                g_ = groups.setdefault((b_, 2 * M_ * N_ * K_), [0, 0.0])
-                g_[0] += 1
-                g_[1] += ms_
-            key = (bytes_per_launch, flops_per_launch)
-            if key in groups:
-                launches, avg_ms = groups[key][0], groups[key][1] / groups[key][0]
-                timing = "HIP start/stop events attached to each kernel launch (hipExtLaunchKernelGGL) on its stream, " + \
-                         ("eager re-run of the same kernels right after the graph-replay timed region"
-                          if gstep is not None else "inside the timed region")
-        mfma_peak = MFMA_PEAK_BY_OP.get(dominant, MFMA_F32_PEAK_TF)
-        hbm_frac = (bytes_per_launch / (avg_ms * 1e-3) / 1e9) / HBM_PEAK_GBS
-        mfma_frac = (flops_per_launch / (avg_ms * 1e-3) / 1e12) / mfma_peak
-        if mfma_frac > hbm_frac:
-            roof = {"bound": "mfma", "achieved": flops_per_launch / (avg_ms * 1e-3) / 1e12, "peak": mfma_peak,
-                    "unit": "TFLOP/s", "frac": mfma_frac, "traffic": None}
-        else:
-            roof = {"bound": "hbm", "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": hbm_frac, "traffic": None}
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this exact workload (never guessed)
-        try:
-            if args.scale == 100 and args.dim == 128 and not args.strong:
-                tr_ = json.load(open(os.path.join(REPO, "profiles", "r1_traffic_x100.json")))
-                roof["traffic"] = tr_["per_kernel"][dominant]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r1_traffic_x100.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
-        except Exception:
-            roof["traffic"] = None
-        roof.update({"kernel": dominant, "op_ms_per_step": dom["ms"] / max(args.steps, 1),
-                     "avg_launch_ms": avg_ms, "launches_timed": launches, "timing": timing,
-                     "avg_launch_ms_bracketing_events": bracket_ms,
-                     "algorithmic_bytes_per_launch": bytes_per_launch, "algorithmic_flops_per_launch": flops_per_launch})
-        P_loc = int(w["plan"].n_rows)
+        dt, total_edges = head["dt"], head["edges"]
+        ms_per_step = 1e3 * dt / args.steps
         out = {
             "metric": "has_lab edges/s, one full training step (fwd + weighted-MAE loss + bwd + Adam) of "
                       "predict_lab_values on the full hetero-graph",
-            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "value": total_edges * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"eICU-shape synthetic hetero-graph x{args.scale}"
                                     + (" total, patient-sharded" if args.strong else " per GPU")
                                     + f", {args.dim}-d, 2 SAGE layers x 6 relations, dropout {args.dropout}"),
-                       "patients_per_gpu": P_loc, "has_lab_edges_total": int(total_edges),
-                       "train_pairs_rank0": int(w["pi"].numel()), "hidden_dim": args.dim,
+                       "patients_per_gpu": head["P_loc"], "has_lab_edges_total": int(total_edges),
+                       "train_pairs_rank0": head["pairs"], "hidden_dim": args.dim,
                        "parallelism": f"patient-shard x{world}" if world > 1 else "single GPU",
-                       "launch": ("eager" if gstep is None else "hipGraph replay" if world == 1 else
-                                  f"{sum(1 for k, _ in gstep.items if k == 'graph')} hipGraph segments + "
-                                  f"{sum(1 for k, _ in gstep.items if k == 'all_reduce')} all-reduces per step")},
-            "roofline": roof,
-            "loss": loss_value,
+                       "launch": head["launch"]},
+            "loss": head["loss"],
         }
+        if head["rows"]:
+            table = kernel_table(head["rows"], head["n_probe"], head["extra"])
+            traffic, tsrc = load_traffic(args, args.scale, args.strong)
+            fam = {}
+            for t in table:
+                fam[FOLLOWERS.get(t["kernel"], t["kernel"])] = fam.get(FOLLOWERS.get(t["kernel"], t["kernel"]), 0.0) + t["ms_per_step"]
+            dominant = max(fam.items(), key=lambda kv: kv[1])[0]
+            if args.profile_ops:
+                for t in sorted(table, key=lambda t: -t["ms_per_step"]):
+                    print(f"  {t['kernel']:20s} M={t['M']:8d} N={t['N']:4d} K={t['K']:4d} fl={t['flags']:2d} "
+                          f"x{t['launches_per_step']:5.1f}/step  {1e3 * t['avg_ms']:8.1f} us  {t['ms_per_step']:7.3f} ms/step",
+                          file=sys.stderr)
+            d = op_summary(table, dominant)
+            t_ms = d.get("avg_ms_with_follower", d["avg_ms"])
+            hbm_frac = d["hbm_frac"] or 0.0
+            mfma_frac = d["mfma_frac"] or 0.0
+            if mfma_frac > hbm_frac:
+                roof = {"bound": "mfma", "achieved": d["alg_flops"] / (d["avg_ms"] * 1e-3) / 1e12,
+                        "peak": MFMA_PEAK_BY_OP[dominant], "unit": "TFLOP/s", "frac": mfma_frac, "traffic": None}
+            else:
+                roof = {"bound": "hbm", "achieved": d["alg_bytes"] / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": hbm_frac, "traffic": None}
+            tr = traffic.get(dominant)
+            if tr and d["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / d["alg_bytes"] < 2.0:
+                roof["traffic"] = tr["hbm_bytes_per_launch"]
+                roof["traffic_source"] = tsrc
+            roof.update({"kernel": dominant, "shape": [d["M"], d["N"], d["K"]], "flags": d["flags"],
+                         "op_ms_per_step": fam[dominant], "avg_launch_ms": t_ms,
+                         "launches_per_step": d["launches_per_step"],
+                         "algorithmic_bytes_per_launch": d["alg_bytes"], "algorithmic_flops_per_launch": d["alg_flops"],
+                         "timing": "HIP start/stop events attached to each kernel launch (hipExtLaunchKernelGGL) on its "
+                                   f"own stream, {head['n_probe']} eager steps of the same kernels right after the timed "
+                                   "region; slab-sum kernels are added to the op they finish"})
+            # self-checks: a kernel cannot take longer than the step that contains it, and a roofline fraction is in (0, 1]
+            assert roof["op_ms_per_step"] <= ms_per_step, (roof, ms_per_step)
+            assert 0.0 < roof["frac"] <= 1.0, roof
+            out["roofline"] = roof
+            ks = {}
+            for name, op, fm, fv in (("gather", "gather_rows", None, None), ("scatter", "scatter_rows", 8, 0),
+                                     ("scatter_rowscale", "scatter_rows", 8, 8), ("linear_fwd", "linear_fwd", None, None),
+                                     ("linear_wgrad", "linear_wgrad", None, None), ("pair_head_fwd", "pair_head_fwd", None, None),
+                                     ("pair_head_bwd", "pair_head_bwd", None, None)):
+                s_ = op_summary(table, op, fm, fv)
+                if s_ is None:
+                    continue
+                e = {"avg_launch_us": 1e3 * s_.get("avg_ms_with_follower", s_["avg_ms"]),
+                     "launches_per_step": s_["launches_per_step"], "ms_per_step": fam.get(op) if fm is None else s_["ms_per_step"],
+                     "shape": [s_["M"], s_["N"], s_["K"]]}
+                if "follower_avg_ms" in s_:
+                    e["slab_sum_us"] = 1e3 * s_["follower_avg_ms"]
+                if s_["alg_bytes"]:
+                    e["algorithmic_bytes"] = s_["alg_bytes"]
+                    e["hbm_frac"] = s_["hbm_frac"]
+                    assert 0.0 < e["hbm_frac"] <= 1.0, (name, e)
+                tr = traffic.get(op)
+                if tr and s_["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / s_["alg_bytes"] < 2.0:
+                    e["traffic"] = tr["hbm_bytes_per_launch"]
+                ks[name] = e
+            out["kernels"] = ks
+            out["kernel_ms_per_step_all_probed"] = sum(fam.values())
+        if strong_rec is not None:
+            out["strong_x1000"] = {
+                "value": strong_rec["edges"] * strong_rec["steps"] / strong_rec["dt"], "unit": "edges/s",
+                "ms_per_step": 1e3 * strong_rec["dt"] / strong_rec["steps"], "steps": strong_rec["steps"],
+                "scaling": "strong", "n_gpus": world, "patients_per_gpu": strong_rec["P_loc"],
+                "has_lab_edges_total": int(strong_rec["edges"]), "launch": strong_rec["launch"],
+                "workload": f"ONE eICU-shape x{args.strong_scale} graph, patient-sharded over {world} GPU(s), {args.dim}-d"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))

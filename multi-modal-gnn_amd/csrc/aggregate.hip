@@ -1,14 +1,17 @@
 // Sparse aggregates over CSR-by-patient (replace PyG SAGEConv's gather + scatter-mean and their
-// backward; call site src/model.py:125-131,256 of the reference).  HBM-bound byte work: no MFMA.
+// backward; call site src/model.py:125-131,256 of the reference).
 //
-//  gather : one wave per patient row, lane owns D/64 contiguous floats (a 64-lane row read is one
-//           coalesced 256..1024-B segment); the source tables are the tiny vocab tables (L2-resident).
-//  scatter: patient-major streaming; every workgroup owns a contiguous row chunk and multiplies the
-//           32-row indicator tile (built in LDS from the CSR) with the feature tile on the fp32 matrix
-//           cores, keeping the [V, D] accumulators in registers; ONE partial slab per workgroup, summed
-//           by a second kernel in fixed order (bitwise reproducible).
+//  Simple relations (no repeated (patient, item) pair -- the reference's frames are de-duplicated) have a 0/1
+//  indicator, exact in bf16, and an fp32 feature is the exact sum of three bf16 pieces: Ind . x is three
+//  v_mfma_f32_32x32x16_bf16 with EXACT products and fp32 accumulation.  The adjacency is kept as bit planes
+//  (mmg_rel_mask_build) and expanded into operand fragments in the kernel -- no rowptr -> col chase in the loop.
+//    k_gather_bits  : vocab -> patient (forward; backward of the scatter), item tables split once per workgroup
+//    k_scatter_bits : patient -> vocab (forward; backward of the gather), patient-major streaming of x, all item
+//                     tiles' accumulators in registers, one partial slab per workgroup summed in fixed order
+//  Multigraphs / vocabularies without a bit-plane instance: k_gather_lds (tables resident in LDS, one wave per
+//  patient row), k_gather (L2-served), k_scatter_mfma (fp32 matrix cores on an integer count tile),
+//  k_scatter_atomic (> 512 padded vocab rows).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -193,218 +196,7 @@ __global__ __launch_bounds__(GL_THREADS) void k_gather_lds(RelPack rp, int64_t n
   }
 }
 
-// ------------------------------------------------------------------------------ gather on bf16 matrix cores
-// For simple graphs (MMG_REL_SIMPLE) the per-row indicator is 0/1, which bf16 holds exactly, and an fp32
-// table value splits exactly into three bf16 pieces (hi + mid + lo, 8 significant bits each).  So
-//     out[i, :] = sum_r rs_r[i] * sum_v Ind_r[i, v] * T'_r[v, :]        (T' = colscale * T)
-// is three v_mfma_f32_32x32x16_bf16 per 16 vocab columns with EXACT products and fp32 accumulation: the
-// fp32 result up to summation order, at 16x the fp32 matrix rate.  The three split tables stay in LDS for
-// the whole workgroup ([piece][d][v], v contiguous = the B-fragment order), the 32-row indicator tile is
-// rebuilt per stage ([row][v]); one accumulator per relation keeps the per-relation mean scaling exact.
-// Column ids of the next stage and row bounds of the stage after are prefetched into registers.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float gf32x16 __attribute__((ext_vector_type(16)));
-constexpr int GB_ROWS = 32, GB_PF = 8;
-
-__device__ inline void split3(float v, __bf16& a, __bf16& b, __bf16& c) {
-  a = (__bf16)v;
-  const float r1 = v - (float)a;
-  b = (__bf16)r1;
-  c = (__bf16)(r1 - (float)b);
-}
-
-// v2 layout: every wave owns one 32-column slice of the output and keeps ITS slice of the three split tables
-// in registers for the whole kernel (NKS k16-steps x 3 pieces x 4 VGPRs), so LDS only carries the
-// double-buffered 32-row indicator tile: one workgroup barrier per stage, no cross-wave reduction, and the
-// column ids are read once for the full feature width.
-template <int NKS, int NDT>      // NKS: padded vocab columns / 16;  NDT: D / 32 = waves per workgroup
-__global__ __launch_bounds__(NDT * 64) void k_gather_bf16(RelPack rp, int64_t n_rows, int64_t rows_per_blk, int D,
-                                                          float* __restrict__ out, int accumulate, int dbg) {
-  constexpr int VP = NKS * 16, LDV = VP + 8, NT = NDT * 64;
-  __shared__ __attribute__((aligned(16))) __bf16 CT[2][GB_ROWS * LDV];
-  __shared__ float RS[2][MMG_MAX_REL * GB_ROWS];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int dcol = blockIdx.y * (NDT * 32) + wid * 32 + l31; // this lane's output column
-
-  // ---- table fragments: tb[ks][p] = piece p of T'[v = 16ks + 8h + j][dcol], j = 0..7
-  bf16x8 tb[NKS][3];
-  int kend[MMG_MAX_REL];                                     // first k-step AFTER each relation
-#pragma unroll
-  for (int r = 0; r < MMG_MAX_REL; ++r) kend[r] = r < rp.n ? (rp.r[r].acc_off + ((rp.r[r].n_cols + 15) & ~15)) / 16 : NKS + 1;
-  {
-    // staged through LDS in chunks of 2 k-steps (32 vocab rows x this workgroup's columns, fp32, coalesced
-    // loads all in flight); the indicator buffers are not live yet, so their space is reused
-    constexpr int DCOLS = NDT * 32;
-    float* stage = reinterpret_cast<float*>(&CT[0][0]);
-    static_assert(sizeof(CT) >= 32 * DCOLS * 4, "staging chunk must fit the indicator buffers");
-    const int dbase = blockIdx.y * DCOLS;
-#pragma unroll
-    for (int ch = 0; ch < (NKS + 1) / 2; ++ch) {
-      __syncthreads();
-      for (int i = tid; i < 32 * (DCOLS / 4); i += NT) {
-        const int vr = i / (DCOLS / 4), c4 = i - vr * (DCOLS / 4);
-        const int v = ch * 32 + vr;
-        mmg_f4 val = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < rp.n; ++r) {
-          const int c = v - rp.r[r].acc_off;
-          if (c >= 0 && c < rp.r[r].n_cols) {
-            val = *reinterpret_cast<const mmg_f4*>(rp.r[r].table + (size_t)c * D + dbase + c4 * 4);
-            if (rp.r[r].colscale) val *= rp.r[r].colscale[c];
-          }
-        }
-        *reinterpret_cast<mmg_f4*>(stage + vr * DCOLS + c4 * 4) = val;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ks = ch * 2 + kk;
-        if (ks < NKS) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float val = stage[(kk * 16 + 8 * h + j) * DCOLS + wid * 32 + l31];
-            __bf16 a, b, c3;
-            split3(val, a, b, c3);
-            tb[ks][0][j] = a; tb[ks][1][j] = b; tb[ks][2][j] = c3;
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  const int64_t r_beg = (int64_t)blockIdx.x * rows_per_blk, r_end = min(n_rows, r_beg + rows_per_blk);
-  // indicator rows are built by fixed 8-lane groups (same wave: zero-fill then ones need no workgroup barrier)
-  constexpr int BUILD_T = NT < 256 ? NT : 256;               // threads that build indicator rows
-  constexpr int ROWS_PER_PASS = BUILD_T / 8;                 // rows covered by the workgroup in one pass
-  constexpr int NPASS = GB_ROWS / ROWS_PER_PASS;
-  const bool builder = tid < BUILD_T;
-  const int mrow = tid >> 3, q = tid & 7;
-  int cb[NPASS][MMG_MAX_REL], ce[NPASS][MMG_MAX_REL], nb[NPASS][MMG_MAX_REL], ne[NPASS][MMG_MAX_REL];
-  int cc[NPASS][MMG_MAX_REL][GB_PF];
-  auto bounds = [&](int64_t row0, int (*bb)[MMG_MAX_REL], int (*ee)[MMG_MAX_REL]) {
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int64_t row = row0 + ps * ROWS_PER_PASS + mrow;
-#pragma unroll
-      for (int r = 0; r < MMG_MAX_REL; ++r) {
-        bb[ps][r] = 0; ee[ps][r] = 0;
-        if (builder && r < rp.n && row < r_end) { bb[ps][r] = rp.r[r].rowptr[row]; ee[ps][r] = rp.r[r].rowptr[row + 1]; }
-      }
-    }
-  };
-  auto fetch_cols = [&](int (*bb)[MMG_MAX_REL], int (*ee)[MMG_MAX_REL], int (*dst)[MMG_MAX_REL][GB_PF]) {
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-      for (int r = 0; r < MMG_MAX_REL; ++r)
-#pragma unroll
-        for (int i = 0; i < GB_PF; ++i) {
-          const int k = bb[ps][r] + q + 8 * i;
-          dst[ps][r][i] = (r < rp.n && k < ee[ps][r]) ? rp.r[r].col[k] : -1;
-        }
-  };
-  auto build = [&](int buf, int64_t row0, int (*bb)[MMG_MAX_REL], int (*ee)[MMG_MAX_REL], int (*cols)[MMG_MAX_REL][GB_PF]) {
-    if (!builder) return;
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int m = ps * ROWS_PER_PASS + mrow;
-      __bf16* rowp = &CT[buf][m * LDV];
-      const mmg_f4 z = {0.f, 0.f, 0.f, 0.f};
-      for (int i = q; i < LDV / 8; i += 8) reinterpret_cast<mmg_f4*>(rowp)[i] = z;
-      unsigned short* c16 = reinterpret_cast<unsigned short*>(rowp);
-#pragma unroll
-      for (int r = 0; r < MMG_MAX_REL; ++r) {
-        if (r >= rp.n) continue;
-        const int off = rp.r[r].acc_off;
-#pragma unroll
-        for (int i = 0; i < GB_PF; ++i)
-          if (cols[ps][r][i] >= 0) c16[off + cols[ps][r][i]] = 0x3F80;           // bf16 1.0
-        for (int k = bb[ps][r] + q + 8 * GB_PF; k < ee[ps][r]; k += 8) c16[off + rp.r[r].col[k]] = 0x3F80;
-        if (q == 0) {
-          const int64_t row = row0 + m;
-          RS[buf][r * GB_ROWS + m] = (rp.r[r].rowscale && row < r_end) ? rp.r[r].rowscale[row] : 1.f;
-        }
-      }
-    }
-  };
-  if (r_beg >= r_end) return;
-  bounds(r_beg, cb, ce);
-  fetch_cols(cb, ce, cc);
-  bounds(r_beg + GB_ROWS, nb, ne);
-  build(0, r_beg, cb, ce, cc);
-  __syncthreads();
-
-  int buf = 0;
-  for (int64_t r0 = r_beg; r0 < r_end; r0 += GB_ROWS, buf ^= 1) {
-    // ---- prefetch: columns of the next stage, bounds of the one after, old output values of this one
-    int tc[NPASS][MMG_MAX_REL][GB_PF], tb2[NPASS][MMG_MAX_REL], te2[NPASS][MMG_MAX_REL];
-    if (!(dbg & 8)) { fetch_cols(nb, ne, tc); bounds(r0 + 2 * GB_ROWS, tb2, te2); }
-    else {
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-        for (int r = 0; r < MMG_MAX_REL; ++r) { tb2[ps][r] = 0; te2[ps][r] = 0;
-#pragma unroll
-          for (int i = 0; i < GB_PF; ++i) tc[ps][r][i] = -1; }
-    }
-    float prev[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int64_t gr = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      prev[i] = (accumulate && gr < r_end && !(dbg & 4)) ? out[(size_t)gr * D + dcol] : 0.f;
-    }
-    // ---- matrix products of this stage; the per-relation accumulator is folded at relation boundaries
-    gf32x16 acc;
-    float tot[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; tot[i] = 0.f; }
-    int rcur = 0;
-    if (!(dbg & 1))
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&CT[buf][l31 * LDV + 16 * ks + 8 * h]);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, tb[ks][p], acc, 0, 0, 0);
-      if (ks + 1 == kend[rcur] || ks + 1 == NKS) {          // wave-uniform: end of a relation's columns
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-          tot[i] = fmaf(RS[buf][rcur * GB_ROWS + row], acc[i], tot[i]);
-          acc[i] = 0.f;
-        }
-        rcur = min(rcur + 1, MMG_MAX_REL - 1);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int64_t gr = r0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (gr < r_end && (!(dbg & 4) || i == 0)) out[(size_t)gr * D + dcol] = prev[i] + tot[i];
-    }
-    // ---- build the next stage's indicator tile in the other buffer (its columns arrived during the MFMAs)
-    if (r0 + GB_ROWS < r_end && !(dbg & 2)) build(buf ^ 1, r0 + GB_ROWS, nb, ne, tc);
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-      for (int r = 0; r < MMG_MAX_REL; ++r) { nb[ps][r] = tb2[ps][r]; ne[ps][r] = te2[ps][r]; }
-    __syncthreads();                                         // tile s+1 complete, tile s free
-  }
-}
-
-template <int NKS>
-void launch_gather_bf16(const RelPack& rb, int64_t n_rows, int D, float* out, int accumulate, hipStream_t st) {
-  const char* de = getenv("MMG_GB_DBG");
-  const int dbg = de ? atoi(de) : 0;
-  int64_t nblk = D > 128 ? 128 : 256;
-  const int64_t max_blk = (n_rows + 2 * GB_ROWS - 1) / (2 * GB_ROWS);
-  if (nblk > max_blk) nblk = max_blk;
-  int64_t rows_per_blk = (n_rows + nblk - 1) / nblk;
-  rows_per_blk = (rows_per_blk + GB_ROWS - 1) / GB_ROWS * GB_ROWS;
-  nblk = (n_rows + rows_per_blk - 1) / rows_per_blk;
-  if (D == 64) hipLaunchKernelGGL((k_gather_bf16<NKS, 2>), dim3((unsigned)nblk), dim3(128), 0, st, rb, n_rows, rows_per_blk, D, out, accumulate, dbg);
-  else hipLaunchKernelGGL((k_gather_bf16<NKS, 4>), dim3((unsigned)nblk, (unsigned)(D / 128)), dim3(256), 0, st, rb, n_rows, rows_per_blk, D, out, accumulate, dbg);
-}
-
 
 // ------------------------------------------------------------------------------ scatter
 // out[v, :] = sum_rows Ind[row, v] * x[row, :]  is a tall-skinny product  Ind^T [V x P] . x [P x D].
@@ -418,7 +210,6 @@ void launch_gather_bf16(const RelPack& rb, int64_t n_rows, int D, float* out, in
 // the whole chunk), writes one partial slab; k_scatter_reduce sums the slabs in fixed order.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int SC_ROWS = 32;     // patient rows per LDS stage (= MFMA K extent per stage)
-constexpr int SC_MAX_NT = 16;   // 32-row vocab tiles per launch (512 padded vocab rows)
 
 struct ScatterPlan {
   int nt;              // padded vocab tiles (template instance)
@@ -455,11 +246,10 @@ ScatterPlan plan_scatter(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D
   p.n_split = (int)((n_rows + rps - 1) / rps);
   if (p.n_split < 1) p.n_split = 1;
   // bf16-split kernel: one 512-thread workgroup per CU, stages of SB_SR rows dealt out evenly
-  static const int no_bf16 = [] { const char* e = getenv("MMG_SCATTER_FP32"); return e ? atoi(e) : 0; }();
   bool simple = true;
   for (int r = 0; r < n_rel; ++r)
     simple &= ((rels[r].flags & MMG_REL_SIMPLE) != 0 && rels[r].mask_t != nullptr) || rels[r].n_cols == 0;
-  p.bf16 = p.ok && simple && !no_bf16 && p.nt <= 10 && n_rows >= 64;
+  p.bf16 = p.ok && simple && p.nt <= 10 && n_rows >= 64;
   bool has_rs = false;
   for (int r = 0; r < n_rel; ++r) has_rs |= rels[r].rowscale != nullptr;
   if (p.bf16 && has_rs) {
@@ -747,6 +537,16 @@ __global__ __launch_bounds__(256) void k_scatter_bits(RelPack rp, int64_t n_rows
       for (int t = 0; t < NTW; ++t) afc[t] = afn[t];
 #pragma unroll
       for (int r = 0; r < NREL; ++r) { bc[r][0] = bn[r][0]; bc[r][1] = bn[r][1]; bc[r][2] = bn[r][2]; }
+#ifdef MMG_SCATTER_SGB
+      // one wave per SIMD: the vector work of the NEXT k-step's operands must issue BETWEEN this k-step's matrix
+      // instructions (a clump of 30 MFMAs followed by a clump of VALU work leaves the matrix pipe idle for the clump)
+#pragma unroll
+      for (int i = 0; i < 3 * NTW; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, RS ? 7 : 3, 0);               // a slice of the split / scale work
+        if (i < NTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one LUT read
+      }
+#endif
       if ((ks & 3) == 3) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) mc[t] = mn[t];
@@ -780,11 +580,11 @@ void launch_scatter_bits(const ScatterPlan& p, const RelPack& rp, int64_t n_rows
   for (int r = 0; r < rp.n; ++r) has_rs |= rp.r[r].rowscale != nullptr;
   const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
   if (has_rs) {                                      // plan_scatter only picks this kernel for a static layout
-    if (NT == 10) hipLaunchKernelGGL((k_scatter_bits<10, 4, 1, 2, 6>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
+    if (NT == 10) MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 8, (k_scatter_bits<10, 4, 1, 2, 6>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
   } else if (p.dc == 128) {
-    hipLaunchKernelGGL((k_scatter_bits<NT, 4, 0, 0, 0>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
+    MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 0, (k_scatter_bits<NT, 4, 0, 0, 0>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
   } else {
-    hipLaunchKernelGGL((k_scatter_bits<NT, 2, 0, 0, 0>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
+    MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 0, (k_scatter_bits<NT, 2, 0, 0, 0>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
   }
 }
 
@@ -1052,11 +852,11 @@ void launch_scatter_mfma(const ScatterPlan& p, const RelPack& rp, int64_t n_rows
   bool has_rs = false;
   for (int r = 0; r < rp.n; ++r) has_rs |= rp.r[r].rowscale != nullptr;
   if (p.dc == 128) {
-    if (has_rs) hipLaunchKernelGGL((k_scatter_mfma<NT, 4, true>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
-    else hipLaunchKernelGGL((k_scatter_mfma<NT, 4, false>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
+    if (has_rs) MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 8 | 16, (k_scatter_mfma<NT, 4, true>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
+    else MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 16, (k_scatter_mfma<NT, 4, false>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
   } else {
-    if (has_rs) hipLaunchKernelGGL((k_scatter_mfma<NT, 2, true>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
-    else hipLaunchKernelGGL((k_scatter_mfma<NT, 2, false>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
+    if (has_rs) MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 8 | 16, (k_scatter_mfma<NT, 2, true>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
+    else MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 16, (k_scatter_mfma<NT, 2, false>), grid, dim3(256), 0, st, rp, n_rows, p.rows_per_split, D, x, slab);
   }
 }
 
@@ -1138,31 +938,10 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
   hipStream_t st = (hipStream_t)stream;
   int total_cols = 0;
   for (int r = 0; r < n_rel; ++r) total_cols += rels[r].n_cols;
-  // bf16-split matrix-core path: simple relations whose padded vocab fits the register-resident table slices
-  {
-    bool simple = true;
-    int vp = 0;
-    for (int r = 0; r < n_rel; ++r) { simple &= (rels[r].flags & MMG_REL_SIMPLE) != 0; vp += (rels[r].n_cols + 15) & ~15; }
-    // Opt-in (MMG_AGG_BF16=1).  Measured on MI355X at x100 / D=128: 200-208 us per launch vs 159-167 us for the
-    // LDS-table kernel below.  Ablation (MMG_GB_DBG bits): skeleton + table setup 50 us, matrix phase 42 us
-    // (one dependent accumulator chain), indicator build 38 us, output read-modify-write 40 us, index prefetch
-    // 30 us -- and at one wave per SIMD (the register-resident table slices need ~500 VGPRs) the phases ADD
-    // instead of overlapping.  Next: split MFMA / loader wave roles and two accumulators.
-    static const int use_bf16 = [] { const char* e = getenv("MMG_AGG_BF16"); return e ? atoi(e) : 0; }();
-    if (use_bf16 && simple && vp > 0 && vp <= 20 * 16 && n_rows >= 256) {
-      RelPack rb = rp;
-      int off = 0;
-      for (int r = 0; r < n_rel; ++r) { rb.r[r].acc_off = off; off += (rels[r].n_cols + 15) & ~15; }
-      if (vp <= 12 * 16) launch_gather_bf16<12>(rb, n_rows, D, out, accumulate, st);
-      else launch_gather_bf16<20>(rb, n_rows, D, out, accumulate, st);
-      MMG_GATHER_TAIL("gather_rows(bf16)");
-    }
-  }
   // bit-plane matrix-core kernel: simple relations in a layout with a static instance -- the eICU vocabulary
   // (64 | 128 | 128 padded items) or its first relation alone (the last layer's backward only reaches the labs)
   {
-    static const int no_bits = [] { const char* e = getenv("MMG_GATHER_LDS"); return e ? atoi(e) : 0; }();
-    bool okb = !no_bits && (n_rel == 3 || n_rel == 1) && D >= 128 && n_rows >= 32 &&
+    bool okb = (n_rel == 3 || n_rel == 1) && D >= 128 && n_rows >= 32 &&
                (uint64_t)n_rows * (uint64_t)D * 4u < (1ull << 32);     // `out` sits behind one 32-bit buffer descriptor
     for (int r = 0; r < n_rel && okb; ++r) okb = (rels[r].flags & MMG_REL_SIMPLE) != 0 && rels[r].mask_r != nullptr;
     okb = okb && ((rels[0].n_cols + 31) & ~31) == 64;
@@ -1173,8 +952,8 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
       int g = 256 / n_dchunks;
       if (g > n_tiles) g = n_tiles;
       dim3 grid((unsigned)g, (unsigned)n_dchunks);
-      if (accumulate) hipLaunchKernelGGL((k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
-      else hipLaunchKernelGGL((k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
+      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
+      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       MMG_CHECK_LAUNCH("gather_rows(bits)");
       if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
       return MMG_OK;
@@ -1185,8 +964,8 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
       int g = 256 / n_dchunks;
       if (g > n_tiles) g = n_tiles;
       dim3 grid((unsigned)g, (unsigned)n_dchunks);
-      if (accumulate) hipLaunchKernelGGL((k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
-      else hipLaunchKernelGGL((k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
+      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
+      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       MMG_CHECK_LAUNCH("gather_rows(bits)");
       if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
       return MMG_OK;
@@ -1206,11 +985,11 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
     nblk = (n_rows + rows_per_blk - 1) / rows_per_blk;
     dim3 grid((unsigned)nblk, (unsigned)n_dchunks);
     if (dc == 128) {
-      (void)hipFuncSetAttribute((const void*)k_gather_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL_LDS_BUDGET);
-      hipLaunchKernelGGL(k_gather_lds<2>, grid, dim3(GL_THREADS), lds, st, rp, n_rows, rows_per_blk, D, out, accumulate);
+      MMG_CHECK_HIP((MmgMaxLds<&k_gather_lds<2>, (int)GL_LDS_BUDGET>::set()), "gather_rows(attr)");
+      MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, accumulate | 16, k_gather_lds<2>, grid, dim3(GL_THREADS), lds, st, rp, n_rows, rows_per_blk, D, out, accumulate);
     } else {
-      (void)hipFuncSetAttribute((const void*)k_gather_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GL_LDS_BUDGET);
-      hipLaunchKernelGGL(k_gather_lds<1>, grid, dim3(GL_THREADS), lds, st, rp, n_rows, rows_per_blk, D, out, accumulate);
+      MMG_CHECK_HIP((MmgMaxLds<&k_gather_lds<1>, (int)GL_LDS_BUDGET>::set()), "gather_rows(attr)");
+      MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, accumulate | 16, k_gather_lds<1>, grid, dim3(GL_THREADS), lds, st, rp, n_rows, rows_per_blk, D, out, accumulate);
     }
     MMG_GATHER_TAIL("gather_rows(lds)");
   }
@@ -1246,7 +1025,8 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     rc = pack(rels, n_rel, &rp, false, true, false);
     if (rc) return rc;
     for (int r = 0; r < n_rel; ++r)
-      if (rels[r].n_cols > 0) (void)hipMemsetAsync(rels[r].out, 0, (size_t)rels[r].n_cols * D * 4, st);
+      if (rels[r].n_cols > 0)
+        MMG_CHECK_HIP(hipMemsetAsync(rels[r].out, 0, (size_t)rels[r].n_cols * D * 4, st), "scatter_rows(memset)");
     if (n_rows == 0) return MMG_OK;
     MMG_CHECK_ARG(x, "scatter_rows: x is null");
     const unsigned nb = (unsigned)((n_rows + 3) / 4);
@@ -1282,8 +1062,8 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     default: launch_scatter_mfma<16>(p, rp, n_rows, D, x, slab, st); break;
   }
   const int64_t n = (int64_t)p.total_pad * D;
-  hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiScatter>), dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4,
-                     p.n_split, EpiScatter{rp, D});
+  MMG_LAUNCH(MMG_PROBE_SCATTER_REDUCE, n_rows, D, p.total_pad, 0, (mmg_k_reduce_slabs<EpiScatter>),
+             dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4, p.n_split, EpiScatter{rp, D});
   MMG_CHECK_LAUNCH("scatter_rows");
   return MMG_OK;
 }
@@ -1302,18 +1082,12 @@ extern "C" int mmg_rel_mask_build(const int32_t* rowptr, const int32_t* col, int
   hipStream_t st = (hipStream_t)stream;
   const int padc = (n_cols + 31) & ~31;
   if (mask_t) {
-    if (hipMemsetAsync(mask_t, 0, words * sizeof(uint64_t), st) != hipSuccess) {
-      mmg_set_error("rel_mask_build: memset failed");
-      return MMG_E_LAUNCH;
-    }
+    MMG_CHECK_HIP(hipMemsetAsync(mask_t, 0, words * sizeof(uint64_t), st), "rel_mask_build(memset)");
     hipLaunchKernelGGL(k_mask_build, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rowptr, col, n_rows, padc,
                        reinterpret_cast<unsigned long long*>(mask_t));
   }
   if (mask_r) {
-    if (hipMemsetAsync(mask_r, 0, words * sizeof(uint64_t), st) != hipSuccess) {
-      mmg_set_error("rel_mask_build: memset failed");
-      return MMG_E_LAUNCH;
-    }
+    MMG_CHECK_HIP(hipMemsetAsync(mask_r, 0, words * sizeof(uint64_t), st), "rel_mask_build(memset)");
     hipLaunchKernelGGL(k_mask_build_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rowptr, col, n_rows,
                        padc / 16, reinterpret_cast<unsigned*>(mask_r));
   }
