@@ -211,14 +211,14 @@ int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const int64_t* ro
 int mmg_bn_bwd_apply_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
                           const mmg_prologue_t* pro, float* dY, int N, void* stream);
 
-/* Measurement hook (bench.py).  After mmg_probe_arm(n) the next n launches of the big kernels made BY THE CALLING THREAD
- * carry a HIP start / stop event pair on the kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end
+/* Measurement hook (bench.py).  After mmg_probe_arm(n) the next n launches of the big kernels (from any host thread: the
+ * backward of a step runs on the autograd engine's thread) carry a HIP start / stop event pair on the kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end
  * timestamps on its stream -- what rocprofv3 reports -- not a pair of extra queue entries around it).  mmg_probe_read
  * waits for them, disarms the hook and returns how many entries it wrote (<= cap):
  *   ms = kernel duration, tag = MMG_PROBE_* family, (M, N, K) = the launch's shape: rows / output width / inner width for
  *   the dense kernels; patient rows / D / total vocab rows of the fused relations for the aggregates; pairs / 0 / 0 for
  *   the heads;  flags: 1 = accumulate, 4 = prologue, 8 = rowscale.
- * State is per thread (like mmg_last_error); the product path never arms it. */
+ * The hook is the library's only process-wide mutable state (mutex-guarded); the product path never arms it. */
 #define MMG_PROBE_LINEAR_FWD 1
 #define MMG_PROBE_LINEAR_WGRAD 2
 #define MMG_PROBE_LINEAR_WGRAD_REDUCE 3

@@ -219,7 +219,6 @@ struct ScatterPlan {
   int n_split;
   int64_t rows_per_split;
   bool ok;
-  bool bf16;           // all relations simple and the tiles fit: the bf16-split matrix-core kernel
 };
 
 int pad32(int n) { return (n + 31) & ~31; }
@@ -245,25 +244,6 @@ ScatterPlan plan_scatter(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D
   p.rows_per_split = rps;
   p.n_split = (int)((n_rows + rps - 1) / rps);
   if (p.n_split < 1) p.n_split = 1;
-  // bf16-split kernel: one 512-thread workgroup per CU, stages of SB_SR rows dealt out evenly
-  bool simple = true;
-  for (int r = 0; r < n_rel; ++r)
-    simple &= ((rels[r].flags & MMG_REL_SIMPLE) != 0 && rels[r].mask_t != nullptr) || rels[r].n_cols == 0;
-  p.bf16 = p.ok && simple && p.nt <= 10 && n_rows >= 64;
-  bool has_rs = false;
-  for (int r = 0; r < n_rel; ++r) has_rs |= rels[r].rowscale != nullptr;
-  if (p.bf16 && has_rs) {
-    // the rowscale kernel needs a compile-time tile -> relation map: instances exist for the eICU vocabulary
-    // (50 / 114 / 100 items -> tiles 2 | 4 | 4) at 128 feature columns per workgroup; others count in fp32
-    p.bf16 = n_rel == 3 && p.nt == 10 && p.dc == 128 && pad32(rels[0].n_cols) == 64 && pad32(rels[1].n_cols) == 128 &&
-             pad32(rels[2].n_cols) == 128;
-  }
-  if (p.bf16) {
-    const int64_t nst = (n_rows + 63) / 64;
-    int64_t g = 256 / p.n_dchunks;
-    if (g > nst) g = nst;
-    p.n_split = (int)g;
-  }
   return p;
 }
 
@@ -384,208 +364,450 @@ __device__ inline void split8(const float* v, bf16x8& p0, bf16x8& p1, bf16x8& p2
   }
 }
 
-// RS = 1: a rowscale per relation, relation r owning the item tiles [T(r), T(r+1)) with T = {0, T1, T2, NT} fixed at
-// compile time (the tile -> relation map must be static for the accumulators to stay in registers).
-template <int NT, int KT, int RS, int T1, int T2>
-__global__ __launch_bounds__(256) void k_scatter_bits(RelPack rp, int64_t n_rows, int n_stage_total, int D,
-                                                      const float* __restrict__ x, float* __restrict__ slab) {
-  // One wave per SIMD (the accumulators of ALL item tiles + an 8-deep operand ring need > 256 registers): latency
-  // is hidden by run-ahead, not by occupancy -- 6 k-steps x 2 KB x 4 waves = 48 KB of x in flight per CU -- and the
-  // operands of k-step q+1 (bf16 split, indicator fragments) are produced in the shadow of the MFMAs of k-step q.
-  constexpr int NTOT = NT * 32, NSPLIT = 4 / KT, NTW = (NT + NSPLIT - 1) / NSPLIT;
-  constexpr int KS = 8, RING = 8, AHEAD = 6, NREL = RS ? 3 : 1;
-  static_assert(!RS || KT == 4, "static tile -> relation map needs every wave to own all item tiles");
+// k_scatter_strip: the workgroup owns a 32-column STRIP of x for a range of rows; its four waves (one per SIMD: the
+// accumulators of ALL item tiles stay in one wave's registers, so x is split into its bf16 pieces exactly once) take a
+// quarter of those rows each and their partial accumulators are summed through LDS in fixed order at the end, so ONE
+// [padded items x 32] strip per workgroup goes to the partial slabs: 256 / (D / 32) row ranges -> 10.5 MB at the eICU
+// vocabulary instead of 42 MB (the slabs were 84 MB of traffic beside 94 MB of x).
+// No rowscale here: with one, every relation needs its own scaled copy of x split into pieces (3x the vector work of
+// a wave that is already alone on its SIMD) -- measured 56 us against 50 us for k_scatter_units below, which takes
+// those launches (and every vocabulary beyond 10 tiles).
+// The operands of k-step q+1 are produced in the shadow of the matrix instructions of k-step q: a wave that is alone
+// on its SIMD hides at most ~24 cycles of other issue per 32-cycle MFMA (MI355X_MICROARCH.md), so the vector work is
+// dealt out between the MFMAs explicitly (sched_group_barrier) instead of left in clumps.
+constexpr int ST_TP = 5;                     // tiles per phase of the final cross-wave sum (80 registers x 4 waves = 80 KB)
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_rows, int n_stage_total, int D, int total_pad,
+                                                       const float* __restrict__ x, float* __restrict__ slab) {
+  constexpr int KS = 8, RING = 8, AHEAD = 6;
   __shared__ __attribute__((aligned(16))) unsigned lut[256][4];            // byte -> 8 bf16 in {0, 1}
-  __shared__ __attribute__((aligned(16))) float rss[RS ? 2 : 1][RS ? 4 : 1][3][2 * SB_SR];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) float st_red[];           // [4 waves][ST_TP * 16][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const int kt = wid % KT, nt0 = (wid / KT) * NTW;
-  const int d0 = blockIdx.y * (KT * 32);
+  const int d0 = blockIdx.y * 32;
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
   __syncthreads();
-  const int s_beg = (int)((int64_t)blockIdx.x * n_stage_total / gridDim.x);
-  const int s_end = (int)((int64_t)(blockIdx.x + 1) * n_stage_total / gridDim.x);
+  // stages of this wave: the n_stage_total 64-row stages are dealt evenly over (workgroup, wave)
+  const int q_id = blockIdx.x * 4 + wid, n_q = gridDim.x * 4;
+  const int s_beg = (int)((int64_t)q_id * n_stage_total / n_q);
+  const int s_end = (int)((int64_t)(q_id + 1) * n_stage_total / n_q);
   const int ns = s_end - s_beg;
   const int64_t r_beg = (int64_t)s_beg * SB_SR;
 
-  // this wave's tiles: mask pointer (lane = item row of the tile and patient half), words per stage.
-  // Padding tiles (no relation) read some valid word and select the all-zero LUT entry.
-  const uint64_t* mb[NTW];
-  int ms[NTW];
-  bool live[NTW];
-  const uint64_t* any_mask = nullptr;
+  f32x16 acc[NT];
 #pragma unroll
-  for (int r = 0; r < MMG_MAX_REL; ++r)
-    if (r < rp.n && rp.r[r].mask && !any_mask) any_mask = rp.r[r].mask;
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    mb[t] = any_mask; ms[t] = 0; live[t] = false;
-    const int c0 = (nt0 + t) * 32;
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  if (ns > 0) {
+    // this wave's tiles: mask pointer (lane = item row of the tile and patient half), words per stage.
+    // Padding tiles (no relation) read some valid word and select the all-zero LUT entry.
+    const uint64_t* mb[NT];
+    int ms[NT];
+    bool live[NT];
+    const uint64_t* any_mask = nullptr;
 #pragma unroll
-    for (int r = 0; r < MMG_MAX_REL; ++r) {
-      if (r >= rp.n) continue;
-      const int padc = (rp.r[r].n_cols + 31) & ~31;
-      if (rp.r[r].mask && c0 >= rp.r[r].acc_off && c0 < rp.r[r].acc_off + padc) {
-        mb[t] = rp.r[r].mask + ((size_t)s_beg * padc + (c0 - rp.r[r].acc_off) + l31) * 2 + h;
-        ms[t] = 2 * padc; live[t] = true;
+    for (int r = 0; r < MMG_MAX_REL; ++r)
+      if (r < rp.n && rp.r[r].mask && !any_mask) any_mask = rp.r[r].mask;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      mb[t] = any_mask; ms[t] = 0; live[t] = false;
+      const int c0 = t * 32;
+#pragma unroll
+      for (int r = 0; r < MMG_MAX_REL; ++r) {
+        if (r >= rp.n) continue;
+        const int padc = (rp.r[r].n_cols + 31) & ~31;
+        if (rp.r[r].mask && c0 >= rp.r[r].acc_off && c0 < rp.r[r].acc_off + padc) {
+          mb[t] = rp.r[r].mask + ((size_t)s_beg * padc + (c0 - rp.r[r].acc_off) + l31) * 2 + h;
+          ms[t] = 2 * padc; live[t] = true;
+        }
+      }
+    }
+    // x goes through a buffer descriptor that covers exactly this wave's rows: the range check returns 0 for rows past
+    // the end and for the run-ahead past the last k-step (no clamps, no exec-masked regions in the loop), and an address
+    // is  descriptor base + one 32-bit lane offset + a scalar row offset  (one VALU add per k-step).
+    const int64_t rows_here = (n_rows - r_beg) < (int64_t)ns * SB_SR ? (n_rows - r_beg) : (int64_t)ns * SB_SR;
+    const float* xw = x + (size_t)r_beg * D + d0;
+    const __amdgpu_buffer_rsrc_t xsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xw), 0, (int)((rows_here * D - d0) * 4), 0x00020000);
+    const unsigned row_bytes = (unsigned)D * 4u;
+    const unsigned voff0 = (unsigned)(8 * h) * row_bytes + (unsigned)l31 * 4u;
+    float xq[RING][8];                                 // ring of k-step operands: slot = k-step & 7
+    auto loadx = [&](int kg, float* dst) {
+      const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, j * row_bytes, 0));
+    };
+    auto loadm = [&](int s, uint64_t* dst) {           // past the end: re-read the last stage (its x reads as 0)
+      const int sc = s < ns ? s : ns - 1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dst[t] = mb[t][(size_t)sc * ms[t]];
+    };
+    // operands of one k-step.  kq = k-step inside its 64-row stage (0..3): field kq of the mask word is
+    // (8 patient bits) << 4 = the byte offset of the LUT entry that expands them.
+    auto make_af = [&](const uint64_t* mw, int kq, bf16x8* af) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const unsigned w = (kq & 2) ? (unsigned)(mw[t] >> 32) : (unsigned)mw[t];
+        unsigned off = __builtin_amdgcn_ubfe(w, 16u * (kq & 1), 12u);
+        if (!live[t]) off = 0;
+        af[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
+      }
+    };
+    uint64_t mc[NT], mn[NT];
+    loadm(0, mc);
+    // drain before the ring is primed: the loop is then entered with exactly the loads its back edge carries, so
+    // the wait counts inside stay exact (otherwise every iteration starts by draining the whole ring)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) loadx(q, xq[q]);
+    bf16x8 afc[NT], bc[3];
+    make_af(mc, 0, afc);
+    split8(xq[0], bc[0], bc[1], bc[2]);
+
+    const int n2 = (ns + 1) / 2;
+    for (int u = 0; u < n2; ++u) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if ((ks & 3) == 0) loadm(2 * u + (ks >> 2) + 1, mn);             // words of the next stage
+        loadx(u * KS + ks + AHEAD, xq[(ks + AHEAD) & (RING - 1)]);       // into a slot consumed two k-steps ago
+        __builtin_amdgcn_sched_barrier(0);             // keep the run-ahead: the scheduler would sink these loads
+        bf16x8 afn[NT], bn[3];
+        make_af((ks & 3) == 3 ? mn : mc, (ks + 1) & 3, afn);
+        split8(xq[(ks + 1) & (RING - 1)], bn[0], bn[1], bn[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[p], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) afc[t] = afn[t];
+        bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
+        // deal the next k-step's vector work out between this k-step's matrix instructions (~4 per MFMA by count)
+#pragma unroll
+        for (int i = 0; i < 3 * NT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                      // a slice of the split work
+          if (i < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one LUT read
+        }
+        if ((ks & 3) == 3) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) mc[t] = mn[t];
+        }
       }
     }
   }
-  f32x16 acc[NTW];
+  // ---- fixed-order sum of the four waves' partial accumulators through LDS, ST_TP tiles at a time: every wave parks
+  // its registers of the phase, then sums a QUARTER of them over the four copies (wave 0 + 1 + 2 + 3) and stores it
+  float* dst = slab + (size_t)blockIdx.x * total_pad * D + d0 + l31;
 #pragma unroll
-  for (int t = 0; t < NTW; ++t)
+  for (int t0 = 0; t0 < NT; t0 += ST_TP) {
+    constexpr int dummy = 0; (void)dummy;
+    const int ntp = (NT - t0) < ST_TP ? (NT - t0) : ST_TP;
+    if (t0 > 0) __syncthreads();                       // the previous phase's reads are done
+#pragma unroll
+    for (int t = 0; t < ST_TP; ++t)
+      if (t0 + t < NT) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st_red[((size_t)wid * ST_TP * 16 + t * 16 + i) * 64 + lane] = acc[t0 + t][i];
+      }
+    __syncthreads();
+    const int nreg = ntp * 16;
+    for (int idx = wid * nreg / 4; idx < (wid + 1) * nreg / 4; ++idx) {
+      float v = st_red[((size_t)0 * ST_TP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)1 * ST_TP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)2 * ST_TP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)3 * ST_TP * 16 + idx) * 64 + lane];
+      const int i = idx & 15;
+      const int vrow = (t0 + (idx >> 4)) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      dst[(size_t)vrow * D] = v;
+    }
+  }
+}
+
+template <int NT>
+int launch_scatter_strip(const RelPack& rp, int64_t n_rows, int D, int n_ranges, int total_pad, const float* x, float* slab,
+                         hipStream_t st) {
+  constexpr int lds = 4 * ST_TP * 16 * 64 * 4;
+  MMG_CHECK_HIP((MmgMaxLds<&k_scatter_strip<NT>, lds>::set()), "scatter_rows(attr)");
+  const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
+  MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, total_pad, 0, (k_scatter_strip<NT>),
+             dim3((unsigned)n_ranges, (unsigned)(D / 32)), dim3(256), lds, st, rp, n_rows, nst, D, total_pad, x, slab);
+  return MMG_OK;
+}
+
+// strip plan: instance (padded tile count) and number of row ranges; ok = false -> k_scatter_units / fp32 kernels
+struct StripPlan { bool ok; int nt; int n_ranges; int total_pad; };
+StripPlan plan_strip(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
+  StripPlan sp{};
+  sp.ok = false;
+  int tiles = 0;
+  bool has_rs = false;
+  for (int r = 0; r < n_rel; ++r) {
+    if (rels[r].n_cols == 0) continue;
+    if ((rels[r].flags & MMG_REL_SIMPLE) == 0 || rels[r].mask_t == nullptr) return sp;
+    tiles += pad32(rels[r].n_cols) / 32;
+    has_rs |= rels[r].rowscale != nullptr;
+  }
+  // (one wave holds every tile's accumulators + a double-buffered operand set: 10 tiles fill the 512 registers)
+  if (tiles == 0 || tiles > 10 || n_rows < SB_SR) return sp;
+  if (has_rs) return sp;
+  const int inst[] = {4, 8, 10};
+  for (int i = 0; i < 3; ++i)
+    if (tiles <= inst[i]) { sp.nt = inst[i]; break; }
+  sp.total_pad = sp.nt * 32;
+  const int strips = D / 32;
+  int64_t nr = 256 / strips;
+  const int64_t nst = (n_rows + SB_SR - 1) / SB_SR;
+  if (nr * 4 > nst) nr = (nst + 3) / 4;
+  if (nr < 1) nr = 1;
+  sp.n_ranges = (int)nr;
+  sp.ok = true;
+  return sp;
+}
+
+// ------------------------------------------------------------------------------ scatter, unit-per-wave layout
+// Same arithmetic as k_scatter_bits (0/1 indicator fragments x three exact bf16 pieces of x, fp32 accumulation), laid
+// out for the two things the counters said that kernel lost its time to: (1) with ALL item tiles in one wave (160
+// accumulator registers) only one wave fits a SIMD, and a lone wave serialises its vector work (piece split, fragment
+// expansion) with its matrix instructions -- the matrix pipe idled ~45 % of the loop; (2) 256 partial slabs of
+// [320 x 128] were written and read back (84 MB of traffic beside 94 MB of x).
+//   * A wave owns ONE "unit": up to SU_NT consecutive 32-item tiles of ONE relation (64 accumulator registers), so a
+//     rowscale is one scale vector per wave for ANY vocabulary layout (no compile-time tile -> relation map), and three
+//     waves share a SIMD: one multiplies while the others split / expand / wait for memory.
+//   * A workgroup owns a 32-column strip of x for a range of rows: its U units x R row sub-ranges (U x R <= 12 waves)
+//     stream that strip; the R partial accumulators of a unit are summed through LDS in fixed order, so ONE
+//     [padded items x 32] strip leaves the workgroup: 256 / (D / 32) row ranges -> 10.5 MB of partial slabs instead of 42.
+//   * The bf16 split uses v_dot2c_f32_bf16 for the residuals (x - hi as ONE instruction: hi.lo * -1 + hi.hi * 0 + x,
+//     exact): 28 instead of 52 vector instructions per 8 values.
+constexpr int SU_NT = 4;          // tiles per unit
+constexpr int SU_MAXU = 6;        // units per launch (<= 24 tiles = 768 padded items)
+constexpr int SU_MAXW = 12;       // waves per workgroup (three per SIMD at <= 168 registers)
+constexpr int SU_AH = 3;          // k-steps of x in flight per wave (ring of 4)
+
+struct ScUnits {
+  const uint64_t* mask[SU_MAXU];  // bit planes of the unit's relation
+  int padc[SU_MAXU];              // padded items of that relation (mask row stride)
+  int tile0[SU_MAXU];             // first tile of the unit inside its relation
+  int ntiles[SU_MAXU];            // 1 .. SU_NT
+  int rel[SU_MAXU];               // relation index (rowscale)
+  int out_tile[SU_MAXU];          // first tile of the unit in the slab
+  int n_units, R, n_waves;
+  unsigned char wave_unit[SU_MAXW], wave_rq[SU_MAXW];   // wave -> (unit, row sub-range): balanced over the four SIMDs on the host
+};
+
+template <int NT, bool RS>
+__device__ __forceinline__ void scatter_unit_body(const ScUnits& su, const RelPack& rp, int u, int rq, int64_t n_rows,
+                                                  int n_stage_total, int D, const float* __restrict__ x,
+                                                  const unsigned (*lut)[4], float* rss, f32x16* acc) {
+  const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+  const int d0 = blockIdx.y * 32;
+  // stages of this workgroup, then of this wave
+  const int S0 = (int)((int64_t)blockIdx.x * n_stage_total / gridDim.x);
+  const int S1 = (int)((int64_t)(blockIdx.x + 1) * n_stage_total / gridDim.x);
+  const int s_beg = S0 + (int)((int64_t)rq * (S1 - S0) / su.R), s_end = S0 + (int)((int64_t)(rq + 1) * (S1 - S0) / su.R);
+  const int ns = s_end - s_beg;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  // x goes through a buffer descriptor that covers exactly this workgroup's rows: the range check returns 0 for
-  // rows past the end and for the run-ahead past the last k-step (no clamps, no exec-masked regions in the loop),
-  // and an address is  descriptor base + one 32-bit lane offset + a scalar row offset  (one VALU add per k-step).
+  if (ns <= 0) return;
+  const int64_t r_beg = (int64_t)s_beg * SB_SR;
   const int64_t rows_here = (n_rows - r_beg) < (int64_t)ns * SB_SR ? (n_rows - r_beg) : (int64_t)ns * SB_SR;
+  // bit-plane words: lane = (item row of the tile, patient half)
+  const int padc = su.padc[u];
+  const uint64_t* mb = su.mask[u] + ((size_t)s_beg * padc + (size_t)su.tile0[u] * 32 + l31) * 2 + h;
+  const size_t ms = (size_t)2 * padc;
+  // x through a buffer descriptor over exactly this wave's rows: rows past the end (and the run-ahead past the last
+  // k-step) read 0, no clamps and no exec-masked regions in the loop
   const float* xw = x + (size_t)r_beg * D + d0;
   const __amdgpu_buffer_rsrc_t xsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xw), 0, (int)((rows_here * D - d0) * 4), 0x00020000);
-  const unsigned voff0 = (unsigned)((8 * h * D + kt * 32 + l31) * 4);
   const unsigned row_bytes = (unsigned)D * 4u;
-  float xq[RING][8];                                 // ring of k-step operands: slot = k-step & 7
+  const unsigned voff0 = (unsigned)(8 * h) * row_bytes + (unsigned)l31 * 4u;
+  const float* rsp = RS ? rp.r[su.rel[u]].rowscale : nullptr;
+  float xq[4][8];
   auto loadx = [&](int kg, float* dst) {
     const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, j * row_bytes, 0));
   };
-  auto loadm = [&](int s, uint64_t* dst) {           // past the end: re-read the last stage (its x reads as 0)
+  auto loadm = [&](int s, uint64_t* dst) {
     const int sc = s < ns ? s : ns - 1;
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) dst[t] = mb[t][(size_t)sc * ms[t]];
+    for (int t = 0; t < NT; ++t) dst[t] = mb[(size_t)sc * ms + (size_t)t * 64];
   };
-  auto loadrs = [&](int s, float* dst) {             // lane = patient of the stage
+  auto loadrs = [&](int s) -> float {                 // lane = patient of the stage
     int64_t lr = (int64_t)(s < ns ? s : ns - 1) * SB_SR + lane;
     if (lr > rows_here - 1) lr = rows_here - 1;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) dst[r] = (r < rp.n && rp.r[r].rowscale) ? rp.r[r].rowscale[r_beg + lr] : 1.f;
+    return rsp ? rsp[r_beg + lr] : 1.f;
   };
-  // operands of one k-step.  kq = k-step inside its 64-row stage (0..3): field kq of the mask word is
-  // (8 patient bits) << 4 = the byte offset of the LUT entry that expands them.
-  auto make_af = [&](const uint64_t* mw, int kq, bf16x8* af) {
+  uint64_t mc[NT], mn[NT];
+  float rsn = 1.f;
+  loadm(0, mc);
+  if (RS) { rss[lane] = loadrs(0); rsn = loadrs(1); }
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const unsigned w = (kq & 2) ? (unsigned)(mw[t] >> 32) : (unsigned)mw[t];
-      unsigned off = __builtin_amdgcn_ubfe(w, 16u * (kq & 1), 12u);
-      if (!live[t]) off = 0;
-      af[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
-    }
-  };
-  auto make_b = [&](const float* xs, int par, int k8, bf16x8 (*b)[3]) {      // k8 = k-step inside the 128-row pair
-    if (!RS) {
-      split8(xs, b[0][0], b[0][1], b[0][2]);
-    } else {
+  for (int q = 0; q < SU_AH; ++q) loadx(q, xq[q]);
+  for (int s = 0; s < ns; ++s) {
+    loadm(s + 1, mn);
+    float* rs_cur = rss + (s & 1) * SB_SR;
+    if (RS) { rss[((s + 1) & 1) * SB_SR + lane] = rsn; rsn = loadrs(s + 2); }
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const f32x4s s0 = *reinterpret_cast<const f32x4s*>(&rss[par][wid][r][k8 * 16 + 8 * h]);
-        const f32x4s s1 = *reinterpret_cast<const f32x4s*>(&rss[par][wid][r][k8 * 16 + 8 * h + 4]);
+    for (int kq = 0; kq < 4; ++kq) {
+      loadx(s * 4 + kq + SU_AH, xq[(kq + SU_AH) & 3]);
+      bf16x8 b0, b1, b2;
+      if (RS) {
+        const f32x4s s0 = *reinterpret_cast<const f32x4s*>(rs_cur + kq * 16 + 8 * h);
+        const f32x4s s1 = *reinterpret_cast<const f32x4s*>(rs_cur + kq * 16 + 8 * h + 4);
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = xs[j] * s0[j]; v[4 + j] = xs[4 + j] * s1[j]; }
-        split8(v, b[r][0], b[r][1], b[r][2]);
+        for (int j = 0; j < 4; ++j) { v[j] = xq[kq][j] * s0[j]; v[4 + j] = xq[kq][4 + j] * s1[j]; }
+        split8(v, b0, b1, b2);
+      } else {
+        split8(xq[kq], b0, b1, b2);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const unsigned w = (kq & 2) ? (unsigned)(mc[t] >> 32) : (unsigned)mc[t];
+        const unsigned off = __builtin_amdgcn_ubfe(w, 16u * (kq & 1), 12u);
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[t], 0, 0, 0);
       }
     }
-  };
-  uint64_t mc[NTW], mn[NTW];
-  float rsn[2][3];
-  loadm(0, mc);
-  if (RS) {
-    loadrs(0, rsn[0]); loadrs(1, rsn[1]);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { rss[0][wid][r][lane] = rsn[0][r]; rss[0][wid][r][SB_SR + lane] = rsn[1][r]; }
-    loadrs(2, rsn[0]); loadrs(3, rsn[1]);
-  }
-  // drain before the ring is primed: the loop is then entered with exactly the loads its back edge carries, so
-  // the wait counts inside stay exact (otherwise every iteration starts by draining the whole ring)
-  __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
-#pragma unroll
-  for (int q = 0; q < AHEAD; ++q) loadx(q, xq[q]);
-  bf16x8 afc[NTW], bc[NREL][3];
-  make_af(mc, 0, afc);
-  make_b(xq[0], 0, 0, bc);
-
-  const int n2 = (ns + 1) / 2;
-  for (int u = 0; u < n2; ++u) {
-    if (RS) {                                         // scales of the NEXT pair of stages -> the other LDS buffer
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {                   // private to this wave: no barrier
-        rss[(u + 1) & 1][wid][r][lane] = rsn[0][r]; rss[(u + 1) & 1][wid][r][SB_SR + lane] = rsn[1][r];
-      }
-      loadrs(2 * u + 4, rsn[0]); loadrs(2 * u + 5, rsn[1]);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if ((ks & 3) == 0) loadm(2 * u + (ks >> 2) + 1, mn);             // words of the next stage
-      loadx(u * KS + ks + AHEAD, xq[(ks + AHEAD) & (RING - 1)]);       // into a slot consumed two k-steps ago
-      __builtin_amdgcn_sched_barrier(0);             // keep the run-ahead: the scheduler would sink these loads
-      bf16x8 afn[NTW], bn[NREL][3];
-      make_af((ks & 3) == 3 ? mn : mc, (ks + 1) & 3, afn);
-      make_b(xq[(ks + 1) & (RING - 1)], ks == KS - 1 ? (u + 1) & 1 : u & 1, (ks + 1) & (KS - 1), bn);
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const int r = RS ? (t < T1 ? 0 : (t < T2 ? 1 : 2)) : 0;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[r][0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[r][1], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[r][2], acc[t], 0, 0, 0);
-      }
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) afc[t] = afn[t];
-#pragma unroll
-      for (int r = 0; r < NREL; ++r) { bc[r][0] = bn[r][0]; bc[r][1] = bn[r][1]; bc[r][2] = bn[r][2]; }
-#ifdef MMG_SCATTER_SGB
-      // one wave per SIMD: the vector work of the NEXT k-step's operands must issue BETWEEN this k-step's matrix
-      // instructions (a clump of 30 MFMAs followed by a clump of VALU work leaves the matrix pipe idle for the clump)
-#pragma unroll
-      for (int i = 0; i < 3 * NTW; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, RS ? 7 : 3, 0);               // a slice of the split / scale work
-        if (i < NTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one LUT read
-      }
-#endif
-      if ((ks & 3) == 3) {
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) mc[t] = mn[t];
-      }
-    }
-  }
-  float* dst = slab + (size_t)blockIdx.x * NTOT * D;
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    if (nt0 + t >= NT) continue;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int v = (nt0 + t) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      dst[(size_t)v * D + d0 + kt * 32 + l31] = acc[t][i];
-    }
+    for (int t = 0; t < NT; ++t) mc[t] = mn[t];
   }
 }
 
-// tile -> relation layouts with a static instance of the rowscale kernel: {T1, T2} for NT tiles
-inline bool scatter_bits_rs_layout(const RelPack& rp, int nt, int* t1, int* t2) {
-  if (rp.n != 3) return false;
-  *t1 = rp.r[1].acc_off / 32; *t2 = rp.r[2].acc_off / 32;
-  return nt == 10 && *t1 == 2 && *t2 == 6;         // 50 / 114 / 100 items (the eICU vocabulary)
+template <bool RS>
+__global__ __launch_bounds__(64 * SU_MAXW) void k_scatter_units(ScUnits su, RelPack rp, int64_t n_rows, int n_stage_total,
+                                                                 int D, int total_pad, const float* __restrict__ x,
+                                                                 float* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char su_lds[];
+  unsigned (*lut)[4] = reinterpret_cast<unsigned (*)[4]>(su_lds);                       // [256][4]: byte -> 8 bf16 {0,1}
+  float* rss_all = reinterpret_cast<float*>(su_lds + 4096);                              // [waves][2][64] row scales
+  float* red = reinterpret_cast<float*>(su_lds + 4096 + SU_MAXW * 2 * SB_SR * 4);        // [units][SU_NT * 16][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: everything derived from it stays scalar
+  const int h = lane >> 5, l31 = lane & 31;
+  if (tid < 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
+  }
+  __syncthreads();
+  const int u = su.wave_unit[wid], rq = su.wave_rq[wid];
+  const int nt = su.ntiles[u];
+  f32x16 acc[SU_NT];
+  float* rss = rss_all + wid * 2 * SB_SR;
+  switch (nt) {                                     // wave-uniform: one static tile count per code path
+    case 1: scatter_unit_body<1, RS>(su, rp, u, rq, n_rows, n_stage_total, D, x, lut, rss, acc); break;
+    case 2: scatter_unit_body<2, RS>(su, rp, u, rq, n_rows, n_stage_total, D, x, lut, rss, acc); break;
+    case 3: scatter_unit_body<3, RS>(su, rp, u, rq, n_rows, n_stage_total, D, x, lut, rss, acc); break;
+    default: scatter_unit_body<4, RS>(su, rp, u, rq, n_rows, n_stage_total, D, x, lut, rss, acc); break;
+  }
+  // fixed-order sum of the R row sub-ranges of every unit through LDS, then ONE strip per workgroup
+  float* mine = red + (size_t)u * (SU_NT * 16 * 64);
+  for (int rnd = 1; rnd < su.R; ++rnd) {
+    if (rq == rnd) {
+#pragma unroll
+      for (int t = 0; t < SU_NT; ++t)               // (static register indices; the tile count is wave-uniform)
+        if (t < nt) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) mine[(t * 16 + i) * 64 + lane] = acc[t][i];
+        }
+    }
+    __syncthreads();
+    if (rq == 0) {
+#pragma unroll
+      for (int t = 0; t < SU_NT; ++t)
+        if (t < nt) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t][i] += mine[(t * 16 + i) * 64 + lane];
+        }
+    }
+    __syncthreads();
+  }
+  if (rq == 0) {
+    float* dst = slab + ((size_t)blockIdx.x * total_pad + (size_t)su.out_tile[u] * 32) * D + blockIdx.y * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < SU_NT; ++t)
+      if (t < nt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int v = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          dst[(size_t)v * D] = acc[t][i];
+        }
+      }
+  }
 }
 
-template <int NT>
-void launch_scatter_bits(const ScatterPlan& p, const RelPack& rp, int64_t n_rows, int D, const float* x, float* slab,
-                         hipStream_t st) {
-  dim3 grid((unsigned)p.n_split, (unsigned)p.n_dchunks);
-  bool has_rs = false;
-  for (int r = 0; r < rp.n; ++r) has_rs |= rp.r[r].rowscale != nullptr;
-  const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
-  if (has_rs) {                                      // plan_scatter only picks this kernel for a static layout
-    if (NT == 10) MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 8, (k_scatter_bits<10, 4, 1, 2, 6>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
-  } else if (p.dc == 128) {
-    MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 0, (k_scatter_bits<NT, 4, 0, 0, 0>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
-  } else {
-    MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, NT * 32, 0, (k_scatter_bits<NT, 2, 0, 0, 0>), grid, dim3(256), 0, st, rp, n_rows, nst, D, x, slab);
+// host side: units (<= SU_NT tiles of one relation each), row sub-ranges, and a wave -> (unit, sub-range) table that
+// spreads every SIMD's (wave id % 4) matrix work evenly
+struct UnitsPlan { ScUnits su; int n_ranges; int total_pad; size_t lds; bool ok; };
+
+UnitsPlan plan_units(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
+  UnitsPlan up{};
+  up.ok = false;
+  ScUnits& su = up.su;
+  int U = 0, tile_off = 0;
+  for (int r = 0; r < n_rel; ++r) {
+    const int tiles = pad32(rels[r].n_cols) / 32;
+    if (tiles == 0) continue;
+    if ((rels[r].flags & MMG_REL_SIMPLE) == 0 || rels[r].mask_t == nullptr) return up;
+    const int chunks = (tiles + SU_NT - 1) / SU_NT;
+    int t0 = 0;
+    for (int c = 0; c < chunks; ++c) {
+      const int nt = (tiles - t0 + (chunks - c) - 1) / (chunks - c);      // balanced chunks: 7 -> 4 + 3
+      if (U >= SU_MAXU) return up;
+      su.mask[U] = rels[r].mask_t; su.padc[U] = tiles * 32; su.tile0[U] = t0; su.ntiles[U] = nt; su.rel[U] = r;
+      su.out_tile[U] = tile_off + t0;
+      ++U; t0 += nt;
+    }
+    tile_off += tiles;
   }
+  if (U == 0 || n_rows < SB_SR) return up;
+  su.n_units = U;
+  su.R = U <= 3 ? 4 : (U == 4 ? 3 : 2);
+  su.n_waves = U * su.R;
+  up.total_pad = tile_off * 32;
+  // greedy: heaviest (unit, sub-range) first onto the SIMD with the least tiles that still has a free slot
+  int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0};
+  const int slots = (su.n_waves + 3) / 4;
+  int order[SU_MAXU];
+  for (int i = 0; i < U; ++i) order[i] = i;
+  for (int i = 0; i < U; ++i)
+    for (int j = i + 1; j < U; ++j)
+      if (su.ntiles[order[j]] > su.ntiles[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+  for (int i = 0; i < U; ++i)
+    for (int rq = 0; rq < su.R; ++rq) {
+      int best = -1;
+      for (int sd = 0; sd < 4; ++sd) {
+        if (used[sd] >= slots || sd + 4 * used[sd] >= su.n_waves) continue;
+        if (best < 0 || load[sd] < load[best]) best = sd;
+      }
+      if (best < 0) return up;
+      const int w = best + 4 * used[best];
+      su.wave_unit[w] = (unsigned char)order[i]; su.wave_rq[w] = (unsigned char)rq;
+      load[best] += su.ntiles[order[i]]; ++used[best];
+    }
+  const int strips = D / 32;
+  int64_t nr = 256 / strips;
+  const int64_t nst = (n_rows + SB_SR - 1) / SB_SR;
+  if (nr > nst) nr = nst;
+  if (nr < 1) nr = 1;
+  up.n_ranges = (int)nr;
+  up.lds = 4096 + (size_t)SU_MAXW * 2 * SB_SR * 4 + (size_t)U * SU_NT * 16 * 64 * 4;
+  up.ok = true;
+  return up;
 }
 
 // bit planes of a CSR-by-row relation.  Word [row / 64][col][half] (half = bit 3 of the row inside its 64-row
@@ -1003,6 +1225,10 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
 
 extern "C" size_t mmg_scatter_rows_ws_bytes(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
   if (!rels || n_rel < 1 || n_rel > MMG_MAX_REL || !mmg_valid_D(D) || n_rows < 0) return 0;
+  const StripPlan sp = plan_strip(rels, n_rel, n_rows, D);
+  if (sp.ok) return (size_t)sp.n_ranges * sp.total_pad * D * 4 + 256;
+  const UnitsPlan up = plan_units(rels, n_rel, n_rows, D);
+  if (up.ok) return (size_t)up.n_ranges * up.total_pad * D * 4 + 256;
   ScatterPlan p = plan_scatter(rels, n_rel, n_rows, D);
   if (!p.ok) return 256;
   return (size_t)p.n_split * p.total_pad * D * 4 + 256;
@@ -1043,15 +1269,44 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     return MMG_E_WS;
   }
   float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  if (p.bf16) {
-    switch (p.nt) {
-      case 2: launch_scatter_bits<2>(p, rp, n_rows, D, x, slab, st); break;
-      case 4: launch_scatter_bits<4>(p, rp, n_rows, D, x, slab, st); break;
-      case 6: launch_scatter_bits<6>(p, rp, n_rows, D, x, slab, st); break;
-      case 8: launch_scatter_bits<8>(p, rp, n_rows, D, x, slab, st); break;
-      default: launch_scatter_bits<10>(p, rp, n_rows, D, x, slab, st); break;
+  // 1. bit-plane strip kernel: simple relations, <= 10 tiles, no rowscale
+  const StripPlan sp = plan_strip(rels, n_rel, n_rows, D);
+  if (sp.ok) {
+    int rc2 = MMG_OK;
+    if (sp.nt == 4) rc2 = launch_scatter_strip<4>(rp, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else if (sp.nt == 8) rc2 = launch_scatter_strip<8>(rp, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else rc2 = launch_scatter_strip<10>(rp, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    if (rc2) return rc2;
+    const int64_t n = (int64_t)sp.total_pad * D;
+    MMG_LAUNCH(MMG_PROBE_SCATTER_REDUCE, n_rows, D, sp.total_pad, 0, (mmg_k_reduce_slabs<EpiScatter>),
+               dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4, sp.n_ranges, EpiScatter{rp, D});
+    MMG_CHECK_LAUNCH("scatter_rows(strip)");
+    return MMG_OK;
+  }
+  // 2. unit-per-wave kernel: any vocabulary layout of simple relations up to 24 tiles, with or without a rowscale
+  const UnitsPlan up = plan_units(rels, n_rel, n_rows, D);
+  if (up.ok) {
+    bool has_rs = false;
+    for (int r = 0; r < n_rel; ++r) has_rs |= rels[r].rowscale != nullptr;
+    constexpr int lds_max = 4096 + SU_MAXW * 2 * SB_SR * 4 + SU_MAXU * SU_NT * 16 * 64 * 4;
+    const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
+    dim3 grid((unsigned)up.n_ranges, (unsigned)(D / 32));
+    if (has_rs) {
+      MMG_CHECK_HIP((MmgMaxLds<&k_scatter_units<true>, lds_max>::set()), "scatter_rows(attr)");
+      MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, up.total_pad, 8 | 32, k_scatter_units<true>, grid, dim3(64 * up.su.n_waves),
+                 up.lds, st, up.su, rp, n_rows, nst, D, up.total_pad, x, slab);
+    } else {
+      MMG_CHECK_HIP((MmgMaxLds<&k_scatter_units<false>, lds_max>::set()), "scatter_rows(attr)");
+      MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, up.total_pad, 32, k_scatter_units<false>, grid, dim3(64 * up.su.n_waves),
+                 up.lds, st, up.su, rp, n_rows, nst, D, up.total_pad, x, slab);
     }
-  } else
+    const int64_t n = (int64_t)up.total_pad * D;
+    MMG_LAUNCH(MMG_PROBE_SCATTER_REDUCE, n_rows, D, up.total_pad, 0, (mmg_k_reduce_slabs<EpiScatter>),
+               dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4, up.n_ranges, EpiScatter{rp, D});
+    MMG_CHECK_LAUNCH("scatter_rows(units)");
+    return MMG_OK;
+  }
+  // 3. multigraphs (repeated (patient, item) pairs): integer count tile on the fp32 matrix cores
   switch (p.nt) {
     case 2: launch_scatter_mfma<2>(p, rp, n_rows, D, x, slab, st); break;
     case 4: launch_scatter_mfma<4>(p, rp, n_rows, D, x, slab, st); break;

@@ -48,9 +48,9 @@ struct MmgMaxLds {
   }
 };
 
-// Measurement hook (mmg_probe_arm / mmg_probe_read, include/mmgnn.h; state is thread-local, like mmg_last_error):
-// while the calling thread has armed it, a launch made through MMG_LAUNCH carries a HIP start / stop event pair on the
-// kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps on its stream).
+// Measurement hook (mmg_probe_arm / mmg_probe_read, include/mmgnn.h): while armed, a launch made through MMG_LAUNCH
+// carries a HIP start / stop event pair on the kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end
+// timestamps on its stream).  Process-wide and mutex-guarded (api.hip); unarmed cost: one relaxed atomic load.
 bool mmg_probe_take(int tag, int64_t M, int N, int K, int flags, hipEvent_t* e0, hipEvent_t* e1);
 #define MMG_LAUNCH(tag, pM, pN, pK, pflags, kernel, grid, block, lds, st, ...)                         \
   do {                                                                                                \

@@ -92,7 +92,7 @@ PROBE_TAGS = {1: "linear_fwd", 2: "linear_wgrad", 3: "linear_wgrad_reduce", 4: "
 
 
 def probe_arm(n: int):
-    """Measurement hook: the next n big-kernel launches of this thread carry their own HIP start / stop event pair."""
+    """Measurement hook: the next n big-kernel launches (any host thread) carry their own HIP start / stop event pair."""
     check(_lib.load().mmg_probe_arm(int(n)), "mmg_probe_arm")
 
 

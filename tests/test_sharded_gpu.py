@@ -136,7 +136,14 @@ def _virtual_shards_vs_unsharded(n, hidden, dropout, bounds=None, world=2, seed=
             if k == "embeddings.patient.weight":
                 gref = gref[lo:hi]
             # replicated parameters: every shard ends the step with the FULL gradient
-            assert float((got - gref).abs().max()) <= 2e-4 * float(gref.abs().max()) + 2e-6 * gmax, (rank, k)
+            tol = 2e-4 * float(gref.abs().max()) + 2e-6 * gmax
+            diff = (got - gref).abs()
+            if float(diff.max()) > tol:
+                bad = diff > tol
+                nrows = int(bad.reshape(bad.shape[0], -1).any(1).sum()) if bad.dim() > 1 else int(bad.sum())
+                raise AssertionError(f"rank {rank} {k}: max diff {float(diff.max()):.3e} > tol {tol:.3e}; {int(bad.sum())} "
+                                     f"elements in {nrows} rows of {tuple(got.shape)}; rel L2 "
+                                     f"{float(diff.norm() / gref.norm()):.3e}")
         for (k, bf), (_, br) in zip(m.named_buffers(), ref.named_buffers()):
             if k.endswith("num_batches_tracked"):
                 assert int(bf) == int(br), k
