@@ -117,10 +117,17 @@ int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
  * Prologue applied to X on load (all optional):
  *   x' = dropout( relu( x * scale[k] + shift[k] ) )      scale/shift = folded BatchNorm
  * ------------------------------------------------------------------------------------- */
+#define MMG_ACT_NONE 0
+#define MMG_ACT_RELU 1
+#define MMG_ACT_LEAKY_RELU 2
+#define MMG_ACT_ELU 3
 typedef struct {
   const float* scale;      /* [K] or NULL: no affine */
   const float* shift;      /* [K] */
-  int relu;                /* apply max(.,0) after the affine */
+  int relu;                /* activation after the affine: MMG_ACT_NONE / _RELU / _LEAKY_RELU (slope 0.01) / _ELU (alpha 1)
+                              -- the three src/model.py:145-152 accepts.  The dense kernels' prologue takes NONE / RELU
+                              only (patient_transform and the heads are ReLU by construction, model.py:93-103,373-386);
+                              the materialising / backward kernels (mmg_affine_act_drop*, mmg_bn_bwd_*) take all four. */
   float drop_p;            /* 0 = no dropout */
   uint64_t seed;           /* dropout RNG: keep(seed, site, global_row*K + k) */
   uint32_t site;

@@ -113,7 +113,22 @@ __host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, ui
   return mmg_rng_field(w0, w1, (uint32_t)elem & 3u) >= mmg_keep_threshold(p);
 }
 
-// folded prologue: dropout(relu(x*scale+shift)); returns the transformed value
+// activation codes of mmg_prologue_t::relu (include/mmgnn.h): the reference's HeteroRGCN accepts relu, elu and leaky_relu
+// (src/model.py:145-152) for its conv layers.  act'(v) is taken at the PRE-activation value v, as autograd does.
+__device__ static inline float mmg_act(int code, float v) {
+  if (code == MMG_ACT_RELU) return fmaxf(v, 0.f);
+  if (code == MMG_ACT_LEAKY_RELU) return v > 0.f ? v : 0.01f * v;
+  if (code == MMG_ACT_ELU) return v > 0.f ? v : expm1f(v);
+  return v;
+}
+__device__ static inline float mmg_act_grad(int code, float v) {
+  if (code == MMG_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  if (code == MMG_ACT_LEAKY_RELU) return v > 0.f ? 1.f : 0.01f;
+  if (code == MMG_ACT_ELU) return v > 0.f ? 1.f : expf(v);
+  return 1.f;
+}
+
+// folded prologue: dropout(act(x*scale+shift)); returns the transformed value
 struct ProDev {
   const float* scale; const float* shift; int relu; float p; float inv_keep; uint64_t seed; uint32_t site;
   int64_t row_offset; const uint64_t* seed_ptr;
@@ -146,16 +161,19 @@ __device__ static inline void mmg_pro_apply4(const ProDev& pr, V4& v, const V4& 
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], sc[j], sh[j]);
   }
-  if (pr.relu) {
+  if (pr.relu == MMG_ACT_RELU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+  } else if (pr.relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = mmg_act(pr.relu, v[j]);
   }
   if (pr.p > 0.f) mmg_drop4(v, pr.key, (uint64_t)(pr.row_offset + row) * (uint64_t)K + (uint64_t)k0, pr.thr, pr.inv_keep);
 }
 __device__ static inline float mmg_pro_apply(const ProDev& pr, float x, float sc, float sh, int64_t row,
                                              int k, int K) {
   float v = pr.scale ? fmaf(x, sc, sh) : x;
-  if (pr.relu) v = fmaxf(v, 0.f);
+  if (pr.relu) v = mmg_act(pr.relu, v);
   if (pr.p > 0.f) {
     uint64_t e = (uint64_t)(pr.row_offset + row) * (uint64_t)K + (uint64_t)k;
     v = mmg_keep(pr.seed, pr.site, e, pr.p) ? v * pr.inv_keep : 0.f;

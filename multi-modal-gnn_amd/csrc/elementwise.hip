@@ -56,11 +56,17 @@ __global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, 
     if (MODE == 1) {                 // a = upstream grad G, b = pre-BN activation Y: g through relu, then dropout
       f32x4 a2 = {0.f, 0.f, 0.f, 0.f};
       if (A2) a2 = *reinterpret_cast<const f32x4*>(A2 + (size_t)r * N + c4 * 4);
-      if (pr.relu) {
+      if (pr.relu == MMG_ACT_RELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float o = pr.scale ? fmaf(b[j], sc[j], sh[j]) : b[j];
           if (!(o > 0.f)) { a[j] = 0.f; a2[j] = 0.f; }
+        }
+      } else if (pr.relu) {            // elu / leaky_relu: the slope at the pre-activation value
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = mmg_act_grad(pr.relu, pr.scale ? fmaf(b[j], sc[j], sh[j]) : b[j]);
+          a[j] *= d; a2[j] *= d;
         }
       }
       if (pr.p > 0.f)
@@ -204,12 +210,15 @@ __global__ __launch_bounds__(256) void k_affine_act_drop_rows(const float* __res
 // rows are patched afterwards.  g' = G_rows * [y*scale+shift > 0] * keepmask/(1-p) with the masks of the ORIGINAL rows.
 __device__ __forceinline__ f32x4 bn_rows_gprime(const ProDev& pr, f32x4 g, const f32x4& y, const f32x4& sc, const f32x4& sh,
                                                 int64_t row, int c, int N) {
-  if (pr.relu) {
+  if (pr.relu == MMG_ACT_RELU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float act = pr.scale ? fmaf(y[j], sc[j], sh[j]) : y[j];
       if (!(act > 0.f)) g[j] = 0.f;
     }
+  } else if (pr.relu) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] *= mmg_act_grad(pr.relu, pr.scale ? fmaf(y[j], sc[j], sh[j]) : y[j]);
   }
   if (pr.p > 0.f) mmg_drop4(g, pr.key, (uint64_t)(pr.row_offset + row) * (uint64_t)N + (uint64_t)c, pr.thr, pr.inv_keep);
   return g;
@@ -317,11 +326,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
     if (accumulate) prev = *reinterpret_cast<const f32x4*>(dY + (size_t)i * 4);
     f32x4 o, gm = g4, gm2 = zero;
     if (G2) gm2 = *reinterpret_cast<const f32x4*>(G2 + (size_t)i * 4);      // second upstream gradient (see k_col_reduce)
-    if (pr.relu) {
+    if (pr.relu == MMG_ACT_RELU) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float act = pr.scale ? fmaf(y4[j], sc[j], sh[j]) : y4[j];
         if (!(act > 0.f)) { gm[j] = 0.f; gm2[j] = 0.f; }
+      }
+    } else if (pr.relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = mmg_act_grad(pr.relu, pr.scale ? fmaf(y4[j], sc[j], sh[j]) : y4[j]);
+        gm[j] *= d; gm2[j] *= d;
       }
     }
     if (pr.p > 0.f) mmg_drop4(gm, pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)c, pr.thr, pr.inv_keep);

@@ -931,6 +931,7 @@ extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, c
   if (M == 0) return MMG_OK;
   MMG_CHECK_ARG(X && W && Y, "linear_fwd: null buffer");
   MMG_CHECK_ARG(!pro || !pro->scale || pro->shift, "linear_fwd: prologue scale without shift");
+  MMG_CHECK_ARG(!pro || pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_fwd: the prologue takes relu only");
   hipStream_t st = (hipStream_t)stream;
   const ProDev pr = mmg_pro_dev(pro);
   if (M <= 512) {          // vocab-side tables
@@ -985,6 +986,7 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
     return MMG_OK;
   }
   MMG_CHECK_ARG(dY && X && ws, "linear_wgrad: null buffer");
+  MMG_CHECK_ARG(!pro || pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_wgrad: the prologue takes relu only");
   const size_t need = mmg_linear_wgrad_ws_bytes(M, N, K);
   if (ws_bytes < need) {
     mmg_set_error("linear_wgrad: workspace %zu < %zu", ws_bytes, need);

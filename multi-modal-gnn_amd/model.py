@@ -126,13 +126,17 @@ class HeteroRGCN(nn.Module):
             if use_batch_norm:
                 self.batch_norms.append(nn.ModuleDict({t: nn.BatchNorm1d(D) for t in self._node_types}))
 
-        if activation == "relu":
+        if activation == "relu":                                                         # model.py:145-152
             self.activation = F.relu
-        elif activation in ("elu", "leaky_relu"):
-            raise NotImplementedError(f"activation '{activation}': only 'relu' (the configured one, "
-                                      "conf/config.yaml) is implemented in the HIP epilogues")
+        elif activation == "elu":
+            self.activation = F.elu
+        elif activation == "leaky_relu":
+            self.activation = F.leaky_relu
         else:
-            raise ValueError(f"Unknown activation: {activation}")                       # model.py:152
+            raise ValueError(f"Unknown activation: {activation}")
+        # activation code of the HIP epilogues (MMG_ACT_*): conv layers only -- patient_transform and the heads are
+        # nn.ReLU by construction (model.py:93-103, 373-386)
+        self._act_code = {"relu": 1, "leaky_relu": 2, "elu": 3}[activation]
 
         self.edge_predictor = EdgeRegressionHead(2 * D, [64, 32], 1, dropout)           # model.py:159-164
         self.tabular_mlp = EdgeRegressionHead(2 * D, [64, 32], 1, dropout)              # model.py:172-177
@@ -668,7 +672,7 @@ class _Run:
             sharded = t == ROW_TYPE
             fold = self.bn_fold(y[t], self.m.batch_norms[l][t], 1, sharded,
                                 sums=rec.get("ysums") if t == ROW_TYPE else None) if self.m.use_batch_norm else None
-            pro = Pro(fold.scale if fold else None, fold.shift if fold else None, True, p, self.seed,
+            pro = Pro(fold.scale if fold else None, fold.shift if fold else None, self.m._act_code, p, self.seed,
                       SITE_CONV + 8 * l + ti, plan.row_offset if sharded else 0, self.seed_dev)
             out[t] = ops.affine_act_drop(y[t], pro)
             folds[t], pros[t] = fold, pro

@@ -127,10 +127,11 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 @dataclass
 class Pro:
-    """Prologue dropout(relu(x*scale+shift)) applied on load (mmg_prologue_t)."""
+    """Prologue dropout(act(x*scale+shift)) applied on load (mmg_prologue_t).  relu: False / True, or an MMG_ACT_* code
+    (2 = leaky_relu, 3 = elu: the materialising and backward kernels only)."""
     scale: Optional[torch.Tensor] = None
     shift: Optional[torch.Tensor] = None
-    relu: bool = False
+    relu: int = 0
     p: float = 0.0
     seed: int = 0
     site: int = 0

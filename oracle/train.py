@@ -58,14 +58,15 @@ def weighted_loss(pred, target, lab_idx, weights, sup_mask, loss_type="mae"):
 
 
 def train_step_grads(sd, g, pi, li, target, weights, sup_mask, *, p=0.0, masks=None, loss_type="mae",
-                     num_layers=2, degree_threshold=6):
+                     num_layers=2, degree_threshold=6, use_batch_norm=True, activation="relu"):
     """One fwd + weighted loss + bwd (train.py:347-392 minus optimizer.step).
     Returns (loss, pred, grads dict over every floating parameter incl. embeddings, bufs)."""
     leaf = {k: (v.detach().clone().requires_grad_(True)
                 if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
             for k, v in sd.items()}
     pred, bufs = om.predict_lab_values(leaf, g, pi, li, num_layers=num_layers, training=True, p=p, masks=masks,
-                                       degree_threshold=degree_threshold)
+                                       degree_threshold=degree_threshold, use_batch_norm=use_batch_norm,
+                                       activation=activation)
     loss = weighted_loss(pred, target, li, weights, sup_mask, loss_type)
     loss.backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v))

@@ -31,3 +31,14 @@ def checksum(x):
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_close(a, b, rtol=1e-4, atol_frac=1e-6):
+    """Element-wise  |a - b| <= rtol * |b| + atol  with  atol = atol_frac * max|b|  -- north_star's "within 1e-4 relative
+    fp32" per VALUE (small predictions are not hidden behind the largest one); the absolute floor only covers entries that
+    are rounding noise at the tensor's scale.  -> (ok, worst excess ratio)."""
+    a, b = a.double(), b.double()
+    atol = atol_frac * float(b.abs().max().clamp_min(1e-30))
+    ratio = (a - b).abs() / (rtol * b.abs() + atol)
+    worst = float(ratio.max()) if ratio.numel() else 0.0
+    return worst <= 1.0, worst

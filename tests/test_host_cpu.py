@@ -112,3 +112,38 @@ def test_hetero_graph_container_protocol():
     assert set(g.edge_index_dict) == set(g.edge_types)
     assert g[("patient", "has_lab", "lab")].edge_attr.shape == (3, 1) and g.indexers == {"x": 1}
     assert g.to("cpu") is g
+
+
+@pytest.mark.parametrize("E", [10, 61484])
+def test_edge_masker_splits_match_the_reference(E):
+    """mmgnn.train.EdgeMasker (train.py:37-176) on a CPU graph: the 70/15/15 masks are the ones the REFERENCE's EdgeMasker
+    produced for seed 42 (tests/golden/splits.npz), the supervision mask follows the injected generator, and the masker
+    follows the graph when Trainer moves it (EdgeMasker.to)."""
+    import mmgnn  # noqa: F401
+    from mmgnn.data import HeteroGraph
+    from mmgnn.train import EdgeMasker
+    from golden_io import load, unpack_mask
+    gold, _ = load("splits.npz")
+    g = HeteroGraph()
+    g["patient"].num_nodes = E
+    g["lab"].num_nodes = 3
+    ei = torch.stack([torch.arange(E), torch.arange(E) % 3])
+    g["patient", "has_lab", "lab"].edge_index = ei
+    g["patient", "has_lab", "lab"].edge_attr = torch.arange(E, dtype=torch.float32).unsqueeze(-1)
+    m = EdgeMasker(g, 0.7, 0.15, 0.15, mask_fraction=0.2, seed=42, mask_generator=torch.Generator().manual_seed(9))
+    for nm, mask in zip(("train", "val", "test"), (m.train_mask, m.val_mask, m.test_mask)):
+        assert torch.equal(mask, unpack_mask(gold[f"E{E}/{nm}"], E))
+    if E == 61484:
+        assert [int(x.sum()) for x in (m.train_mask, m.val_mask, m.test_mask)] == [43038, 9222, 9224]
+    idx, val, mask, sup = m.get_masked_data("train")
+    n_tr = int(m.train_mask.sum())
+    assert idx.shape == (2, n_tr) and val.shape == (n_tr,) and sup.shape == (n_tr,) and torch.equal(mask, m.train_mask)
+    assert torch.equal(sup, torch.rand(n_tr, generator=torch.Generator().manual_seed(9)) < 0.2)
+    assert m.get_masked_data("train")[0] is idx                       # one tensor object per split (pair-cache key)
+    assert bool(m.get_masked_data("val")[3].all())
+    with pytest.raises(ValueError, match="Unknown split"):
+        m.get_masked_data("dev")
+    with pytest.raises(AssertionError):
+        EdgeMasker(g, 0.7, 0.2, 0.2)
+    m.to(g, "cpu")
+    assert m._cache == {} and m.edge_index is g["patient", "has_lab", "lab"].edge_index

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_io import checksum, load, rel_err, t, unpack_mask
+from golden_io import checksum, load, rel_close, rel_err, t, unpack_mask
 from oracle import fixtures as fx
 from oracle import model as om
 from oracle import train as ot
@@ -26,13 +26,15 @@ def dev():
     return torch.device("cuda:0")
 
 
-def make(dev, n, hidden, dropout=0.0):
+def make(dev, n, hidden, dropout=0.0, **model_kw):
     import mmgnn  # noqa: F401
     from mmgnn.model import build_model
     g = fx.graph_from_frames(fx.det_frames(*n))
     gv = om.GraphView(g)
-    sd = fx.det_state(gv.num_nodes, hidden)
-    cfg = {"model": dict(CFG["model"], hidden_dim=hidden, dropout=dropout)}
+    cfg = {"model": dict(CFG["model"], hidden_dim=hidden, dropout=dropout, **model_kw)}
+    sd = fx.det_state(gv.num_nodes, hidden, num_layers=cfg["model"]["num_layers"])
+    if not cfg["model"]["use_batch_norm"]:
+        sd = {k: v for k, v in sd.items() if not k.startswith("batch_norms.")}
     model = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
     gd = g.clone().to(dev)
     model._init_embeddings(gd)
@@ -63,6 +65,8 @@ def test_eval_matches_reference_golden(dev, tag, n, hidden):
         fwd = model(gd)
         pred = model.predict_lab_values(gd, ei[0][te].to(dev), ei[1][te].to(dev))
     assert rel_err(pred.cpu(), t(gold["eval/pred_test"])) <= TOL
+    ok, worst = rel_close(pred.cpu(), t(gold["eval/pred_test"]))          # 1e-4 relative PER VALUE (atol 1e-6 max|ref|)
+    assert ok, f"element-wise relative error {worst:.2f} x the 1e-4 bar"
     for nt in gv.node_types:
         if f"eval/enc/{nt}" in gold:
             assert rel_err(enc[nt].cpu(), t(gold[f"eval/enc/{nt}"])) <= TOL
@@ -108,14 +112,15 @@ def test_train_step_matches_reference_golden(dev, tag, n, hidden):
             assert rel_err(b.cpu(), ref) <= TOL, k
 
 
-def _oracle_masks(ops, dev, seed, p, gv, n_pairs, D):
+def _oracle_masks(ops, dev, seed, p, gv, n_pairs, D, num_layers=2):
     P = gv.num_nodes["patient"]
     m = {}
     for c in (0, 1):
         m[f"enc{c}.drop0"] = ops.dropout_mask(seed, 2 * c, P, D, p, dev).cpu().float()
         m[f"enc{c}.drop1"] = ops.dropout_mask(seed, 2 * c + 1, P, D, p, dev).cpu().float()
-    for ti, nt in enumerate(gv.node_types):
-        m[f"conv0.{nt}"] = ops.dropout_mask(seed, 16 + ti, gv.num_nodes[nt], D, p, dev).cpu().float()
+    for l in range(num_layers - 1):                 # dropout after every conv layer but the last (model.py:267-269)
+        for ti, nt in enumerate(gv.node_types):
+            m[f"conv{l}.{nt}"] = ops.dropout_mask(seed, 16 + 8 * l + ti, gv.num_nodes[nt], D, p, dev).cpu().float()
     m["head.drop0"] = ops.dropout_mask(seed, 64, n_pairs, 64, p, dev).cpu().float()
     m["head.drop1"] = ops.dropout_mask(seed, 65, n_pairs, 32, p, dev).cpu().float()
     return m
@@ -215,6 +220,67 @@ def test_other_hidden_dims_match_oracle(dev, hidden):
     for k, pm in model.named_parameters():
         gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
         assert float((gr - ograds[k]).abs().max()) <= 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax, k
+
+
+def _train_step_vs_oracle(dev, n, hidden, p=0.0, sup_seed=11, **model_kw):
+    """One training step of the HIP model against the oracle on the same inputs (dropout 0 or injected masks):
+    predictions 1e-4 (max-relative AND per value), loss 1e-4, every gradient 2e-4 of its max, BatchNorm buffers 1e-4."""
+    from mmgnn import ops
+    model, g, gd, gv, sd, ei, ea = make(dev, n, hidden, dropout=p, **model_kw)
+    L = model_kw.get("num_layers", 2)
+    tr, va, te = ot.edge_splits(ei.shape[1], 0.7, 0.15, 0.15, 42)
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    w = ot.lab_weights(li, y, gv.num_nodes["lab"])
+    sup = ot.supervision_mask(int(tr.sum()), 0.2, torch.Generator().manual_seed(sup_seed))
+    seed = 424242
+    model._dropout_seed = seed
+    model.train()
+    pred = model.predict_lab_values(gd, pi.to(dev), li.to(dev))
+    loss = ((pred[sup.to(dev)] - y[sup].to(dev)).abs() * w[li[sup]].to(dev)).mean()
+    loss.backward()
+    masks = _oracle_masks(ops, dev, seed, p, gv, pi.numel(), hidden, L) if p > 0 else None
+    oloss, opred, ograds, obufs = ot.train_step_grads(
+        sd, gv, pi, li, y, w, sup, p=p, masks=masks, num_layers=L,
+        use_batch_norm=model_kw.get("use_batch_norm", True), activation=model_kw.get("activation", "relu"))
+    assert rel_err(pred.detach().cpu(), opred) <= TOL
+    ok, worst = rel_close(pred.detach().cpu(), opred)
+    assert ok, f"element-wise relative error {worst:.2f} x the 1e-4 bar"
+    assert abs(float(loss) - float(oloss)) <= TOL * abs(float(oloss))
+    gmax = max(float(v.abs().max()) for v in ograds.values())
+    for k, pm in model.named_parameters():
+        gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
+        assert float((gr - ograds[k]).abs().max()) <= 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax, k
+    for k, b in model.named_buffers():
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == int(obufs[k]), k
+        else:
+            assert rel_err(b.cpu(), obufs[k]) <= TOL, k
+    return model
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_config4_eicu_vocabulary_at_256d(dev, p):
+    """BASELINE.json config 4's model: the eICU vocabulary (1,834 / 50 / 114 / 100) at 256-d -- the bit-plane aggregates
+    with eight 32-column strips / two 128-column chunks and the K = 256 dense kernels, end to end against the oracle."""
+    _train_step_vs_oracle(dev, (1834, 50, 114, 100), 256, p=p, sup_seed=3)
+
+
+@pytest.mark.parametrize("activation", ["elu", "leaky_relu"])
+def test_activation_variants_match_oracle(dev, activation):
+    """model.py:145-152 accepts relu / elu / leaky_relu for the conv layers."""
+    _train_step_vs_oracle(dev, (500, 20, 25, 18), 128, p=0.2, activation=activation)
+
+
+def test_without_batch_norm_matches_oracle(dev):
+    """use_batch_norm = False (model.py:259-261): activation + dropout straight on the HeteroConv sums."""
+    m = _train_step_vs_oracle(dev, (500, 20, 25, 18), 128, p=0.2, use_batch_norm=False)
+    assert m.batch_norms is None
+
+
+@pytest.mark.parametrize("num_layers", [1, 3])
+def test_other_layer_counts_match_oracle(dev, num_layers):
+    """num_layers != 2 (conf/config.yaml model.num_layers): dropout after every layer but the last (model.py:267-269)."""
+    _train_step_vs_oracle(dev, (500, 20, 25, 18), 128, p=0.2, num_layers=num_layers)
 
 
 def test_mimic_schema_vocabulary_matches_oracle(dev):

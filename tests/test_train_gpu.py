@@ -1,0 +1,178 @@
+"""Caller side of the hot path on the GPU: the product's EdgeMasker / Trainer (counterparts of the reference's
+src/train.py:37-176, 183-561) driven in the REFERENCE's call order (train.py:605-642), checkpoint layout (train.py:501-509)
+and reload path (evaluate.py:620-632), frozen-embedding default and the explicit switch, and a multi-epoch
+mask-and-recover run whose imputation metrics are compared with the CPU oracle trained on the same masks."""
+import json
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_io import load, rel_err, t
+from oracle import fixtures as fx
+from oracle import model as om
+from oracle import train as ot
+
+
+def _config(hidden=64, dropout=0.0, epochs=3, opt="adam", lr=1e-3):
+    return {"model": {"architecture": "RGCN", "hidden_dim": hidden, "num_layers": 2, "dropout": dropout,
+                      "use_batch_norm": True, "activation": "relu"},
+            "train": {"optimizer": {"type": opt, "lr": lr, "weight_decay": 1e-5, "momentum": 0.0},
+                      "lr_scheduler": {"enabled": True, "type": "reduce_on_plateau", "factor": 0.5, "patience": 10},
+                      "loss": "mae", "epochs": epochs, "early_stopping_patience": 20, "train_split": 0.7,
+                      "val_split": 0.15, "test_split": 0.15, "mask_fraction": 0.2, "seed": 42, "device": "cuda"},
+            "logging": {"save_checkpoints": True, "checkpoint_interval": 2}}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _reference_order(dev, cfg, n=(300, 12, 15, 10), sd=None, train_embeddings=False, mask_seed=123):
+    """train.py:605-622 of the reference: the masker is built from the CPU graph, THEN Trainer moves model and graph."""
+    import mmgnn  # noqa: F401
+    from mmgnn.model import build_model
+    from mmgnn.train import EdgeMasker, Trainer
+    g = fx.graph_from_frames(fx.det_frames(*n))                      # on the CPU, as torch.load(graph.pt) yields it
+    tc = cfg["train"]
+    masker = EdgeMasker(g, tc["train_split"], tc["val_split"], tc["test_split"], tc["mask_fraction"], tc["seed"],
+                        mask_generator=torch.Generator().manual_seed(mask_seed))
+    model = build_model(cfg, (g.node_types, g.edge_types), None)
+    if sd is not None:
+        model._init_embeddings(g)
+        model.load_state_dict(sd)
+    trainer = Trainer(model, g, masker, cfg, dev, train_embeddings=train_embeddings)
+    return g, masker, model, trainer
+
+
+def test_reference_main_order_trains_and_roundtrips_checkpoint(dev, tmp_path):
+    import mmgnn  # noqa: F401
+    from mmgnn.model import build_model
+    cfg = _config(epochs=3)
+    g, masker, model, trainer = _reference_order(dev, cfg)
+    assert masker.edge_index.device.type == "cuda" and masker.train_mask.device.type == "cuda"      # followed the graph
+    assert trainer.lab_weights.device.type == "cuda"
+    hist = trainer.train(tmp_path)
+    assert len(hist["train_loss"]) == 3 and all(np.isfinite(hist["train_loss"])) and all(np.isfinite(hist["val_loss"]))
+    assert json.load(open(tmp_path / "training_history.json"))["val_loss"] == hist["val_loss"]
+    assert (tmp_path / "best_model.pt").exists() and (tmp_path / "checkpoint_epoch_2.pt").exists()
+    ck = torch.load(tmp_path / "best_model.pt", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "config"}      # train.py:503-509
+    gold, meta = load("model_small.npz")
+    assert list(ck["model_state_dict"].keys()) == meta["state_keys"]                                   # the reference's layout
+    assert ck["val_loss"] == min(hist["val_loss"]) and ck["config"] == cfg
+    n_opt = sum(len(gr["params"]) for gr in ck["optimizer_state_dict"]["param_groups"])
+    assert n_opt == len([p for n, p in model.named_parameters() if not n.startswith("embeddings.")])   # F5: the lazily
+    # created tables are not in the optimizer (train.py:219 runs before model.py:247) -> never updated, while their
+    # .grad is computed
+    ck2 = torch.load(tmp_path / "checkpoint_epoch_2.pt", map_location="cpu", weights_only=False)
+    for k, v in model.state_dict().items():
+        if k.startswith("embeddings."):
+            assert torch.equal(v.cpu(), ck2["model_state_dict"][k]), k
+            assert float(dict(model.named_parameters())[k].grad.abs().sum()) > 0
+    trainer.load_best_model(tmp_path)
+    test_loss = trainer.validate("test")
+    # evaluate.py:620-632: fresh model, _init_embeddings BEFORE load_state_dict; both PyG key manglings load
+    gd = trainer.data
+    pi, li = masker.edge_index[0][masker.test_mask].contiguous(), masker.edge_index[1][masker.test_mask].contiguous()
+    y = masker.edge_attr[masker.test_mask].squeeze(-1)
+    for old_keys in (False, True):
+        sd = ck["model_state_dict"]
+        if old_keys:
+            sd = {(re.sub(r"<(.+)>", lambda m: m.group(1).replace("___", "__"), k)): v for k, v in sd.items()}
+            assert any("patient__has_lab__lab" in k for k in sd)
+        fresh = build_model(cfg, (gd.node_types, gd.edge_types), None).to(dev)
+        fresh._init_embeddings(gd)
+        fresh.load_state_dict(sd)
+        fresh.eval()
+        with torch.no_grad():
+            pred = fresh.predict_lab_values(gd, pi, li)
+        assert abs(float((pred - y).abs().mean()) - test_loss) <= 1e-6 * max(1.0, test_loss)
+
+
+def test_train_epoch_is_the_oracle_step_plus_sgd(dev):
+    """One Trainer.train_epoch = the oracle's fwd + weighted MAE + bwd on the same supervision mask, followed by a plain SGD
+    update of the non-embedding parameters (SGD: the update is linear in the gradient, so the comparison is exact)."""
+    cfg = _config(hidden=64, dropout=0.0, epochs=1, opt="sgd", lr=0.05)
+    n = (300, 12, 15, 10)
+    g0 = fx.graph_from_frames(fx.det_frames(*n))
+    gv = om.GraphView(g0)
+    sd = fx.det_state(gv.num_nodes, 64)
+    g, masker, model, trainer = _reference_order(dev, cfg, n, sd=sd, mask_seed=77)
+    gold, meta = load("model_small.npz")
+    assert rel_err(trainer.lab_weights.cpu(), t(gold["lab_weights"])) <= 1e-5            # train.py:295-330
+    loss = trainer.train_epoch()
+    # the same mask the trainer drew: its generator restarted from the same seed
+    ei, ea = g0["patient", "has_lab", "lab"].edge_index, g0["patient", "has_lab", "lab"].edge_attr
+    tr, _, _ = ot.edge_splits(ei.shape[1])
+    assert torch.equal(masker.train_mask.cpu(), tr)
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    gen = torch.Generator().manual_seed(77)
+    torch.rand(int(tr.sum()), generator=gen)                 # Trainer.__init__ -> _compute_lab_weights draws one mask first
+    sup = torch.rand(int(tr.sum()), generator=gen) < 0.2
+    w = ot.lab_weights(li, y, gv.num_nodes["lab"])
+    oloss, opred, ograds, obufs = ot.train_step_grads(sd, gv, pi, li, y, w, sup, p=0.0)
+    assert abs(loss - float(oloss)) <= 1e-4 * abs(float(oloss))
+    lr, wd = 0.05, 1e-5
+    for k, p in model.named_parameters():
+        # (the tables exist before the optimizer is built here -- a loaded state -- so they are updated as well)
+        # a parameter no output depends on (the last layer's convs into the vocab types) has .grad None: SGD skips it
+        want = sd[k] if p.grad is None else sd[k] - lr * (ograds[k] + wd * sd[k])
+        assert p.grad is not None or float(ograds[k].abs().max()) == 0.0, k
+        assert float((p.detach().cpu() - want).abs().max()) <= lr * (2e-4 * float(ograds[k].abs().max()) + 1e-7), k
+
+
+def test_train_embeddings_switch(dev):
+    cfg = _config(epochs=2, lr=1e-2)
+    g, masker, model, trainer = _reference_order(dev, cfg, train_embeddings=True)
+    before = {k: v.detach().clone() for k, v in model.embeddings.state_dict().items()}
+    trainer.train_epoch(); trainer.train_epoch()
+    after = model.embeddings.state_dict()
+    assert all(float((after[k] - before[k]).abs().max()) > 0 for k in before)   # the switch makes them trainable
+
+
+def test_mask_and_recover_metrics_follow_the_oracle(dev):
+    """BASELINE config 5's parity criterion at test size: several epochs of mask-and-recover training (a new 20 % mask
+    every epoch, injected so that both sides see the same masks), then R^2 / MAE of the imputed TEST labs.  The oracle is
+    trained by the same plain-SGD rule on the CPU; dropout 0 (the device RNG cannot be replayed on the host)."""
+    import mmgnn  # noqa: F401
+    from mmgnn.evaluate import compute_regression_metrics
+    cfg = _config(hidden=64, dropout=0.0, epochs=6, opt="sgd", lr=0.2)
+    n = (900, 50, 200, 100)                                   # the MIMIC-III schema's vocabulary (config.yaml:70,101,112)
+    g0 = fx.graph_from_frames(fx.det_frames(*n))
+    gv = om.GraphView(g0)
+    sd = fx.det_state(gv.num_nodes, 64)
+    g, masker, model, trainer = _reference_order(dev, cfg, n, sd=sd, mask_seed=5)
+    for _ in range(6):
+        trainer.train_epoch()
+    ei, ea = g0["patient", "has_lab", "lab"].edge_index, g0["patient", "has_lab", "lab"].edge_attr
+    tr, va, te = ot.edge_splits(ei.shape[1])
+    pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
+    w = ot.lab_weights(li, y, gv.num_nodes["lab"])
+    gen = torch.Generator().manual_seed(5)
+    torch.rand(int(tr.sum()), generator=gen)
+    cur = {k: v.clone() for k, v in sd.items()}
+    for _ in range(6):
+        sup = torch.rand(int(tr.sum()), generator=gen) < 0.2
+        _, _, grads, bufs = ot.train_step_grads(cur, gv, pi, li, y, w, sup, p=0.0)
+        for k in grads:                                       # (loaded state: the tables are in the optimizer too)
+            if float(grads[k].abs().max()) > 0.0:             # .grad None in autograd: the optimizer skips the tensor
+                cur[k] = cur[k] - 0.2 * (grads[k] + 1e-5 * cur[k])
+        cur.update(bufs)
+    tp, tl, ty = ei[0][te], ei[1][te], ea[te].squeeze(-1)
+    model.eval()
+    with torch.no_grad():
+        pred = model.predict_lab_values(trainer.data, tp.to(dev), tl.to(dev)).cpu()
+    opred, _ = om.predict_lab_values(cur, gv, tp, tl)
+    got = compute_regression_metrics(pred.numpy(), ty.numpy())
+    want = ot.regression_metrics(opred.numpy(), ty.numpy())
+    assert rel_err(pred, opred) <= 2e-3                      # six chained steps: rounding differences compound
+    assert abs(got["mae"] - want["mae"]) <= 1e-3 * want["mae"]
+    assert abs(got["r2"] - want["r2"]) <= 2e-3
+    assert abs(got["rmse"] - want["rmse"]) <= 1e-3 * want["rmse"]
