@@ -323,6 +323,24 @@ int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold,
                     const int64_t* io_perm, float* dpred_sorted, int64_t n_pairs, int32_t* sel_low, int32_t* sel_high,
                     int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Evaluation reducers on the device (src/evaluate.py:36-82 metrics, :417-440 per-lab +-3 sigma winsorisation, :89-141
+ * per-lab rows, :237-342 stratifications).  Every figure evaluate_model reports is a segment sum over the prediction
+ * pairs (segment = lab index, patient-degree bucket, lab-frequency bucket; seg[k] outside [0, n_seg) = not counted), so
+ * the predictions stay on the device and [n_seg, 8] doubles come back.
+ *   mmg_seg_moments: moments[s] = (n, sum r, sum r^2), r = pred - target.
+ *   mmg_seg_metrics: residuals clipped to mean +- n_sigma * std of their segment (population std, segments with > 1
+ *     sample; n_sigma <= 0 or moments NULL: none), adjusted prediction = target + clipped residual (written to
+ *     pred_out when non-NULL); sums[s] = (n, sum |e|, sum e^2, sum t, sum t^2, sum |e/t| over t != 0, count(t != 0),
+ *     count(clipped)) with e = t - adjusted prediction.  fp64 accumulation.  n_seg <= 2048.
+ * ------------------------------------------------------------------------------------- */
+size_t mmg_seg_reduce_ws_bytes(int64_t n, int n_seg);
+int mmg_seg_moments(const float* pred, const float* target, const int64_t* seg, int64_t n, int n_seg,
+                    double* moments, void* ws, size_t ws_bytes, void* stream);
+int mmg_seg_metrics(const float* pred, const float* target, const int64_t* seg, int64_t n, int n_seg,
+                    const double* moments, float n_sigma, float* pred_out, double* sums, void* ws, size_t ws_bytes,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

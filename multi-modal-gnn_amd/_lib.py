@@ -89,6 +89,9 @@ SIGNATURES = {
                                     _vp, _vp, _vp]),
     "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mmg_seg_reduce_ws_bytes": (_sz, [_i64, _i32]),
+    "mmg_seg_moments": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "mmg_seg_metrics": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),
     "mmg_pair_select_ws_bytes": (_sz, [_i64]),
     "mmg_pair_select": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -251,7 +251,7 @@ ScatterPlan plan_scatter(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D
 // The indicator tile holds integer edge COUNTS (ds_add_u32: multi-edges add up, exactly like
 // scatter_add); the rowscale of the tile's relation is applied when the A fragment is read.
 template <int NT, int KT, bool HAS_RS>   // KT = 32-column tiles per workgroup (dc = 32*KT)
-__global__ __launch_bounds__(256, 2) void k_scatter_mfma(RelPack rp, int64_t n_rows, int64_t rows_per_split, int D,
+__global__ __launch_bounds__(256) void k_scatter_mfma(RelPack rp, int64_t n_rows, int64_t rows_per_split, int D,
                                                          const float* __restrict__ x, float* __restrict__ slab) {
   constexpr int NTOT = NT * 32, DC = KT * 32;
   constexpr int NSPLIT = 4 / KT, NTW = NT / NSPLIT;

@@ -9,7 +9,10 @@ and files written as the reference:
   stratify_by_lab_frequency   :290-342   quartiles of the non-zero lab counts
   evaluate_model              :349-570   predict -> per-lab +-3 sigma winsorisation -> metrics -> json / csv
 
-The predictions come from the HIP path (one gather / head launch over all test pairs); the reducers are O(pairs)
+The predictions come from the HIP path (one gather / head launch over all test pairs).  On a HIP device ``evaluate_model``
+reduces them there (``device_*`` below: every reported figure is a segment sum over the pairs -- mmg_seg_moments /
+mmg_seg_metrics -- so only [segments, 8] doubles leave the device instead of the predictions); the host reducers below are
+the same arithmetic in numpy, the checker of the device path (tests/test_evaluate_gpu.py).  The host reducers are O(pairs)
 float64 host arithmetic exactly as in the reference (sklearn's MAE/MSE/R^2 are restated in closed form: sklearn is
 not a dependency of this package).  The per-lab loops are segment reductions over a stable sort instead of one boolean
 mask per lab, which keeps the x1000 scale (92 M test pairs) linear.  Golden parity: tests/test_evaluate_cpu.py.
@@ -166,6 +169,73 @@ def stratify_by_lab_frequency(predictions, targets, lab_indices, graph) -> Dict[
                     "very common (top 25%)": f > q75}, predictions, targets)
 
 
+# ---------------------------------------------------------------------------------------------- device reducers
+def metrics_from_sums(s) -> Dict[str, float]:
+    """MAE / RMSE / R^2 / MAPE from one row (or the sum of rows) of ops.seg_sums:
+    (n, sum|e|, sum e^2, sum t, sum t^2, sum|e/t| over t != 0, count(t != 0), clipped) -- evaluate.py:36-82."""
+    n, s_abs, s_sq, s_t, s_t2, s_ape, n_nz = (float(s[i]) for i in range(7))
+    if n <= 0:
+        return {"mae": float("nan"), "rmse": float("nan"), "r2": float("nan"), "mape": float("nan")}
+    ss_tot = s_t2 - s_t * s_t / n
+    if s_sq == 0:
+        r2 = 1.0
+    elif ss_tot > 1e-12 * max(s_t2, 1e-300):
+        r2 = 1.0 - s_sq / ss_tot
+    else:
+        r2 = 0.0                                   # constant target, non-zero residual (sklearn's force_finite)
+    mape = s_ape / n_nz * 100.0 if n_nz > 0 else float("nan")
+    return {"mae": s_abs / n, "rmse": float(np.sqrt(s_sq / n)), "r2": r2, "mape": mape}
+
+
+def device_evaluate(predictions: torch.Tensor, targets: torch.Tensor, patient_indices: torch.Tensor,
+                    lab_indices: torch.Tensor, graph, lab_names: Dict[int, str], stratify=(), n_sigma: float = 3.0):
+    """Everything evaluate_model reports, from device-side segment sums (one D2H copy of a few [segments, 8] doubles):
+    -> (overall metrics, number of clipped residuals, per-lab DataFrame, stratified results)."""
+    from . import ops
+    n_labs = int(graph["lab"].num_nodes)
+    li64 = lab_indices.to(torch.int64).contiguous()
+    # per-lab +-3 sigma winsorisation, then the per-lab sums of the ADJUSTED predictions; overall = their total
+    sums, adj = ops.seg_sums(predictions.contiguous(), targets.contiguous(), li64, n_labs, n_sigma, want_adjusted=bool(stratify))
+    per_lab = sums.cpu().numpy()
+    overall = metrics_from_sums(per_lab.sum(0))
+    num_capped = int(round(per_lab[:, 7].sum()))
+    rows = []
+    for j in range(n_labs):
+        if per_lab[j, 0] < 2:
+            continue
+        m = metrics_from_sums(per_lab[j])
+        m["lab_index"], m["lab_name"], m["num_samples"] = j, lab_names.get(j, f"Lab_{j}"), int(per_lab[j, 0])
+        rows.append(m)
+    per_lab_df = pd.DataFrame(rows)
+    if len(per_lab_df):
+        per_lab_df = per_lab_df.sort_values("mae")
+    strat = {}
+    ei = graph["patient", "has_lab", "lab"].edge_index
+    if "num_labs" in stratify:                       # evaluate.py:237-287: 1-5 / 6-15 / 16+ observed labs
+        deg = torch.bincount(ei[0], minlength=int(graph["patient"].num_nodes))[patient_indices]
+        seg = torch.full_like(deg, -1)
+        seg[(deg >= 1) & (deg <= 5)] = 0
+        seg[(deg >= 6) & (deg <= 15)] = 1
+        seg[deg >= 16] = 2
+        g = ops.seg_sums(adj, targets.contiguous(), seg.contiguous(), 3)[0].cpu().numpy()
+        strat["by_patient_degree"] = {nm: dict(metrics_from_sums(g[i]), num_samples=int(g[i, 0]))
+                                      for i, nm in enumerate(("low (1-5 labs)", "medium (6-15 labs)", "high (16+ labs)"))
+                                      if g[i, 0] > 0}
+    if "lab_frequency" in stratify:                  # evaluate.py:290-342: quartiles of the non-zero lab counts
+        counts = torch.bincount(ei[1], minlength=n_labs)
+        cn = counts.cpu().numpy()
+        q25, q75 = np.percentile(cn[cn > 0], 25), np.percentile(cn[cn > 0], 75)
+        f = counts[li64].double()
+        seg = torch.ones_like(li64)
+        seg[f < q25] = 0
+        seg[f > q75] = 2
+        g = ops.seg_sums(adj, targets.contiguous(), seg.contiguous(), 3)[0].cpu().numpy()
+        strat["by_lab_frequency"] = {nm: dict(metrics_from_sums(g[i]), num_samples=int(g[i, 0]))
+                                     for i, nm in enumerate(("rare (bottom 25%)", "common (middle 50%)",
+                                                             "very common (top 25%)")) if g[i, 0] > 0}
+    return overall, num_capped, per_lab_df, strat
+
+
 @torch.no_grad()
 def evaluate_model(model, graph, test_edges, config: Dict, output_dir) -> Dict:
     """evaluate.py:349-570.  ``model`` is this package's HeteroRGCN (or anything with ``eval()``, ``parameters()`` and
@@ -181,6 +251,27 @@ def evaluate_model(model, graph, test_edges, config: Dict, output_dir) -> Dict:
 
     predictions = model.predict_lab_values(graph, patient_indices, lab_indices)
 
+    ev = config["evaluation"]
+    if predictions.is_cuda:
+        # HIP device: every reducer runs there (segment sums); the predictions never travel to the host
+        lab_store = graph["lab"]
+        meta = getattr(lab_store, "metadata", None) if "metadata" in lab_store else None
+        lab_names = ({idx: m["label"] for idx, m in meta.items()} if meta
+                     else {i: f"Lab_{i}" for i in range(graph["lab"].num_nodes)})
+        overall_metrics, num_capped, per_lab_df, stratified_results = device_evaluate(
+            predictions, edge_values.reshape(-1).float(), patient_indices, lab_indices, graph, lab_names,
+            stratify=tuple(ev.get("stratify_by") or ()))
+        logging.info(f"  Capped {num_capped}/{predictions.numel()} outlier residuals")
+        logging.info(f"Overall: MAE {overall_metrics['mae']:.4f} RMSE {overall_metrics['rmse']:.4f} "
+                     f"R2 {overall_metrics['r2']:.4f} MAPE {overall_metrics['mape']:.2f}%")
+        if ev.get("per_lab_metrics", True):
+            per_lab_df.to_csv(output_dir / "per_lab_metrics.csv", index=False)
+        all_results = {"overall_metrics": overall_metrics, "num_test_samples": int(predictions.numel()),
+                       "stratified_results": stratified_results}
+        with open(output_dir / "evaluation_results.json", "w") as f:
+            json.dump(all_results, f, indent=2)
+        return all_results
+
     predictions_np = predictions.cpu().numpy()
     targets_np = edge_values.cpu().numpy()
     patient_indices_np = patient_indices.cpu().numpy()
@@ -193,7 +284,6 @@ def evaluate_model(model, graph, test_edges, config: Dict, output_dir) -> Dict:
     logging.info(f"Overall: MAE {overall_metrics['mae']:.4f} RMSE {overall_metrics['rmse']:.4f} "
                  f"R2 {overall_metrics['r2']:.4f} MAPE {overall_metrics['mape']:.2f}%")
 
-    ev = config["evaluation"]
     if ev.get("per_lab_metrics", True):
         lab_store = graph["lab"]
         meta = getattr(lab_store, "metadata", None) if "metadata" in lab_store else None

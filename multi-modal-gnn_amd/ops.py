@@ -607,3 +607,26 @@ class _PairLossFn(torch.autograd.Function):
 def weighted_pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae", inv_den_dev=None):
     """Differentiable fused loss: inv_den * sum sup*w*|pred-y| (or squared); w/sup are per-pair float vectors."""
     return _PairLossFn.apply(pred, y, w, sup, inv_den, loss_type, inv_den_dev)
+
+
+# ------------------------------------------------------------------------------------------ evaluation reducers
+def seg_sums(pred: torch.Tensor, target: torch.Tensor, seg: torch.Tensor, n_seg: int, n_sigma: float = 0.0,
+             want_adjusted: bool = False):
+    """Segment sums of the evaluation metrics (mmg_seg_moments + mmg_seg_metrics) -> (sums fp64 [n_seg, 8], adjusted
+    predictions or None).  sums[s] = (n, sum|e|, sum e^2, sum t, sum t^2, sum|e/t| over t != 0, count(t != 0), clipped).
+    n_sigma > 0: residuals are clipped to mean +- n_sigma * std of their segment first (evaluate.py:417-440)."""
+    lib = _lib.load()
+    n = pred.numel()
+    dev = pred.device
+    ws = workspace(lib.mmg_seg_reduce_ws_bytes(n, n_seg), dev)
+    moments = None
+    if n_sigma > 0:
+        moments = torch.empty(n_seg, 3, dtype=torch.float64, device=dev)
+        check(lib.mmg_seg_moments(_p(pred), _p(target), _p(seg, torch.int64), n, n_seg, _p(moments, torch.float64),
+                                  _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_seg_moments")
+    sums = torch.empty(n_seg, 8, dtype=torch.float64, device=dev)
+    adj = torch.empty_like(pred) if want_adjusted else None
+    check(lib.mmg_seg_metrics(_p(pred), _p(target), _p(seg, torch.int64), n, n_seg, _p(moments, torch.float64),
+                              float(n_sigma), _p(adj), _p(sums, torch.float64), _p(ws, torch.uint8), ws.numel(), _stream()),
+          "mmg_seg_metrics")
+    return sums, adj

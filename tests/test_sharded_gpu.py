@@ -329,3 +329,76 @@ def test_single_graph_step_matches_eager_steps(overlap, monkeypatch):
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         if not n.startswith("embeddings."):
             assert float((p1 - p2).detach().abs().max()) <= 1e-4 * float(p1.detach().abs().max()) + 1e-6, n
+
+
+def test_rccl_backend_carries_the_sharded_step():
+    """The real collective backend under the sharded step: torch.distributed 'nccl' (= RCCL on ROCm) with world_size 1.
+    A one-rank group cannot show scaling, but every all-reduce of the step -- Sync-BN statistics (fp64), vocab partial
+    sums, the lab-side head gradients, the flat gradient bucket -- goes through ShardComm -> RCCL between the hipGraph
+    segments of PiecewiseGraphedTrainStep, exactly as on N GPUs; results must equal the unsharded eager step."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    import socket
+    import torch.distributed as dist
+    import mmgnn  # noqa: F401
+    from mmgnn import dist as md, ops
+    from mmgnn.data import build_plan
+    from mmgnn.model import build_model
+    from mmgnn.train import PiecewiseGraphedTrainStep
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        g = fx.graph_from_frames(fx.det_frames(900, 20, 25, 18)).to(dev)
+        ei = g["patient", "has_lab", "lab"].edge_index
+        sel = torch.arange(0, ei.shape[1], 2, device=dev)
+        pi, li = ei[0][sel].contiguous(), ei[1][sel].contiguous()
+        y = g["patient", "has_lab", "lab"].edge_attr[sel].squeeze(-1).contiguous()
+        sup = (torch.arange(sel.numel(), device=dev) % 5 == 0)
+        wlab = torch.rand(int(g["lab"].num_nodes), generator=torch.Generator().manual_seed(3)).to(dev) + 0.5
+        n_sup = float(sup.sum())
+
+        def make(sharded):
+            torch.manual_seed(7)
+            m = build_model(CFG, (g.node_types, g.edge_types), None).to(dev)
+            m._init_embeddings(g)
+            plan = build_plan(g, dev, use_cache=False)
+            comm = None
+            if sharded:
+                comm = md.ShardComm()
+                md.shard_plan(plan, comm, 0, plan.n_rows)
+                md.shard_model(m, comm)
+            opt = torch.optim.SGD([p for n, p in m.named_parameters() if not n.startswith("embeddings.")], lr=0.05,
+                                  momentum=0.9)
+            return m, plan, comm, opt
+
+        m1, plan1, _, opt1 = make(False)
+        losses1 = []
+        for _ in range(3):
+            m1.train()
+            m1.zero_grad(set_to_none=True)
+            pred = m1.predict_lab_values(plan1, pi, li)
+            loss = ops.weighted_pair_loss(pred, y, wlab[li].contiguous(), sup.float(), 1.0 / n_sup, "mae")
+            loss.backward()
+            opt1.step()
+            losses1.append(float(loss))
+        m2, plan2, comm2, opt2 = make(True)
+        step = PiecewiseGraphedTrainStep(m2, plan2, pi, li, y, wlab, opt2, sup, comm2, warmup=1)   # n_sup all-reduced inside
+        n_coll = sum(1 for k, _ in step.items if k == "all_reduce")
+        assert n_coll >= 10 and comm2.n_bytes > 0
+        losses2 = [float(step.step()) for _ in range(3)]
+        for a, b in zip(losses1, losses2):
+            assert abs(a - b) <= 2e-5 * abs(a), (losses1, losses2)
+        for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            if not n.startswith("embeddings."):
+                assert float((p1 - p2).detach().abs().max()) <= 1e-4 * float(p1.detach().abs().max()) + 1e-6, n
+        # a new supervision subset of another size: the normaliser follows it (device scalar, all-reduced over the group)
+        sup2 = (torch.arange(sel.numel(), device=dev) % 3 == 0)
+        step.set_mask(sup2)
+        assert abs(float(step._sv.inv_den) - 1.0 / float(sup2.sum())) <= 1e-12
+        assert torch.isfinite(step.step())
+    finally:
+        dist.destroy_process_group()
