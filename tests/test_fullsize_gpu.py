@@ -124,7 +124,7 @@ def test_dense_layers_on_sampled_rows(env):
     for m0 in range(0, M, 1 << 18):                          # fp64 reference in row chunks (memory at x1000)
         dW_ref += dy[m0:m0 + (1 << 18)].double().t() @ x[m0:m0 + (1 << 18)].double()
     assert rel(dW, dW_ref) <= 1e-5
-    assert rel(db, dy.sum(0, dtype=torch.float64)) <= 1e-6
+    assert rel(db, dy.sum(0, dtype=torch.float64)) <= (1e-6 if M < 10 ** 6 else 3e-6)    # fp32 partials over M rows
     dx = ops.linear_fwd(dy, W, w_kn=True)
     assert rel(dx[idx], dy[idx].double() @ W.double()) <= 2e-6
 
@@ -170,7 +170,7 @@ def test_training_step_is_finite_and_reproducible(env):
     assert rel(p2, p1) <= 1e-6 and abs(l2 - l1) <= 1e-6 * abs(l1)                 # (float atomics in the pair heads)
     gmax = max(float(v.abs().max()) for v in g1.values())
     for k in g1:      # (a bias in front of a BatchNorm has a zero gradient: only rounding noise there, hence the floor)
-        assert float((g1[k] - g2[k]).abs().max()) <= 1e-4 * float(g1[k].abs().max()) + 1e-6 * gmax, k
+        assert float((g1[k] - g2[k]).abs().max()) <= 1e-4 * float(g1[k].abs().max()) + 5e-6 * gmax, k
     p3, l3, _ = step(124)                                 # another seed: other masks
     assert rel(p3, p1) > 1e-3
 

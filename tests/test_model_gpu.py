@@ -246,10 +246,22 @@ def _train_step_vs_oracle(dev, n, hidden, p=0.0, sup_seed=11, **model_kw):
     ok, worst = rel_close(pred.detach().cpu(), opred)
     assert ok, f"element-wise relative error {worst:.2f} x the 1e-4 bar"
     assert abs(float(loss) - float(oloss)) <= TOL * abs(float(oloss))
+    # ReLU ties: a pre-activation within fp32 rounding of 0 sends its gradient to one side or the other depending on the
+    # summation order -- the oracle's own fp32 and fp64 runs disagree there (e.g. patient row 1179 of the eICU-shape
+    # fixture at 256-d).  Where they do, the gap between the two oracle runs is added to the tolerance; everywhere else
+    # the bar is 2e-4 of the gradient's max.
+    sd64 = om.cast_state(sd, torch.float64)
+    masks64 = {k: v.double() for k, v in masks.items()} if masks else None
+    _, _, ograds64, _ = ot.train_step_grads(
+        sd64, gv, pi, li, y.double(), w.double(), sup, p=p, masks=masks64, num_layers=L,
+        use_batch_norm=model_kw.get("use_batch_norm", True), activation=model_kw.get("activation", "relu"))
     gmax = max(float(v.abs().max()) for v in ograds.values())
     for k, pm in model.named_parameters():
         gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
-        assert float((gr - ograds[k]).abs().max()) <= 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax, k
+        tie = (ograds[k].double() - ograds64[k]).abs()
+        tol = 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax + 1.5 * tie
+        assert int((tie > 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax).sum()) <= max(2 * hidden, tie.numel() // 500), k
+        assert bool(((gr - ograds[k]).abs().double() <= tol).all()), k
     for k, b in model.named_buffers():
         if k.endswith("num_batches_tracked"):
             assert int(b) == int(obufs[k]), k
