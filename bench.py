@@ -259,8 +259,8 @@ def op_summary(table, op, flags_mask=None, flags_val=None):
     out = dict(big)
     fol = [t for t in table if FOLLOWERS.get(t["kernel"]) == op and t["M"] == big["M"] and t["N"] == big["N"]]
     if fol:
-        # the follower serves every launch of the op with this (M, N): average per launch
-        n_op = sum(t["launches_per_step"] for t in cand if t["M"] == big["M"] and t["N"] == big["N"])
+        # the follower serves every launch of the op with this (M, N), whatever its flags: average per launch
+        n_op = sum(t["launches_per_step"] for t in table if t["kernel"] == op and t["M"] == big["M"] and t["N"] == big["N"])
         f_ms = sum(t["ms_per_step"] for t in fol) / max(n_op, 1e-9)
         out["follower_avg_ms"] = f_ms
         out["avg_ms_with_follower"] = big["avg_ms"] + f_ms
@@ -300,7 +300,7 @@ def load_traffic(args, scale, strong):
     kernel only when its algorithmic bytes match the profiled launch shape."""
     if scale != 100 or args.dim != 128 or strong:
         return {}, None
-    for name in ("r2_traffic_x100.json", "r1_traffic_x100.json"):
+    for name in ("r2_traffic_x100.json",):
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
             try:

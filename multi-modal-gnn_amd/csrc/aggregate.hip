@@ -1034,6 +1034,201 @@ __global__ __launch_bounds__(512) void k_gather_bits(RelPack rp, int64_t n_rows,
   else gather_bits_body<NK, K1, K2, ACCUM, 1>(rp, n_rows, n_tile_total, D, out, lut, rss, xch, stat_partial);
 }
 
+// ------------------------------------------------------------------------------ gather, unit-per-wave layout
+// k_gather_bits above needs its relation boundaries at compile time (the eICU vocabulary).  Every other layout of simple
+// relations up to 768 padded items -- the MIMIC-III schema's 50 / 200 / 100 (conf/config.yaml:70,101,112 of the
+// reference) among them -- takes this kernel: a wave owns one feature tile and ONE unit = up to GU_KU k-steps (16 items
+// each) of ONE relation, keeps that unit's three bf16 table pieces in registers, and its relation's mean scale is one
+// vector per wave; the units' scaled partial tiles are summed through LDS in fixed order (unit 0 + 1 + 2 ...) by the
+// unit-0 wave, which also accumulates into `out` and takes the BatchNorm column sums.  Same arithmetic as k_gather_bits.
+constexpr int GU_KU = 8;          // k-steps per unit (128 items): 96 registers of table pieces
+constexpr int GU_MAXU = 6;        // units per launch
+struct GaUnits {
+  int rel[GU_MAXU], ks0[GU_MAXU], nks[GU_MAXU];   // relation, first k-step inside it (even), k-steps (even, <= GU_KU)
+  int nf[GU_MAXU];                                // uint16 fields per (row, half) of that relation = padded items / 16
+  int n_units, FT;                                // feature tiles (32 columns) per workgroup: waves = FT * n_units
+};
+
+template <bool ACCUM>
+__global__ __launch_bounds__(512) void k_gather_units(GaUnits gu, RelPack rp, int64_t n_rows, int n_tile_total, int D,
+                                                      float* __restrict__ out, double* __restrict__ stat_partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gu_lds[];
+  unsigned (*lut)[4] = reinterpret_cast<unsigned (*)[4]>(gu_lds);                      // [256][4]
+  float* rss_all = reinterpret_cast<float*>(gu_lds + 4096);                             // [waves <= 8][32]
+  float* xch = reinterpret_cast<float*>(gu_lds + 4096 + 8 * 32 * 4);                    // [2][FT][U - 1][16][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int FT = gu.FT, U = gu.n_units;
+  const int ft = wid % FT, u = wid / FT;
+  if (tid < 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
+  }
+  __syncthreads();
+  const int dcol = (blockIdx.y * FT + ft) * 32 + l31;
+  const RelDev& R = rp.r[gu.rel[u]];
+  const int ks0 = gu.ks0[u], nks = gu.nks[u], nf = gu.nf[u];
+  // ---- table pieces of this unit: B[k = item 16 (ks0 + q) + 8 h + j][n = this lane's feature column], pre-scaled by
+  // colscale; every load is issued before any is used (indices clamped, no branch in between)
+  bf16x8 tb[GU_KU][3];
+#pragma unroll
+  for (int q0 = 0; q0 < GU_KU; q0 += 2) {           // two k-steps at a time: 32 loads in flight, 32 registers of staging
+    float tv[2][8], cv[2][8];
+    const float* cs = R.colscale ? R.colscale : R.table;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int q = q0 + qq, item = (ks0 + q) * 16 + 8 * h + j;
+        const int ic = (q < nks && item < R.n_cols) ? item : 0;
+        tv[qq][j] = R.table[(size_t)ic * D + dcol];
+        cv[qq][j] = cs[ic];
+      }
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = q0 + qq;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int item = (ks0 + q) * 16 + 8 * h + j;
+        const float t = R.colscale ? tv[qq][j] * cv[qq][j] : tv[qq][j];
+        v[j] = (q < nks && item < R.n_cols) ? t : 0.f;
+      }
+      split8(v, tb[q][0], tb[q][1], tb[q][2]);
+    }
+  }
+  const int t_step = gridDim.x;
+  const int64_t last_row = n_rows - 1;
+  const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(unsigned)(n_rows * D * 4), 0x00020000);
+  const unsigned row_bytes = (unsigned)D * 4u;
+  const unsigned* mrow = reinterpret_cast<const unsigned*>(R.mask_r);
+  unsigned mcur[GU_KU / 2], mnxt[GU_KU / 2];
+  float rsn = 1.f, prev[16];
+  auto loadm = [&](int tile, unsigned* dst) {                       // this lane's patient (l31) and item half (h)
+    int64_t row = (int64_t)tile * 32 + l31;
+    if (row > last_row) row = last_row;
+    const size_t base = ((size_t)row * 2 + h) * (nf / 2) + ks0 / 2;
+#pragma unroll
+    for (int i = 0; i < GU_KU / 2; ++i) dst[i] = mrow[base + (2 * i < nks ? i : 0)];
+  };
+  auto loadrs = [&](int tile) -> float {
+    int64_t row = (int64_t)tile * 32 + l31;
+    if (row > last_row) row = last_row;
+    return R.rowscale ? R.rowscale[row] : 1.f;
+  };
+  auto loadprev = [&](int tile, float* dst) {
+    const unsigned vo = ((unsigned)(tile * 32 + 4 * h) * (unsigned)D + (unsigned)dcol) * 4u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0));
+  };
+  float* rss = rss_all + wid * 32;
+  double cs1 = 0.0, cs2 = 0.0;
+  int tile = blockIdx.x;
+  if (tile < n_tile_total) {
+    loadm(tile, mcur); rsn = loadrs(tile);
+    if (ACCUM && u == 0) loadprev(tile, prev);
+  }
+  int par = 0;
+  for (; tile < n_tile_total; tile += t_step, par ^= 1) {
+    const int tn = tile + t_step < n_tile_total ? tile + t_step : tile;
+    loadm(tn, mnxt);
+    if (h == 0) rss[l31] = rsn;                                      // private to this wave
+    rsn = loadrs(tn);
+    float pc[16];
+    if (ACCUM && u == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pc[i] = prev[i];
+      loadprev(tn, prev);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < GU_KU; ++q)
+      if (q < nks) {                                                 // wave-uniform
+        const unsigned off = __builtin_amdgcn_ubfe(mcur[q >> 1], 16u * (q & 1), 12u);
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][2], acc, 0, 0, 0);
+      }
+    // scaled partial in the C layout: register i <-> patient row (i & 3) + 8 (i >> 2) + 4 h, lane <-> feature column
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4s sc = *reinterpret_cast<const f32x4s*>(&rss[8 * q + 4 * h]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * q + e] = sc[e] * acc[4 * q + e];
+    }
+    float* xb = xch + ((size_t)(par * FT + ft) * (U - 1)) * (16 * 64);
+    if (u > 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xb[((size_t)(u - 1) * 16 + i) * 64 + lane] = v[i];
+    }
+    __syncthreads();
+    if (u == 0) {
+      const unsigned vo = ((unsigned)(tile * 32 + 4 * h) * (unsigned)D + (unsigned)dcol) * 4u;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float t = v[i];
+        for (int uu = 1; uu < U; ++uu) t += xb[((size_t)(uu - 1) * 16 + i) * 64 + lane];     // fixed order
+        if (ACCUM) t += pc[i];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0);
+        if ((int64_t)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < n_rows) { t1 += t; t2 = fmaf(t, t, t2); }
+      }
+      if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }
+    }
+#pragma unroll
+    for (int i = 0; i < GU_KU / 2; ++i) mcur[i] = mnxt[i];
+  }
+  if (stat_partial && u == 0) {               // the two lane halves hold different rows of the same column
+    cs1 += __shfl_xor(cs1, 32, 64);
+    cs2 += __shfl_xor(cs2, 32, 64);
+    if (h == 0) {
+      stat_partial[((size_t)blockIdx.x * 2 + 0) * D + dcol] = cs1;
+      stat_partial[((size_t)blockIdx.x * 2 + 1) * D + dcol] = cs2;
+    }
+  }
+}
+
+struct GaPlan { GaUnits gu; bool ok; int waves; size_t lds; };
+GaPlan plan_gather_units(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
+  GaPlan gp{};
+  gp.ok = false;
+  if (D % 32 || n_rows < 32 || (uint64_t)n_rows * (uint64_t)D * 4u >= (1ull << 31)) return gp;
+  int U = 0;
+  for (int r = 0; r < n_rel; ++r) {
+    if (rels[r].n_cols == 0) continue;
+    if ((rels[r].flags & MMG_REL_SIMPLE) == 0 || rels[r].mask_r == nullptr) return gp;
+    const int padc = pad32(rels[r].n_cols), nk = padc / 16;
+    const int chunks = (nk + GU_KU - 1) / GU_KU;
+    int k0 = 0;
+    for (int c = 0; c < chunks; ++c) {
+      int n = (nk - k0 + (chunks - c) - 1) / (chunks - c);
+      n = (n + 1) & ~1;                                  // even: fields are read as dwords
+      if (n > nk - k0) n = nk - k0;
+      if (U >= GU_MAXU) return gp;
+      gp.gu.rel[U] = r; gp.gu.ks0[U] = k0; gp.gu.nks[U] = n; gp.gu.nf[U] = padc / 16;
+      ++U; k0 += n;
+    }
+  }
+  if (U == 0) return gp;
+  gp.gu.n_units = U;
+  // two waves per SIMD (<= 256 registers: 96 of table pieces, the accumulator, the previous output tile, ...)
+  const int tiles_d = D / 32;
+  int FT = 4;
+  while (FT > 1 && (FT * U > 8 || tiles_d % FT)) FT >>= 1;
+  gp.gu.FT = FT;
+  gp.waves = FT * U;
+  gp.lds = 4096 + 8 * 32 * 4 + (size_t)2 * FT * (U > 1 ? U - 1 : 1) * 16 * 64 * 4;
+  gp.ok = gp.waves <= 8;
+  return gp;
+}
+
 // row-major bit planes: field [row][half][col / 16] (uint16) |= 1 << (4 + col % 8), half = (col % 16) / 8
 __global__ __launch_bounds__(256) void k_mask_build_rows(const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ col, int64_t n_rows, int nf,
@@ -1189,6 +1384,32 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
       if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       MMG_CHECK_LAUNCH("gather_rows(bits)");
+      if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
+      return MMG_OK;
+    }
+  }
+  // any other layout of simple relations with bit planes: one unit (<= 128 items of one relation) per wave
+  {
+    const GaPlan gp = plan_gather_units(rels, n_rel, n_rows, D);
+    if (gp.ok) {
+      const int n_tiles = (int)((n_rows + 31) / 32);
+      const int gy = (D / 32) / gp.gu.FT;
+      int g = 256 / gy;
+      if (g < 1) g = 1;
+      if (g > n_tiles) g = n_tiles;
+      if (g > 256) g = 256;                              // <= 256 partial statistic rows (workspace)
+      dim3 grid((unsigned)g, (unsigned)gy);
+      constexpr int lds_max = 4096 + 8 * 32 * 4 + 2 * 4 * 5 * 16 * 64 * 4;
+      if (accumulate) {
+        MMG_CHECK_HIP((MmgMaxLds<&k_gather_units<true>, lds_max>::set()), "gather_rows(attr)");
+        MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1 | 32, k_gather_units<true>, grid, dim3(64 * gp.waves), gp.lds, st,
+                   gp.gu, rp, n_rows, n_tiles, D, out, partial);
+      } else {
+        MMG_CHECK_HIP((MmgMaxLds<&k_gather_units<false>, lds_max>::set()), "gather_rows(attr)");
+        MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 32, k_gather_units<false>, grid, dim3(64 * gp.waves), gp.lds, st,
+                   gp.gu, rp, n_rows, n_tiles, D, out, partial);
+      }
+      MMG_CHECK_LAUNCH("gather_rows(units)");
       if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
       return MMG_OK;
     }

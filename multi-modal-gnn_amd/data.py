@@ -183,6 +183,13 @@ def build_plan(data, device=None, validate: bool = True, use_cache: bool = True)
     P = num_nodes[ROW_TYPE]
     plan = GraphPlan(node_types, edge_types, num_nodes, device, n_rows_global=P, key=key)
     shared: Dict[Tuple[str, str], Tuple[torch.Tensor, RelCSR]] = {}
+    # adjacency bit planes are only built where a kernel can take them: the matrix-core aggregates hold <= 768 padded
+    # items per launch (24 tiles of 32; every patient relation of one direction is fused into one launch), so a larger
+    # vocabulary -- e.g. 3,000 diagnosis codes -- keeps the CSR kernels and allocates no masks (they would be
+    # P * items / 4 bytes each)
+    others = {(e[0] if e[2] == ROW_TYPE else e[2]) for e in edge_types
+              if (e[0] == ROW_TYPE) != (e[2] == ROW_TYPE)}
+    masks_fit = sum((num_nodes[o] + 31) // 32 * 32 for o in others) <= 768
     for et in edge_types:
         s, _, d = et
         if (s == ROW_TYPE) == (d == ROW_TYPE):
@@ -218,7 +225,7 @@ def build_plan(data, device=None, validate: bool = True, use_cache: bool = True)
             cnt, inv_col = ops.col_degree(col, num_nodes[other])
             prow = ei[1] if patient_is_dst else ei[0]
             ocol = ei[0] if patient_is_dst else ei[1]
-            simple = E == 0 or int(torch.unique(prow * num_nodes[other] + ocol).numel()) == E     # one-off check
+            simple = masks_fit and (E == 0 or int(torch.unique(prow * num_nodes[other] + ocol).numel()) == E)  # one-off
             mask_t, mask_r = ops.rel_mask_build(rowptr, col, num_nodes[other]) if simple and P > 0 else (None, None)
             rel = RelCSR(et, other, patient_is_dst, num_nodes[other], rowptr, col, perm, inv_row, inv_col, cnt, E,
                          simple, mask_t, mask_r)

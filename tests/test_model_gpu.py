@@ -295,6 +295,16 @@ def test_other_layer_counts_match_oracle(dev, num_layers):
     _train_step_vs_oracle(dev, (500, 20, 25, 18), 128, p=0.2, num_layers=num_layers)
 
 
+def test_large_vocabulary_without_bit_planes_matches_oracle(dev):
+    """A vocabulary beyond the matrix-core aggregates' 768 padded items (900 diagnosis codes): no adjacency bit planes
+    are allocated, the CSR kernels (tables through L2 / global float atomics) carry the aggregates -- same results."""
+    from mmgnn.data import build_plan
+    m = _train_step_vs_oracle(dev, (400, 30, 900, 40), 128, p=0.0)
+    g = fx.graph_from_frames(fx.det_frames(400, 30, 900, 40)).to(dev)
+    plan = build_plan(g, dev, use_cache=False)
+    assert all(r.mask_t is None and r.mask_r is None for r in plan.rels.values())
+
+
 def test_mimic_schema_vocabulary_matches_oracle(dev):
     """BASELINE.json config 5: the MIMIC-III schema keeps the top 50 labs / 200 diagnoses / 100 medications
     (conf/config.yaml:70,101,112) -- a vocabulary layout other than eICU's (64 | 224 | 128 padded item rows)."""
