@@ -307,11 +307,16 @@ int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* 
                       const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
                       float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
                       float* pred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream);
+/* Backward: the weight-side gradients (dW2, db2, dW3, db3, dB) leave every workgroup as ONE partial slab in `ws` and are
+ * summed in fixed order (bitwise reproducible); dA rows are flushed per patient run (pairs sorted by patient: a row
+ * receives at most two partial sums unless one patient holds more than 32 listed pairs). */
+size_t mmg_pair_head_bwd_ws_bytes(int64_t n_pairs, int n_labs);
 int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,
                       const int32_t* pi, const int32_t* li, const int32_t* deg, int degree_threshold,
                       int want_low, int64_t n_pairs, int n_labs, float drop_p, uint64_t seed,
                       const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred,
-                      const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream);
+                      const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
+                      void* ws, size_t ws_bytes, void* stream);
 
 /* Stable two-way compaction of pair positions by head: position k goes to sel_low if deg[pi[k]] < threshold,
  * else to sel_high -- and only if dpred is NULL or dpred[k] != 0.  Order inside a list = pair order (pairs sorted

@@ -87,8 +87,9 @@ SIGNATURES = {
     "mmg_dropout_mask": (C.c_int, [_u64, _vp, _u32, _i64, _i64, _f32, _vp, _vp]),
     "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
+    "mmg_pair_head_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64,
-                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmg_seg_reduce_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_seg_moments": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "mmg_seg_metrics": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),

@@ -245,6 +245,8 @@ __device__ __forceinline__ void layer2_fields(uint32_t key, const unsigned* PLo,
   bits[14] = quad_bcast_field<14>(hw0, hw1, sub); bits[15] = quad_bcast_field<15>(hw0, hw1, sub);
 }
 
+__host__ __device__ constexpr int pair_slab_floats(int LT) { return 2048 + LT * 2048 + 68; }
+
 template <int LT, bool AUX>       // AUX: io_perm and / or pair_id are present (else neither is loaded)
 __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                        const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
@@ -252,11 +254,13 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
                                                        uint64_t seed, const uint64_t* __restrict__ seed_ptr,
                                                        const int64_t* __restrict__ pair_id,
                                                        const float* __restrict__ dpred, const int32_t* __restrict__ sel,
-                                                       const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io) {
+                                                       const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io,
+                                                       float* __restrict__ slab) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) n = *n_sel;                   // compacted pair list (device-resident length): see mmg_pair_select
   __shared__ __attribute__((aligned(16))) float sm[4 * WAVE_LDS];
   __shared__ __attribute__((aligned(16))) float W2s[32 * LDH];      // W2[u][k], row stride LDH (shared by the 4 waves)
+  __shared__ float tail_red[4][68];                                 // per wave: dW3[32] | db2[32] | db3
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   float* H1s = sm + wid * WAVE_LDS;                 // [32][LDH]  (later: dH1 tile)
@@ -544,25 +548,59 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
     }
     __syncthreads();
   }
+  // One partial slab per workgroup, summed over the workgroups in FIXED order by mmg_k_reduce_slabs (global float
+  // atomics here made the weight gradients depend on the order in which the workgroups finished):
+  //   [0, 2048) dW2[u][k] | [2048, 2048 + LT * 2048) dB[lab][k] | db2[32] | dW3[32] | db3, padded to 68
+  float* my = slab + (size_t)blockIdx.x * pair_slab_floats(LT);
   for (int e = tid; e < NR * 64; e += 256) {         // element e = (slot, lane'): slot = which accumulator register
     const int slot = e >> 6, ln = e & 63;
     const float v = red[e];
     const int hh = ln >> 5, c31 = ln & 31;
     if (slot < 32) {                                 // dW2: slot = ct * 16 + r
       const int ct = slot >> 4, r = slot & 15;
-      atomicAdd(Gd.dW2 + crow(r, hh) * 64 + ct * 32 + c31, v);
+      my[crow(r, hh) * 64 + ct * 32 + c31] = v;
     } else {                                         // dB: slot - 32 = lt * 32 + ct * 16 + r
       const int q = slot - 32, lt = q >> 5, ct = (q >> 4) & 1, r = q & 15;
-      const int lab = lt * 32 + crow(r, hh);
-      if (lab < n_labs) atomicAdd(Gd.dB + (size_t)lab * 64 + ct * 32 + c31, v);
+      my[2048 + (lt * 32 + crow(r, hh)) * 64 + ct * 32 + c31] = v;
     }
   }
   w3acc += __shfl_xor(w3acc, 32, 64);
   b2acc += __shfl_xor(b2acc, 32, 64);
   b3acc = wave_sum(b3acc);
-  if (lane < 32) { atomicAdd(Gd.dW3 + lane, w3acc); atomicAdd(Gd.db2 + lane, b2acc); }
-  if (lane == 0) atomicAdd(Gd.db3, b3acc);
+  if (lane < 32) { tail_red[wid][lane] = w3acc; tail_red[wid][32 + lane] = b2acc; }
+  if (lane == 0) tail_red[wid][64] = b3acc;
+  __syncthreads();
+  if (tid < 68) {
+    const float t = tid < 65 ? ((tail_red[0][tid] + tail_red[1][tid]) + tail_red[2][tid]) + tail_red[3][tid] : 0.f;
+    // slab order: db2 | dW3 | db3  (tail_red holds dW3 first)
+    const int dst = tid < 32 ? 32 + tid : (tid < 64 ? tid - 32 : tid);
+    my[2048 + LT * 2048 + dst] = t;
+  }
 }
+
+// adds the summed slab into the caller's gradient buffers (single writer per element: plain read-modify-write)
+struct EpiPairFlush {
+  float *dW2, *dB, *db2, *dW3, *db3;
+  int n_labs, LT;
+  __device__ void operator()(int64_t i4, mmg_f4 v) const {
+    const int i = (int)i4 * 4;
+    if (i < 2048) {
+      mmg_f4* o = reinterpret_cast<mmg_f4*>(dW2 + i);
+      *o = *o + v;
+    } else if (i < 2048 + LT * 2048) {
+      const int j = i - 2048;
+      if (j / 64 < n_labs) {
+        mmg_f4* o = reinterpret_cast<mmg_f4*>(dB + j);
+        *o = *o + v;
+      }
+    } else {
+      const int t = i - (2048 + LT * 2048);
+      if (t < 32) { for (int q = 0; q < 4; ++q) db2[t + q] += v[q]; }
+      else if (t < 64) { for (int q = 0; q < 4; ++q) dW3[t - 32 + q] += v[q]; }
+      else if (t == 64) db3[0] += v[0];
+    }
+  }
+};
 
 // ---------------------------------------------------------------------------- forward on MFMA
 // One wave per 32 pairs.  The layer-2 product is computed TRANSPOSED, H2pre^T[unit, pair] = W2 . H1^T (A = W2 rows in
@@ -922,11 +960,16 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   return MMG_OK;
 }
 
+extern "C" size_t mmg_pair_head_bwd_ws_bytes(int64_t n_pairs, int n_labs) {
+  if (n_pairs <= 0 || n_labs < 0 || n_labs > 128) return 256;
+  return (size_t)256 * pair_slab_floats(n_labs <= 64 ? 2 : 4) * sizeof(float) + 256;
+}
+
 extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi, const int32_t* li,
                                  const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
                                  float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
                                  const float* dpred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
-                                 void* stream) {
+                                 void* ws, size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0 && n_labs >= 0, "pair_head_bwd: negative size");
   MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_bwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
@@ -945,14 +988,20 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     if (g > 256) g = 256;                // 509 registers: ONE workgroup is resident per CU; fewer workgroups = fewer
                                          // global atomics in the final flush (512 -> 256: -0.6 % on the step)
     if (g < 1) g = 1;
+    MMG_CHECK_ARG(ws && ws_bytes >= mmg_pair_head_bwd_ws_bytes(n_pairs, n_labs), "pair_head_bwd: workspace too small");
+    float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
 #define MMG_LAUNCH_PBWD(LT_, AUX_)                                                                                    \
   MMG_LAUNCH(MMG_PROBE_PAIR_BWD, n_pairs, 0, 0, want_low ? 2 : 0, (k_pair_bwd_mfma<LT_, AUX_>), dim3((unsigned)g),      \
              dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed,    \
-             seed_ptr, pair_id, dpred, sel, n_sel, io_perm)
+             seed_ptr, pair_id, dpred, sel, n_sel, io_perm, slab)
     const bool aux = pair_id != nullptr || io_perm != nullptr;
     if (n_labs <= 64) { if (aux) MMG_LAUNCH_PBWD(2, true); else MMG_LAUNCH_PBWD(2, false); }
     else { if (aux) MMG_LAUNCH_PBWD(4, true); else MMG_LAUNCH_PBWD(4, false); }
 #undef MMG_LAUNCH_PBWD
+    const int LT = n_labs <= 64 ? 2 : 4;
+    const int64_t n4 = pair_slab_floats(LT) / 4;
+    hipLaunchKernelGGL((mmg_k_reduce_slabs<EpiPairFlush>), dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, st, slab, n4,
+                       (int)g, EpiPairFlush{G.dW2, G.dB, G.db2, G.dW3, G.db3, n_labs, LT});
   } else {
     size_t lds = BWD_LDS_FIXED;
     int lds_db = 0;

@@ -564,11 +564,12 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
         return
     h = head.c()
     g = HeadGradT(_p(grads.A), _p(grads.B), _p(grads.W2), _p(grads.b2), _p(grads.W3), _p(grads.b3))
+    ws = workspace(lib.mmg_pair_head_bwd_ws_bytes(n, n_labs), head.A.device)
     _tok = _pb("pair_head_bwd")
     check(lib.mmg_pair_head_bwd(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32),
                                 thr, int(want_low), n, n_labs, float(p), seed & 0xFFFFFFFFFFFFFFFF,
                                 _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _p(sel, torch.int32),
-                                _p(n_sel, torch.int32), _p(io_perm, torch.int64), _stream()),
+                                _p(n_sel, torch.int32), _p(io_perm, torch.int64), _p(ws, torch.uint8), ws.numel(), _stream()),
           "mmg_pair_head_bwd")
     _pe(_tok, "pair_head_bwd", n * 12 + 2 * 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (4 * 64 * 32))
 
