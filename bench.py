@@ -135,9 +135,10 @@ def build_workload(args, world, rank, dev, scale, strong):
     y = g[LAB].edge_attr[tr].squeeze(-1).contiguous()
     sup = torch.rand(tr.numel(), generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev) < 0.2
     wlab = torch.ones(int(g["lab"].num_nodes), device=dev)
-    # F5: embeddings are not in the optimizer.  fused = one multi-tensor kernel for all ~60 parameter tensors
-    opt = torch.optim.Adam([p for n, p in model.named_parameters() if not n.startswith("embeddings.")],
-                           lr=1e-3, weight_decay=1e-5, capturable=True, fused=True)
+    # F5: embeddings are not in the optimizer.  mmgnn.optim.Adam = torch.optim.Adam's arithmetic as ONE launch of
+    # mmg_adam_step over the flat parameter bucket
+    from mmgnn.optim import Adam
+    opt = Adam([p for n, p in model.named_parameters() if not n.startswith("embeddings.")], lr=1e-3, weight_decay=1e-5)
     n_sup_global = torch.tensor([float(sup.sum())], device=dev)
     if comm is not None:
         torch.distributed.all_reduce(n_sup_global)

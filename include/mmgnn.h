@@ -329,6 +329,30 @@ int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold,
                     int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Optimizer step (src/train.py:219,390: torch.optim.Adam(model.parameters()).step()) and small vector sums.
+ * mmg_adam_step updates EVERY parameter in one launch: p / m / v are flat fp32 buckets holding the tensors back to back
+ * at offsets[0 .. n_tensors] (ascending, offsets[n_tensors] = end); grads[i] (HOST array of device pointers; NULL = the
+ * tensor received no gradient and is left untouched, as torch skips a .grad of None) is read where the backward kernels
+ * wrote it.  Arithmetic of torch.optim.Adam (amsgrad / maximize off, L2 weight decay added to the gradient).  `step`
+ * (device float, the number of steps taken so far) is advanced by the kernel -- hipGraph replays keep counting --
+ * through `ticket` (device uint32, zero-initialised by the caller once).
+ * mmg_vec_sums: dst_j = src_j0 + src_j1 (+ src_j2 + src_j3), fixed order, <= MMG_SUM_MAX_JOBS vectors per launch (the
+ * three lin_r weights / lin_l biases that share x_patient in a HeteroConv layer, src/model.py:125-131).
+ * ------------------------------------------------------------------------------------- */
+#define MMG_ADAM_MAX_TENSORS 96
+#define MMG_SUM_MAX_JOBS 8
+int mmg_adam_step(float* p, float* m, float* v, const float* const* grads, const int32_t* offsets, int n_tensors,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, float* step, uint32_t* ticket,
+                  void* stream);
+typedef struct {
+  float* dst;
+  const float* src[4];
+  int n_src;               /* 1..4 */
+  int len;                 /* elements */
+} mmg_sum_job_t;
+int mmg_vec_sums(const mmg_sum_job_t* jobs, int n_jobs, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Evaluation reducers on the device (src/evaluate.py:36-82 metrics, :417-440 per-lab +-3 sigma winsorisation, :89-141
  * per-lab rows, :237-342 stratifications).  Every figure evaluate_model reports is a segment sum over the prediction
  * pairs (segment = lab index, patient-degree bucket, lab-frequency bucket; seg[k] outside [0, n_seg) = not counted), so

@@ -40,6 +40,10 @@ class HeadGradT(C.Structure):
                 ("dW3", C.c_void_p), ("db3", C.c_void_p)]
 
 
+class SumJobT(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p * 4), ("n_src", C.c_int), ("len", C.c_int)]
+
+
 _vp, _i64, _i32, _f32, _sz, _u64, _u32 = (C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t,
                                           C.c_uint64, C.c_uint32)
 _P = C.POINTER
@@ -90,6 +94,8 @@ SIGNATURES = {
     "mmg_pair_head_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmg_adam_step": (C.c_int, [_vp, _vp, _vp, _P(C.c_void_p), _P(C.c_int32), _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
+    "mmg_vec_sums": (C.c_int, [_P(SumJobT), _i32, _vp]),
     "mmg_seg_reduce_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_seg_moments": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "mmg_seg_metrics": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),

@@ -1,0 +1,116 @@
+// Optimizer step and small vector sums on the device (caller side of the hot path: the reference's
+// torch.optim.Adam(model.parameters()).step() of src/train.py:219,390).
+//
+// mmg_adam_step: ONE launch updates every parameter.  Parameters, first and second moments live in three flat fp32
+// buckets (483,970 elements for the reference model without its frozen embedding tables); the gradients stay where the
+// backward kernels wrote them and are found through a pointer table passed by value (<= MMG_ADAM_MAX_TENSORS entries
+// per launch; longer lists take several launches that share the step counter).  Arithmetic = torch.optim.Adam
+// (amsgrad = False, maximize = False): g += wd * p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The step counter t is a device-resident float (hipGraph
+// replays advance it): every workgroup reads it on entry, the LAST workgroup to finish writes t + 1.
+#include "common.h"
+
+namespace {
+
+struct AdamTable {
+  const float* grad[MMG_ADAM_MAX_TENSORS];   // NULL: the parameter received no gradient this step (left untouched)
+  int32_t off[MMG_ADAM_MAX_TENSORS + 1];     // element offsets of the tensors inside the flat buckets (ascending)
+  int n;
+};
+
+__global__ __launch_bounds__(256) void k_adam(AdamTable tb, float* __restrict__ p, float* __restrict__ m,
+                                              float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
+                                              float* __restrict__ step, unsigned* __restrict__ ticket, int bump) {
+  const float t = *step + 1.f;
+  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  const float step_size = lr / bc1;
+  const int total = tb.off[tb.n] - tb.off[0];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int e = tb.off[0] + i;
+    int lo = 0, hi = tb.n;                       // tensor of element e: last offset <= e
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tb.off[mid] <= e) lo = mid; else hi = mid;
+    }
+    const float* gp = tb.grad[lo];
+    if (!gp) continue;
+    float g = gp[e - tb.off[lo]];
+    const float pv = p[e];
+    if (wd != 0.f) g = fmaf(wd, pv, g);
+    const float mv = fmaf(b1, m[e], (1.f - b1) * g);
+    const float vv = fmaf(b2, v[e], (1.f - b2) * g * g);
+    m[e] = mv; v[e] = vv;
+    p[e] = pv - step_size * (mv / (sqrtf(vv) / bc2s + eps));
+  }
+  if (bump) {                                    // the last workgroup to finish advances the step counter
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      const unsigned old = atomicAdd(ticket, 1u);
+      if (old == gridDim.x - 1) { *step = t; *ticket = 0u; }
+    }
+  }
+}
+
+struct SumJobs {
+  float* dst[MMG_SUM_MAX_JOBS];
+  const float* src[MMG_SUM_MAX_JOBS][4];
+  int n_src[MMG_SUM_MAX_JOBS], len[MMG_SUM_MAX_JOBS];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void k_vec_sums(SumJobs jb) {
+  const int j = blockIdx.y;
+  const int n = jb.len[j];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float s = jb.src[j][0][i];
+    for (int q = 1; q < jb.n_src[j]; ++q) s += jb.src[j][q][i];      // fixed order
+    jb.dst[j][i] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int mmg_adam_step(float* p, float* m, float* v, const float* const* grads, const int32_t* offsets, int n_tensors,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, float* step,
+                             uint32_t* ticket, void* stream) {
+  MMG_CHECK_ARG(p && m && v && grads && offsets && step && ticket, "adam_step: null buffer");
+  MMG_CHECK_ARG(n_tensors >= 1, "adam_step: no tensors");
+  hipStream_t st = (hipStream_t)stream;
+  for (int t0 = 0; t0 < n_tensors; t0 += MMG_ADAM_MAX_TENSORS) {
+    AdamTable tb;
+    const int n = n_tensors - t0 < MMG_ADAM_MAX_TENSORS ? n_tensors - t0 : MMG_ADAM_MAX_TENSORS;
+    tb.n = n;
+    for (int i = 0; i < n; ++i) { tb.grad[i] = grads[t0 + i]; tb.off[i] = offsets[t0 + i]; }
+    tb.off[n] = offsets[t0 + n];
+    MMG_CHECK_ARG(tb.off[n] >= tb.off[0], "adam_step: offsets must ascend");
+    const int total = tb.off[n] - tb.off[0];
+    int nb = (total + 256 * 4 - 1) / (256 * 4);
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    const int last = t0 + MMG_ADAM_MAX_TENSORS >= n_tensors;
+    hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, st, tb, p, m, v, lr, beta1, beta2, eps, weight_decay, step, ticket, last);
+  }
+  MMG_CHECK_LAUNCH("adam_step");
+  return MMG_OK;
+}
+
+extern "C" int mmg_vec_sums(const mmg_sum_job_t* jobs, int n_jobs, void* stream) {
+  MMG_CHECK_ARG(jobs && n_jobs >= 1 && n_jobs <= MMG_SUM_MAX_JOBS, "vec_sums: 1..%d jobs", MMG_SUM_MAX_JOBS);
+  SumJobs jb;
+  jb.n = n_jobs;
+  int maxlen = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    MMG_CHECK_ARG(jobs[j].dst && jobs[j].n_src >= 1 && jobs[j].n_src <= 4 && jobs[j].len >= 0, "vec_sums: bad job %d", j);
+    jb.dst[j] = jobs[j].dst; jb.n_src[j] = jobs[j].n_src; jb.len[j] = jobs[j].len;
+    for (int q = 0; q < 4; ++q) jb.src[j][q] = q < jobs[j].n_src ? jobs[j].src[q] : nullptr;
+    for (int q = 0; q < jobs[j].n_src; ++q) MMG_CHECK_ARG(jobs[j].src[q], "vec_sums: job %d has a null source", j);
+    if (jobs[j].len > maxlen) maxlen = jobs[j].len;
+  }
+  if (maxlen == 0) return MMG_OK;
+  int nb = (maxlen + 256 * 4 - 1) / (256 * 4);
+  if (nb > 64) nb = 64;
+  hipLaunchKernelGGL(k_vec_sums, dim3(nb, n_jobs), dim3(256), 0, (hipStream_t)stream, jb);
+  MMG_CHECK_LAUNCH("vec_sums");
+  return MMG_OK;
+}

@@ -234,6 +234,19 @@ class HeteroRGCN(nn.Module):
 # =============================================================================================
 # one forward(+backward) of the hot path: manual tape over the C-ABI ops
 # =============================================================================================
+class _LazyAct:
+    """dropout(act(BN(y))) that is NOT materialised: its consumers fold it into their load (GEMM / weight-gradient
+    prologue).  Used for the last conv layer's patient activations inside predict_lab_values, which only feed the edge
+    head's first linear and its weight gradient (one write + two reads of a [P, D] tensor less per step)."""
+
+    def __init__(self, y: torch.Tensor, pro: Pro):
+        self.y, self.pro = y, pro
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+
 class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, run, mode, n_out, *params):
@@ -272,6 +285,7 @@ class _Run:
         self.tape = {}
         self._nbt = {}               # BatchNorm step counters to advance: {id(module): [buffer, increment]}
         self.pairs = None
+        self.lazy_final = False      # predict mode: the final patient activations stay folded (see _LazyAct)
         # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
         # dependency chain) runs on a side stream underneath the patient-side kernels of the same layer
         # (MMG_OVERLAP=0: one stream).  Sharded runs keep every collective on the main stream.
@@ -357,6 +371,7 @@ class _Run:
             self.tape["mode"] = ("forward", enc, layers)
             self.out_types = list(x.keys())
             return [x[t] for t in self.out_types]
+        self.lazy_final = True
         # predict: encode_nodes runs twice (model.py:294 and :301->251).  The two passes differ only by
         # their dropout masks, so with p == 0 (or eval) one pass is computed and BN running stats are
         # advanced twice.
@@ -674,7 +689,10 @@ class _Run:
                                 sums=rec.get("ysums") if t == ROW_TYPE else None) if self.m.use_batch_norm else None
             pro = Pro(fold.scale if fold else None, fold.shift if fold else None, self.m._act_code, p, self.seed,
                       SITE_CONV + 8 * l + ti, plan.row_offset if sharded else 0, self.seed_dev)
-            out[t] = ops.affine_act_drop(y[t], pro)
+            if last and t == ROW_TYPE and self.lazy_final and self.m._act_code == 1:
+                out[t] = _LazyAct(y[t], pro)                     # consumed through the heads' GEMM prologues
+            else:
+                out[t] = ops.affine_act_drop(y[t], pro)
             folds[t], pros[t] = fold, pro
 
         names = [self.conv_name(l, r.edge_type) for r in rin]
@@ -718,11 +736,19 @@ class _Run:
             # ---- dst = patient: y_P = x_P (sum_r W_r)^T + sum_r b_r + sum_r mean_gather(x_v W_l^T)
             if not rin:
                 return
-            Wsum = self.W(names[0] + ".lin_r.weight")
-            bsum = self.W(names[0] + ".lin_l.bias")
-            for nme in names[1:]:
-                Wsum = Wsum + self.W(nme + ".lin_r.weight")
-                bsum = bsum + self.W(nme + ".lin_l.bias")
+            if len(names) == 1:
+                Wsum, bsum = self.W(names[0] + ".lin_r.weight"), self.W(names[0] + ".lin_l.bias")
+            elif len(names) <= 4:                # the lin_r weights / lin_l biases that share x_patient: one launch
+                Wsum = torch.empty(D, D, device=self.dev)
+                bsum = torch.empty(D, device=self.dev)
+                ops.vec_sums([(Wsum, [self.W(n_ + ".lin_r.weight") for n_ in names]),
+                              (bsum, [self.W(n_ + ".lin_l.bias") for n_ in names])])
+            else:
+                Wsum = self.W(names[0] + ".lin_r.weight")
+                bsum = self.W(names[0] + ".lin_l.bias")
+                for nme in names[1:]:
+                    Wsum = Wsum + self.W(nme + ".lin_r.weight")
+                    bsum = bsum + self.W(nme + ".lin_l.bias")
             yP = ops.linear_fwd(xP, Wsum.contiguous(), bsum.contiguous())
             wait_tables()
             rels = [ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv, simple=r.simple, mask_r=r.mask_r)
@@ -914,7 +940,10 @@ class _Run:
         D = self.D
         w1 = mod.mlp[0].weight.detach()
         w1a, w1b = w1[:, :D].contiguous(), w1[:, D:].contiguous()
-        A = ops.linear_fwd(xP, w1a) if xP.shape[0] else torch.zeros(1, w1a.shape[0], device=self.dev)
+        if isinstance(xP, _LazyAct):
+            A = ops.linear_fwd(xP.y, w1a, pro=xP.pro)
+        else:
+            A = ops.linear_fwd(xP, w1a) if xP.shape[0] else torch.zeros(1, w1a.shape[0], device=self.dev)
         B = ops.linear_fwd(xlab, w1b, mod.mlp[0].bias.detach())
         head = ops.Head(A, B, mod.mlp[3].weight.detach(), mod.mlp[3].bias.detach(),
                         mod.mlp[6].weight.detach().reshape(-1).contiguous(), mod.mlp[6].bias.detach())
@@ -983,7 +1012,9 @@ class _Run:
             self.acc(f"{which}.mlp.6.bias", g.b3, partial=True)
             # first-layer weight / bias gradients from this shard's pairs only (the LOCAL dA and dB): per-shard partial
             # sums like every other parameter gradient, summed by the one bucket at the end of the backward
-            if xP.shape[0]:
+            if isinstance(xP, _LazyAct):
+                dW1a = ops.linear_wgrad(g.A, xP.y, xP.pro)
+            elif xP.shape[0]:
                 dW1a = ops.linear_wgrad(g.A, xP)
             else:
                 dW1a = torch.zeros(w1a.shape, device=self.dev)

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import HeadGradT, HeadT, PrologueT, RelT, check
+from ._lib import HeadGradT, HeadT, PrologueT, RelT, SumJobT, check
 
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
@@ -631,3 +631,19 @@ def seg_sums(pred: torch.Tensor, target: torch.Tensor, seg: torch.Tensor, n_seg:
                               float(n_sigma), _p(adj), _p(sums, torch.float64), _p(ws, torch.uint8), ws.numel(), _stream()),
           "mmg_seg_metrics")
     return sums, adj
+
+
+def vec_sums(jobs):
+    """jobs: list of (dst, [src tensors, 1..4]) -- dst = sum of the sources in list order, ONE launch (mmg_vec_sums)."""
+    lib = _lib.load()
+    arr = (SumJobT * len(jobs))()
+    for j, (dst, srcs) in enumerate(jobs):
+        if not 1 <= len(srcs) <= 4:
+            raise ValueError("vec_sums: 1..4 sources per job")
+        sp = (C.c_void_p * 4)()
+        for q, t in enumerate(srcs):
+            if t.numel() != dst.numel():
+                raise ValueError("vec_sums: size mismatch")
+            sp[q] = _p(t).value
+        arr[j] = SumJobT(_p(dst).value, sp, len(srcs), dst.numel())
+    check(lib.mmg_vec_sums(arr, len(jobs), _stream()), "mmg_vec_sums")

@@ -129,8 +129,10 @@ class Trainer:
         kind = oc.get("type", "adam").lower()
         if kind == "adam":
             params = list(self.model.parameters())
-            fused = bool(params) and all(p.is_cuda for p in params)        # one multi-tensor kernel per step
-            return optim.Adam(params, lr=oc["lr"], weight_decay=oc["weight_decay"], fused=fused)
+            if params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+                from .optim import Adam                                        # one launch of mmg_adam_step per step
+                return Adam(params, lr=oc["lr"], weight_decay=oc["weight_decay"])
+            return optim.Adam(params, lr=oc["lr"], weight_decay=oc["weight_decay"])
         if kind == "sgd":
             return optim.SGD(self.model.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"],
                              momentum=oc.get("momentum", 0.9))
