@@ -329,6 +329,33 @@ int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree_threshold,
                     int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Grouped launches for the vocab side (tables of 50 .. 200 rows: every lin_l / lin_r of a SAGEConv into a vocab type, the
+ * transformed tables the patient-side gather reads, their weight / data gradients -- src/model.py:125-131,256 -- is a few
+ * microseconds of work behind a launch).  One launch runs up to MMG_SMALL_MAX independent problems of one (N, K).
+ *   mmg_small_fwd_group  : Y[M,N] (+)= X[M,K] . W^T (+ X2[M,K] . W2^T) + bias ;  flags as mmg_linear_fwd
+ *                          (MMG_LIN_ACCUMULATE, MMG_LIN_W_KN: both W and W2 stored [K,N]);  exact fp32 products
+ *   mmg_small_wgrad_group: dW[N,K] (+)= dY[M,N]^T . X[M,K] ;  dbias[N] (nullable) (+)= column sums of dY
+ * M <= 4096 per problem (M = 0: skipped by the forward, zero / untouched gradient by the weight gradient).
+ * ------------------------------------------------------------------------------------- */
+#define MMG_SMALL_MAX 8
+typedef struct {
+  const float* X; const float* W;      /* [M,K], [N,K] (or [K,N]) */
+  const float* X2; const float* W2;    /* optional second term, both NULL or both set */
+  const float* bias;                   /* [N] or NULL */
+  float* Y;                            /* [M,N] */
+  int64_t M;
+  int flags;
+} mmg_small_fwd_t;
+typedef struct {
+  const float* dY; const float* X;     /* [M,N], [M,K] */
+  float* dW; float* dbias;             /* [N,K], [N] or NULL */
+  int64_t M;
+  int accumulate;
+} mmg_small_wgrad_t;
+int mmg_small_fwd_group(const mmg_small_fwd_t* probs, int n_probs, int N, int K, void* stream);
+int mmg_small_wgrad_group(const mmg_small_wgrad_t* probs, int n_probs, int N, int K, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimizer step (src/train.py:219,390: torch.optim.Adam(model.parameters()).step()) and small vector sums.
  * mmg_adam_step updates EVERY parameter in one launch: p / m / v are flat fp32 buckets holding the tensors back to back
  * at offsets[0 .. n_tensors] (ascending, offsets[n_tensors] = end); grads[i] (HOST array of device pointers; NULL = the

@@ -40,6 +40,16 @@ class HeadGradT(C.Structure):
                 ("dW3", C.c_void_p), ("db3", C.c_void_p)]
 
 
+class SmallFwdT(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("W", C.c_void_p), ("X2", C.c_void_p), ("W2", C.c_void_p), ("bias", C.c_void_p),
+                ("Y", C.c_void_p), ("M", C.c_int64), ("flags", C.c_int)]
+
+
+class SmallWgradT(C.Structure):
+    _fields_ = [("dY", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("M", C.c_int64),
+                ("accumulate", C.c_int)]
+
+
 class SumJobT(C.Structure):
     _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p * 4), ("n_src", C.c_int), ("len", C.c_int)]
 
@@ -94,6 +104,8 @@ SIGNATURES = {
     "mmg_pair_head_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmg_small_fwd_group": (C.c_int, [_P(SmallFwdT), _i32, _i32, _i32, _vp]),
+    "mmg_small_wgrad_group": (C.c_int, [_P(SmallWgradT), _i32, _i32, _i32, _vp]),
     "mmg_adam_step": (C.c_int, [_vp, _vp, _vp, _P(C.c_void_p), _P(C.c_int32), _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
     "mmg_vec_sums": (C.c_int, [_P(SumJobT), _i32, _vp]),
     "mmg_seg_reduce_ws_bytes": (_sz, [_i64, _i32]),

@@ -698,7 +698,11 @@ class _Run:
         names = [self.conv_name(l, r.edge_type) for r in rin]
         tables = []
 
-        def vocab_tables():  # T_v = x_v W_l^T: the transformed vocab rows the patient-side gather reads
+        def vocab_tables():  # T_v = x_v W_l^T: the transformed vocab rows the patient-side gather reads (ONE launch)
+            if all(x[r.other].shape[0] <= ops.SMALL_MAX_ROWS for r in rin):
+                tables.extend(ops.small_fwd_group([ops.SmallFwd(x[r.other], self.W(nme + ".lin_l.weight"))
+                                                   for r, nme in zip(rin, names)]))
+                return
             for r, nme in zip(rin, names):
                 tables.append(ops.linear_fwd(x[r.other], self.W(nme + ".lin_l.weight")))
 
@@ -721,12 +725,24 @@ class _Run:
 
         def vocab_small():
             if rout:
-                for r, agg in zip(rout, scat["aggs"]):
-                    nme = self.conv_name(l, r.edge_type)
-                    first = r.other not in y
-                    y[r.other] = ops.linear_fwd(agg, self.W(nme + ".lin_l.weight"), self.W(nme + ".lin_l.bias"),
-                                                out=None if first else y[r.other], accumulate=not first)
-                    ops.linear_fwd(x[r.other], self.W(nme + ".lin_r.weight"), out=y[r.other], accumulate=True)
+                others = [r.other for r in rout]
+                if len(set(others)) == len(others) and all(r.n_cols <= ops.SMALL_MAX_ROWS for r in rout):
+                    # every vocab type has ONE incoming relation: y_v = agg W_l^T + b + x_v W_r^T is a two-term problem,
+                    # all of them in one launch
+                    outs = ops.small_fwd_group([
+                        ops.SmallFwd(agg, self.W(self.conv_name(l, r.edge_type) + ".lin_l.weight"),
+                                     bias=self.W(self.conv_name(l, r.edge_type) + ".lin_l.bias"), x2=x[r.other],
+                                     W2=self.W(self.conv_name(l, r.edge_type) + ".lin_r.weight"))
+                        for r, agg in zip(rout, scat["aggs"])])
+                    for r, o in zip(rout, outs):
+                        y[r.other] = o
+                else:
+                    for r, agg in zip(rout, scat["aggs"]):
+                        nme = self.conv_name(l, r.edge_type)
+                        first = r.other not in y
+                        y[r.other] = ops.linear_fwd(agg, self.W(nme + ".lin_l.weight"), self.W(nme + ".lin_l.bias"),
+                                                    out=None if first else y[r.other], accumulate=not first)
+                        ops.linear_fwd(x[r.other], self.W(nme + ".lin_r.weight"), out=y[r.other], accumulate=True)
                 rec["aggs"] = scat["aggs"]
             for t in plan.node_types:
                 if t != ROW_TYPE and t in y:
@@ -839,10 +855,33 @@ class _Run:
                 if t != ROW_TYPE:
                     bn_bwd_t(t)
             rels = []
-            for r, agg in zip(rec["rout"], rec.get("aggs", [])):
-                dyv = dy.get(r.other)
-                if dyv is None:
-                    continue
+            live = [(r, agg) for r, agg in zip(rec["rout"], rec.get("aggs", [])) if dy.get(r.other) is not None]
+            if live and all(r.n_cols <= ops.SMALL_MAX_ROWS for r, _ in live) and \
+                    all(g_in[r.other] is None for r, _ in live) and len({r.other for r, _ in live}) == len(live):
+                # grouped: the weight gradients of every relation in one launch, their data gradients in another
+                wg = []
+                for r, agg in live:
+                    dyv = dy[r.other]
+                    wg += [ops.SmallWgrad(dyv, agg, with_bias=True), ops.SmallWgrad(dyv, x[r.other])]
+                res = ops.small_wgrad_group(wg)
+                fw = []
+                for r, agg in live:
+                    nme = self.conv_name(l, r.edge_type)
+                    dyv = dy[r.other]
+                    fw += [ops.SmallFwd(dyv, self.W(nme + ".lin_r.weight"), w_kn=True),      # -> g_in[other]
+                           ops.SmallFwd(dyv, self.W(nme + ".lin_l.weight"), w_kn=True)]      # -> d agg
+                outs = ops.small_fwd_group(fw)
+                for i, (r, agg) in enumerate(live):
+                    nme = self.conv_name(l, r.edge_type)
+                    self.acc(nme + ".lin_l.weight", res[2 * i][0])
+                    self.acc(nme + ".lin_l.bias", res[2 * i][1])
+                    self.acc(nme + ".lin_r.weight", res[2 * i + 1][0])
+                    g_in[r.other] = outs[2 * i]
+                    rels.append(ops.Rel(r.rowptr, r.col, r.n_cols, colscale=r.inv_col, table=outs[2 * i + 1],
+                                        simple=r.simple, mask_r=r.mask_r))
+                return rels
+            for r, agg in live:
+                dyv = dy[r.other]
                 nme = self.conv_name(l, r.edge_type)
                 dWl, dbl = ops.linear_wgrad(dyv, agg, with_bias=True)     # the bias gradient rides in the same pass
                 self.acc(nme + ".lin_l.weight", dWl)
@@ -879,7 +918,24 @@ class _Run:
             if res is None:
                 return
             dTs, dWsum, dbsum, _ = res
-            for r, dT in zip(rec["rin"], dTs):
+            rin_ = rec["rin"]
+            if all(r.n_cols <= ops.SMALL_MAX_ROWS for r in rin_) and len({r.other for r in rin_}) == len(rin_):
+                # grouped: gradients of the vocab-table transforms T_v = x_v W_l^T, one launch each for dW and dX
+                wres = ops.small_wgrad_group([ops.SmallWgrad(dT, x[r.other]) for r, dT in zip(rin_, dTs)])
+                fw = []
+                for r, dT in zip(rin_, dTs):
+                    nme = self.conv_name(l, r.edge_type)
+                    fw.append(ops.SmallFwd(dT, self.W(nme + ".lin_l.weight"), out=g_in[r.other],
+                                           accumulate=g_in[r.other] is not None, w_kn=True))
+                outs = ops.small_fwd_group(fw)
+                for (r, dT), (dW, _), o in zip(zip(rin_, dTs), wres, outs):
+                    nme = self.conv_name(l, r.edge_type)
+                    self.acc(nme + ".lin_r.weight", dWsum, partial=True)
+                    self.acc(nme + ".lin_l.bias", dbsum, partial=True)
+                    self.acc(nme + ".lin_l.weight", dW)
+                    g_in[r.other] = o
+                return
+            for r, dT in zip(rin_, dTs):
                 nme = self.conv_name(l, r.edge_type)
                 self.acc(nme + ".lin_r.weight", dWsum, partial=True)
                 self.acc(nme + ".lin_l.bias", dbsum, partial=True)

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import HeadGradT, HeadT, PrologueT, RelT, SumJobT, check
+from ._lib import HeadGradT, HeadT, PrologueT, RelT, SmallFwdT, SmallWgradT, SumJobT, check
 
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
@@ -647,3 +647,97 @@ def vec_sums(jobs):
             sp[q] = _p(t).value
         arr[j] = SumJobT(_p(dst).value, sp, len(srcs), dst.numel())
     check(lib.mmg_vec_sums(arr, len(jobs), _stream()), "mmg_vec_sums")
+
+
+# ------------------------------------------------------------------------------------------ grouped small launches
+SMALL_MAX_ROWS = 4096
+
+
+@dataclass
+class SmallFwd:
+    """One problem of small_fwd_group: out[M,N] (+)= x @ W^T (+ x2 @ W2^T) + bias (w_kn: W, W2 stored [K,N])."""
+    x: torch.Tensor
+    W: torch.Tensor
+    out: Optional[torch.Tensor] = None
+    bias: Optional[torch.Tensor] = None
+    x2: Optional[torch.Tensor] = None
+    W2: Optional[torch.Tensor] = None
+    accumulate: bool = False
+    w_kn: bool = False
+
+
+def small_fwd_group(probs: Sequence[SmallFwd]):
+    """Runs the problems (same N and K) in ceil(len / 8) launches; allocates missing outputs; returns the outputs."""
+    lib = _lib.load()
+    if not probs:
+        return []
+    K = probs[0].x.shape[1]
+    N = probs[0].W.shape[1] if probs[0].w_kn else probs[0].W.shape[0]
+    outs = []
+    for p in probs:
+        M, k = p.x.shape
+        n = p.W.shape[1] if p.w_kn else p.W.shape[0]
+        if k != K or n != N or (p.W.shape[0] if p.w_kn else p.W.shape[1]) != K or M > SMALL_MAX_ROWS:
+            raise ValueError("small_fwd_group: every problem must share (N, K) and have M <= 4096")
+        if p.out is None:
+            if p.accumulate:
+                raise ValueError("accumulate needs out")
+            p.out = torch.empty(M, N, dtype=torch.float32, device=p.x.device)
+        elif tuple(p.out.shape) != (M, N):
+            raise ValueError("small_fwd_group: out shape")
+        if (p.x2 is None) != (p.W2 is None) or (p.x2 is not None and (tuple(p.x2.shape) != (M, K) or p.W2.shape != p.W.shape)):
+            raise ValueError("small_fwd_group: second term shape")
+        outs.append(p.out)
+    live = [p for p in probs if p.x.shape[0] > 0]              # (an empty table has an empty output)
+    for i0 in range(0, len(live), 8):
+        chunk = live[i0:i0 + 8]
+        arr = (SmallFwdT * len(chunk))()
+        for i, p in enumerate(chunk):
+            arr[i] = SmallFwdT(_p(p.x, name="x").value, _p(p.W, name="W").value,
+                               _p(p.x2).value if p.x2 is not None else None,
+                               _p(p.W2).value if p.W2 is not None else None,
+                               _p(p.bias).value if p.bias is not None else None,
+                               _p(p.out).value, p.x.shape[0], int(p.accumulate) | (2 if p.w_kn else 0))
+        check(lib.mmg_small_fwd_group(arr, len(chunk), N, K, _stream()), "mmg_small_fwd_group")
+    return outs
+
+
+@dataclass
+class SmallWgrad:
+    """One problem of small_wgrad_group: dW[N,K] (+)= dy^T @ x; dbias (+)= column sums of dy (with_bias)."""
+    dy: torch.Tensor
+    x: torch.Tensor
+    dW: Optional[torch.Tensor] = None
+    dbias: Optional[torch.Tensor] = None
+    with_bias: bool = False
+    accumulate: bool = False
+
+
+def small_wgrad_group(probs: Sequence[SmallWgrad]):
+    """Runs the problems (same N and K) in ceil(len / 8) launches; allocates missing outputs; returns [(dW, dbias)]."""
+    lib = _lib.load()
+    if not probs:
+        return []
+    N, K = probs[0].dy.shape[1], probs[0].x.shape[1]
+    res = []
+    for p in probs:
+        M = p.dy.shape[0]
+        if p.dy.shape[1] != N or p.x.shape[1] != K or p.x.shape[0] != M or M > SMALL_MAX_ROWS:
+            raise ValueError("small_wgrad_group: every problem must share (N, K), rows must match, M <= 4096")
+        if p.dW is None:
+            p.dW = torch.empty(N, K, dtype=torch.float32, device=p.x.device)
+            p.accumulate = False
+        if p.with_bias and p.dbias is None:
+            if p.accumulate:
+                raise ValueError("accumulating the bias gradient needs dbias")
+            p.dbias = torch.empty(N, dtype=torch.float32, device=p.x.device)
+        res.append((p.dW, p.dbias))
+    for i0 in range(0, len(probs), 8):
+        chunk = probs[i0:i0 + 8]
+        arr = (SmallWgradT * len(chunk))()
+        for i, p in enumerate(chunk):
+            arr[i] = SmallWgradT(_p(p.dy).value if p.dy.numel() else None, _p(p.x).value if p.x.numel() else None,
+                                 _p(p.dW).value, _p(p.dbias).value if p.dbias is not None else None, p.dy.shape[0],
+                                 int(p.accumulate))
+        check(lib.mmg_small_wgrad_group(arr, len(chunk), N, K, _stream()), "mmg_small_wgrad_group")
+    return res

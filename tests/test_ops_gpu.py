@@ -552,3 +552,59 @@ def test_c_abi_error_behaviour(ops, dev):
 def test_ops_reject_cpu_tensors(ops):
     with pytest.raises(Exception):
         ops.linear_fwd(torch.zeros(4, 64), torch.zeros(64, 64))
+
+
+def test_small_fwd_and_wgrad_groups(dev):
+    """Grouped launches of the vocab-side dense ops (mmg_small_fwd_group / mmg_small_wgrad_group): every problem of a
+    group against an fp64 reference -- one and two terms, bias, accumulate, W stored [K,N], ragged row counts (1 .. 300
+    and an empty table), more problems than one launch holds."""
+    import mmgnn  # noqa: F401
+    from mmgnn import ops
+    gen = torch.Generator().manual_seed(11)
+    for K, N in ((128, 128), (64, 64), (256, 64), (128, 64)):
+        Ms = [50, 114, 100, 1, 33, 300, 200, 64, 7, 0]
+        probs, refs = [], []
+        for i, M in enumerate(Ms):
+            x = torch.randn(M, K, generator=gen).to(dev)
+            wkn = i % 3 == 1
+            W = (torch.randn(K, N, generator=gen) if wkn else torch.randn(N, K, generator=gen)).to(dev) / K ** 0.5
+            two = i % 2 == 0
+            x2 = torch.randn(M, K, generator=gen).to(dev) if two else None
+            W2 = (torch.randn(*W.shape, generator=gen).to(dev) / K ** 0.5) if two else None
+            bias = torch.randn(N, generator=gen).to(dev) if i % 4 != 3 else None
+            acc = i % 5 == 2
+            out = torch.randn(M, N, generator=gen).to(dev) if acc else None
+            ref = x.double() @ (W.double() if wkn else W.double().t())
+            if two:
+                ref = ref + x2.double() @ (W2.double() if wkn else W2.double().t())
+            if bias is not None:
+                ref = ref + bias.double()
+            if acc:
+                ref = ref + out.double()
+            probs.append(ops.SmallFwd(x, W, out=out, bias=bias, x2=x2, W2=W2, accumulate=acc, w_kn=wkn))
+            refs.append(ref)
+        outs = ops.small_fwd_group(probs)
+        for o, r, M in zip(outs, refs, Ms):
+            assert o.shape == (M, N)
+            if M:
+                assert float((o.double() - r).abs().max()) <= 2e-6 * float(r.abs().max()), (K, N, M)
+        wp, wrefs = [], []
+        for i, M in enumerate(Ms):
+            dy = torch.randn(M, N, generator=gen).to(dev)
+            x = torch.randn(M, K, generator=gen).to(dev)
+            acc = i % 3 == 0
+            dW0 = torch.randn(N, K, generator=gen).to(dev) if acc else None
+            db0 = torch.randn(N, generator=gen).to(dev) if acc else None
+            wb = i % 2 == 0
+            rW = dy.double().t() @ x.double() + (dW0.double() if acc else 0)
+            rb = dy.double().sum(0) + (db0.double() if acc else 0)
+            wp.append(ops.SmallWgrad(dy, x, dW=dW0.clone() if acc else None, dbias=db0.clone() if (acc and wb) else None,
+                                     with_bias=wb, accumulate=acc))
+            wrefs.append((rW, rb, wb))
+        res = ops.small_wgrad_group(wp)
+        for (dW, db), (rW, rb, wb), M in zip(res, wrefs, Ms):
+            assert float((dW.double() - rW).abs().max()) <= 2e-6 * max(float(rW.abs().max()), 1e-30) + (0 if M else 0), (K, N, M)
+            if wb:
+                assert float((db.double() - rb).abs().max()) <= 2e-6 * max(float(rb.abs().max()), 1e-30), (K, N, M)
+            else:
+                assert db is None
