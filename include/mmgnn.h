@@ -355,6 +355,37 @@ typedef struct {
 int mmg_small_fwd_group(const mmg_small_fwd_t* probs, int n_probs, int N, int K, void* stream);
 int mmg_small_wgrad_group(const mmg_small_wgrad_t* probs, int n_probs, int N, int K, void* stream);
 
+/* The per-type epilogue of a HeteroConv layer (src/model.py:258-269: BatchNorm1d -> activation -> Dropout) for every
+ * SMALL node type in one launch, and its backward in another.  Per problem (M <= 4096 rows):
+ *   forward : training: batch statistics (fp64 sums) -> scale / shift / mean / rstd written to stats_out[4,N] (the layout
+ *             mmg_bn_finalize produces), running statistics advanced once (unbiased variance, `momentum`);  eval: folded
+ *             from the running statistics;  gamma == NULL: no BatchNorm.  out = dropout(act(Y * scale + shift)).
+ *   backward: g' = G * act'(.) * keep / (1 - p);  training: dY = scale (g' - mean g' - xhat mean(g' xhat)), dbeta = sum g',
+ *             dgamma = sum g' xhat;  eval: dY = scale g';  scale == NULL: dY = g'.
+ * Dropout masks are the ones mmg_affine_act_drop draws for the same (seed, site, row_offset). */
+typedef struct {
+  const float* Y; float* out;           /* [M,N] */
+  const float* gamma; const float* beta; float* running_mean; float* running_var;   /* [N]; gamma NULL = no BatchNorm */
+  float* stats_out;                     /* [4,N]: scale | shift | mean | rstd */
+  int64_t M;
+  int training;
+  int act;                              /* MMG_ACT_* */
+  float drop_p;
+  uint64_t seed; uint32_t site; int64_t row_offset; const uint64_t* seed_ptr;
+} mmg_small_bn_t;
+typedef struct {
+  const float* G; const float* Y; float* dY;                                  /* [M,N] */
+  const float* scale; const float* shift; const float* mean; const float* rstd;   /* [N]; scale NULL = no BatchNorm */
+  float* dbeta; float* dgamma;                                                 /* [N], nullable */
+  int64_t M;
+  int training;
+  int act;
+  float drop_p;
+  uint64_t seed; uint32_t site; int64_t row_offset; const uint64_t* seed_ptr;
+} mmg_small_bn_bwd_t;
+int mmg_small_bn_act_group(const mmg_small_bn_t* probs, int n_probs, int N, float momentum, float eps, void* stream);
+int mmg_small_bn_bwd_group(const mmg_small_bn_bwd_t* probs, int n_probs, int N, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Optimizer step (src/train.py:219,390: torch.optim.Adam(model.parameters()).step()) and small vector sums.
  * mmg_adam_step updates EVERY parameter in one launch: p / m / v are flat fp32 buckets holding the tensors back to back

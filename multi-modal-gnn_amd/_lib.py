@@ -50,6 +50,20 @@ class SmallWgradT(C.Structure):
                 ("accumulate", C.c_int)]
 
 
+class SmallBnT(C.Structure):
+    _fields_ = [("Y", C.c_void_p), ("out", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("stats_out", C.c_void_p), ("M", C.c_int64),
+                ("training", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64), ("site", C.c_uint32),
+                ("row_offset", C.c_int64), ("seed_ptr", C.c_void_p)]
+
+
+class SmallBnBwdT(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("Y", C.c_void_p), ("dY", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dbeta", C.c_void_p), ("dgamma", C.c_void_p), ("M", C.c_int64),
+                ("training", C.c_int), ("act", C.c_int), ("drop_p", C.c_float), ("seed", C.c_uint64), ("site", C.c_uint32),
+                ("row_offset", C.c_int64), ("seed_ptr", C.c_void_p)]
+
+
 class SumJobT(C.Structure):
     _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p * 4), ("n_src", C.c_int), ("len", C.c_int)]
 
@@ -106,6 +120,8 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmg_small_fwd_group": (C.c_int, [_P(SmallFwdT), _i32, _i32, _i32, _vp]),
     "mmg_small_wgrad_group": (C.c_int, [_P(SmallWgradT), _i32, _i32, _i32, _vp]),
+    "mmg_small_bn_act_group": (C.c_int, [_P(SmallBnT), _i32, _i32, _f32, _f32, _vp]),
+    "mmg_small_bn_bwd_group": (C.c_int, [_P(SmallBnBwdT), _i32, _i32, _vp]),
     "mmg_adam_step": (C.c_int, [_vp, _vp, _vp, _P(C.c_void_p), _P(C.c_int32), _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
     "mmg_vec_sums": (C.c_int, [_P(SumJobT), _i32, _vp]),
     "mmg_seg_reduce_ws_bytes": (_sz, [_i64, _i32]),

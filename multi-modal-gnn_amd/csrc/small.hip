@@ -6,6 +6,10 @@
 // kernel time, at the x1 scale (BASELINE config 2) the step is nothing but launches.
 //   mmg_small_fwd_group  : Y[M,N] (+)= X . W^T (+ X2 . W2^T) + bias      fp32 matrix cores (exact fp32 products)
 //   mmg_small_wgrad_group: dW[N,K] (+)= dY^T . X ;  dbias (+)= column sums of dY
+//   mmg_small_bn_act_group / mmg_small_bn_bwd_group: the per-type BatchNorm -> activation -> dropout of a HeteroConv
+//                          layer (src/model.py:258-269) and its backward for ALL small node types in one launch each
+//                          (statistics, folded scale / shift, running-statistics update and the apply pass fused:
+//                          nine, respectively six, launches per layer before)
 #include "common.h"
 
 namespace {
@@ -138,6 +142,175 @@ __global__ __launch_bounds__(256) void k_small_wgrad_group(WgradGroup g, int N, 
   }
 }
 
+struct BnGroup { mmg_small_bn_t p[MMG_SMALL_MAX]; int n; };
+
+__device__ inline ProDev small_pro(const mmg_small_bn_t& P, const float* sc, const float* sh) {
+  ProDev pr;
+  pr.scale = sc; pr.shift = sh; pr.relu = P.act; pr.p = P.drop_p;
+  pr.inv_keep = P.drop_p > 0.f ? 1.0f / (1.0f - P.drop_p) : 1.0f;
+  pr.seed = P.seed; pr.site = P.site; pr.row_offset = P.row_offset; pr.seed_ptr = P.seed_ptr;
+  pr.key = 0; pr.thr = 0;
+  pr.resolve();
+  return pr;
+}
+
+// workgroup = 32 columns of one problem; thread = (4 columns, one of 32 row lanes).  Training: fp64 column sums over the
+// row lanes (fixed order), the BatchNorm fold exactly as k_bn_finalize forms it (elementwise.hip), then the apply pass
+// re-reads Y (L2-resident: <= 4096 rows).
+__global__ __launch_bounds__(256) void k_small_bn_act_group(BnGroup g, int N, float momentum, float eps) {
+  const mmg_small_bn_t& P = g.p[blockIdx.y];
+  const int M = (int)P.M;
+  if (M == 0) return;
+  __shared__ double red[32][8][8];
+  __shared__ double tot[2][32];
+  __shared__ __attribute__((aligned(16))) float scs[32], shs[32];
+  const int tid = threadIdx.x, c4 = tid & 7, rl = tid >> 3;
+  const int c0 = blockIdx.x * 32, c = c0 + c4 * 4;
+  const bool has_bn = P.gamma != nullptr;
+  if (has_bn && P.training) {
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    for (int r = rl; r < M; r += 32) {
+      const sf32x4 v = *reinterpret_cast<const sf32x4*>(P.Y + (size_t)r * N + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[j] += (double)v[j]; s1[j] += (double)v[j] * (double)v[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[rl][c4][j] = s0[j]; red[rl][c4][4 + j] = s1[j]; }
+    __syncthreads();
+    if (tid < 64) {
+      const int col = tid & 31, which = tid >> 5;
+      double t = 0;
+      for (int q = 0; q < 32; ++q) t += red[q][col >> 2][which * 4 + (col & 3)];
+      tot[which][col] = t;
+    }
+    __syncthreads();
+  }
+  if (tid < 32) {
+    const int i = c0 + tid;
+    float sc = 1.f, sh = 0.f;
+    if (has_bn) {
+      float mean, var;
+      if (P.training) {
+        const double m = tot[0][tid] / (double)M;
+        double v = tot[1][tid] / (double)M - m * m;
+        if (v < 0) v = 0;
+        mean = (float)m; var = (float)v;
+        if (P.running_mean) {
+          const float unb = (float)(v * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+          P.running_mean[i] = (1.f - momentum) * P.running_mean[i] + momentum * mean;
+          P.running_var[i] = (1.f - momentum) * P.running_var[i] + momentum * unb;
+        }
+      } else {
+        mean = P.running_mean[i]; var = P.running_var[i];
+      }
+      const float rstd = 1.0f / sqrtf(var + eps);
+      sc = P.gamma[i] * rstd;
+      sh = (P.beta ? P.beta[i] : 0.f) - mean * sc;
+      P.stats_out[i] = sc; P.stats_out[N + i] = sh; P.stats_out[2 * N + i] = mean; P.stats_out[3 * N + i] = rstd;
+    }
+    scs[tid] = sc; shs[tid] = sh;
+  }
+  __syncthreads();
+  const ProDev pr = small_pro(P, has_bn ? scs : nullptr, shs);
+  const sf32x4 sc4 = *reinterpret_cast<const sf32x4*>(&scs[c4 * 4]), sh4 = *reinterpret_cast<const sf32x4*>(&shs[c4 * 4]);
+  for (int r = rl; r < M; r += 32) {
+    sf32x4 v = *reinterpret_cast<const sf32x4*>(P.Y + (size_t)r * N + c);
+    mmg_pro_apply4(pr, v, sc4, sh4, r, c, N);
+    *reinterpret_cast<sf32x4*>(P.out + (size_t)r * N + c) = v;
+  }
+}
+
+struct BnBwdGroup { mmg_small_bn_bwd_t p[MMG_SMALL_MAX]; int n; };
+
+// g' = G * act'(y * scale + shift) * keep / (1 - p);  training: dY = scale * (g' - mean(g') - xhat * mean(g' xhat)),
+// d beta = sum g', d gamma = sum g' xhat;  eval: dY = scale * g';  no BatchNorm: dY = g'.
+__global__ __launch_bounds__(256) void k_small_bn_bwd_group(BnBwdGroup g, int N) {
+  const mmg_small_bn_bwd_t& P = g.p[blockIdx.y];
+  const int M = (int)P.M;
+  if (M == 0) return;
+  __shared__ double red[32][8][8];
+  __shared__ float a0s[32], a1s[32];
+  const int tid = threadIdx.x, c4 = tid & 7, rl = tid >> 3;
+  const int c0 = blockIdx.x * 32, c = c0 + c4 * 4;
+  const bool has_bn = P.scale != nullptr;
+  const sf32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  sf32x4 sc = one, sh = zero, mu = zero, rs = one;
+  if (has_bn) {
+    sc = *reinterpret_cast<const sf32x4*>(P.scale + c); sh = *reinterpret_cast<const sf32x4*>(P.shift + c);
+    mu = *reinterpret_cast<const sf32x4*>(P.mean + c); rs = *reinterpret_cast<const sf32x4*>(P.rstd + c);
+  }
+  mmg_small_bn_t fwd{};                       // (reuses the forward's prologue builder for the dropout fields)
+  fwd.act = P.act; fwd.drop_p = P.drop_p; fwd.seed = P.seed; fwd.site = P.site; fwd.row_offset = P.row_offset;
+  fwd.seed_ptr = P.seed_ptr;
+  const ProDev pr = small_pro(fwd, nullptr, nullptr);
+  auto gprime = [&](int r) {
+    sf32x4 gv = *reinterpret_cast<const sf32x4*>(P.G + (size_t)r * N + c);
+    const sf32x4 y = *reinterpret_cast<const sf32x4*>(P.Y + (size_t)r * N + c);
+    if (P.act) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gv[j] *= mmg_act_grad(P.act, has_bn ? fmaf(y[j], sc[j], sh[j]) : y[j]);
+    }
+    if (pr.p > 0.f) mmg_drop4(gv, pr.key, (uint64_t)(pr.row_offset + r) * (uint64_t)N + (uint64_t)c, pr.thr, pr.inv_keep);
+    return gv;
+  };
+  const bool stats = has_bn && P.training;
+  if (stats) {
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    for (int r = rl; r < M; r += 32) {
+      const sf32x4 gv = gprime(r);
+      const sf32x4 y = *reinterpret_cast<const sf32x4*>(P.Y + (size_t)r * N + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0[j] += (double)gv[j];
+        s1[j] += (double)gv[j] * (double)((y[j] - mu[j]) * rs[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[rl][c4][j] = s0[j]; red[rl][c4][4 + j] = s1[j]; }
+    __syncthreads();
+    if (tid < 64) {
+      const int col = tid & 31, which = tid >> 5;
+      double t = 0;
+      for (int q = 0; q < 32; ++q) t += red[q][col >> 2][which * 4 + (col & 3)];
+      if (which == 0) { a0s[col] = (float)(t / (double)M); if (P.dbeta) P.dbeta[c0 + col] = (float)t; }
+      else { a1s[col] = (float)(t / (double)M); if (P.dgamma) P.dgamma[c0 + col] = (float)t; }
+    }
+    __syncthreads();
+  } else if (has_bn && (P.dbeta || P.dgamma)) {
+    // eval mode: d beta / d gamma are still the column sums (no mean subtraction in dY)
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    for (int r = rl; r < M; r += 32) {
+      const sf32x4 gv = gprime(r);
+      const sf32x4 y = *reinterpret_cast<const sf32x4*>(P.Y + (size_t)r * N + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[j] += (double)gv[j]; s1[j] += (double)gv[j] * (double)((y[j] - mu[j]) * rs[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[rl][c4][j] = s0[j]; red[rl][c4][4 + j] = s1[j]; }
+    __syncthreads();
+    if (tid < 64) {
+      const int col = tid & 31, which = tid >> 5;
+      double t = 0;
+      for (int q = 0; q < 32; ++q) t += red[q][col >> 2][which * 4 + (col & 3)];
+      if (which == 0) { if (P.dbeta) P.dbeta[c0 + col] = (float)t; }
+      else if (P.dgamma) P.dgamma[c0 + col] = (float)t;
+    }
+    __syncthreads();
+  }
+  sf32x4 a0 = zero, a1 = zero;
+  if (stats) { a0 = *reinterpret_cast<const sf32x4*>(&a0s[c4 * 4]); a1 = *reinterpret_cast<const sf32x4*>(&a1s[c4 * 4]); }
+  for (int r = rl; r < M; r += 32) {
+    const sf32x4 gv = gprime(r);
+    sf32x4 o = gv;
+    if (has_bn) {
+      const sf32x4 y = *reinterpret_cast<const sf32x4*>(P.Y + (size_t)r * N + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = sc[j] * (gv[j] - a0[j] - ((y[j] - mu[j]) * rs[j]) * a1[j]);
+    }
+    *reinterpret_cast<sf32x4*>(P.dY + (size_t)r * N + c) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int mmg_small_fwd_group(const mmg_small_fwd_t* probs, int n_probs, int N, int K, void* stream) {
@@ -180,5 +353,44 @@ extern "C" int mmg_small_wgrad_group(const mmg_small_wgrad_t* probs, int n_probs
   dim3 grid((unsigned)(K / 32), (unsigned)(N / 32), (unsigned)n_probs);
   hipLaunchKernelGGL(k_small_wgrad_group, grid, dim3(256), 0, (hipStream_t)stream, g, N, K);
   MMG_CHECK_LAUNCH("small_wgrad_group");
+  return MMG_OK;
+}
+
+extern "C" int mmg_small_bn_act_group(const mmg_small_bn_t* probs, int n_probs, int N, float momentum, float eps,
+                                      void* stream) {
+  MMG_CHECK_ARG(probs && n_probs >= 1 && n_probs <= MMG_SMALL_MAX, "small_bn_act_group: 1..%d problems", MMG_SMALL_MAX);
+  MMG_CHECK_ARG(N > 0 && N % 32 == 0, "small_bn_act_group: N=%d must be a multiple of 32", N);
+  BnGroup g;
+  g.n = n_probs;
+  for (int i = 0; i < n_probs; ++i) {
+    const mmg_small_bn_t& p = probs[i];
+    MMG_CHECK_ARG(p.M >= 0 && p.M <= 4096, "small_bn_act_group: problem %d has M=%lld (0..4096)", i, (long long)p.M);
+    MMG_CHECK_ARG(p.M == 0 || (p.Y && p.out), "small_bn_act_group: problem %d has a null buffer", i);
+    MMG_CHECK_ARG(!p.gamma || (p.stats_out && p.running_mean && p.running_var), "small_bn_act_group: BatchNorm buffers");
+    MMG_CHECK_ARG(!(p.gamma && p.training) || p.M > 1,
+                  "Expected more than 1 value per channel when training (problem %d has %lld rows)", i, (long long)p.M);
+    MMG_CHECK_ARG(p.drop_p >= 0.f && p.drop_p < 1.f && p.act >= 0 && p.act <= 3, "small_bn_act_group: bad activation / p");
+    g.p[i] = p;
+  }
+  hipLaunchKernelGGL(k_small_bn_act_group, dim3((unsigned)(N / 32), (unsigned)n_probs), dim3(256), 0, (hipStream_t)stream, g, N,
+                     momentum, eps);
+  MMG_CHECK_LAUNCH("small_bn_act_group");
+  return MMG_OK;
+}
+
+extern "C" int mmg_small_bn_bwd_group(const mmg_small_bn_bwd_t* probs, int n_probs, int N, void* stream) {
+  MMG_CHECK_ARG(probs && n_probs >= 1 && n_probs <= MMG_SMALL_MAX, "small_bn_bwd_group: 1..%d problems", MMG_SMALL_MAX);
+  MMG_CHECK_ARG(N > 0 && N % 32 == 0, "small_bn_bwd_group: N=%d must be a multiple of 32", N);
+  BnBwdGroup g;
+  g.n = n_probs;
+  for (int i = 0; i < n_probs; ++i) {
+    const mmg_small_bn_bwd_t& p = probs[i];
+    MMG_CHECK_ARG(p.M >= 0 && p.M <= 4096, "small_bn_bwd_group: problem %d has M=%lld (0..4096)", i, (long long)p.M);
+    MMG_CHECK_ARG(p.M == 0 || (p.G && p.Y && p.dY), "small_bn_bwd_group: problem %d has a null buffer", i);
+    MMG_CHECK_ARG(!p.scale || (p.shift && p.mean && p.rstd), "small_bn_bwd_group: folded BatchNorm vectors go together");
+    g.p[i] = p;
+  }
+  hipLaunchKernelGGL(k_small_bn_bwd_group, dim3((unsigned)(N / 32), (unsigned)n_probs), dim3(256), 0, (hipStream_t)stream, g, N);
+  MMG_CHECK_LAUNCH("small_bn_bwd_group");
   return MMG_OK;
 }

@@ -744,8 +744,23 @@ class _Run:
                                                     out=None if first else y[r.other], accumulate=not first)
                         ops.linear_fwd(x[r.other], self.W(nme + ".lin_r.weight"), out=y[r.other], accumulate=True)
                 rec["aggs"] = scat["aggs"]
-            for t in plan.node_types:
-                if t != ROW_TYPE and t in y:
+            vts = [t for t in plan.node_types if t != ROW_TYPE and t in y]
+            if vts and all(y[t].shape[0] <= ops.SMALL_MAX_ROWS for t in vts) and \
+                    not (self.T and self.m.use_batch_norm and any(y[t].shape[0] <= 1 for t in vts)):
+                # BatchNorm statistics + fold + running update + activation + dropout of every vocab type: ONE launch
+                items = []
+                for t in vts:
+                    ti = plan.node_types.index(t)
+                    mod = self.m.batch_norms[l][t] if self.m.use_batch_norm else None
+                    items.append((y[t], mod, Pro(None, None, self.m._act_code, p, self.seed, SITE_CONV + 8 * l + ti, 0,
+                                                 self.seed_dev)))
+                for t, (o, fold), it in zip(vts, ops.small_bn_act_group(items, self.T), items):
+                    out[t], folds[t], pros[t] = o, fold, it[2]
+                    if self.T and it[1] is not None:
+                        ent = self._nbt.setdefault(id(it[1]), [it[1].num_batches_tracked, 0])
+                        ent[1] += 1
+            else:
+                for t in vts:
                     bn_act(t)
 
         def patient_gather(wait_tables):
@@ -851,9 +866,18 @@ class _Run:
 
         def vocab_1():
             """BN backward of the vocab types and everything that only depends on it (vocab destinations)."""
-            for t in y:
-                if t != ROW_TYPE:
-                    bn_bwd_t(t)
+            vts = [t for t in y if t != ROW_TYPE and g_out.get(t) is not None]
+            if vts and all(y[t].shape[0] <= ops.SMALL_MAX_ROWS for t in vts):
+                items = [(g_out[t].contiguous(), y[t], rec["pros"][t], rec["folds"][t]) for t in vts]
+                for t, (dyt, dbeta, dgamma) in zip(vts, ops.small_bn_bwd_group(items)):
+                    dy[t] = dyt
+                    if dbeta is not None:
+                        self.acc(f"batch_norms.{l}.{t}.bias", dbeta)
+                        self.acc(f"batch_norms.{l}.{t}.weight", dgamma)
+            else:
+                for t in y:
+                    if t != ROW_TYPE:
+                        bn_bwd_t(t)
             rels = []
             live = [(r, agg) for r, agg in zip(rec["rout"], rec.get("aggs", [])) if dy.get(r.other) is not None]
             if live and all(r.n_cols <= ops.SMALL_MAX_ROWS for r, _ in live) and \

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import HeadGradT, HeadT, PrologueT, RelT, SmallFwdT, SmallWgradT, SumJobT, check
+from ._lib import HeadGradT, HeadT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, check
 
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
@@ -740,4 +740,70 @@ def small_wgrad_group(probs: Sequence[SmallWgrad]):
                                  _p(p.dW).value, _p(p.dbias).value if p.dbias is not None else None, p.dy.shape[0],
                                  int(p.accumulate))
         check(lib.mmg_small_wgrad_group(arr, len(chunk), N, K, _stream()), "mmg_small_wgrad_group")
+    return res
+
+
+def small_bn_act_group(items, training: bool):
+    """items: list of (y [M,N], bn module or None, Pro with the activation / dropout fields) -- the per-type epilogue of
+    a HeteroConv layer for every small node type in ONE launch (mmg_small_bn_act_group).
+    -> list of (out, BNFold or None); the Pro objects get their scale / shift filled in."""
+    lib = _lib.load()
+    res = []
+    if not items:
+        return res
+    N = items[0][0].shape[1]
+    for i0 in range(0, len(items), 8):
+        chunk = items[i0:i0 + 8]
+        arr = (SmallBnT * len(chunk))()
+        keep = []
+        for i, (y, mod, pro) in enumerate(chunk):
+            M = y.shape[0]
+            if y.shape[1] != N or M > SMALL_MAX_ROWS:
+                raise ValueError("small_bn_act_group: same width, M <= 4096")
+            out = torch.empty_like(y)
+            st = torch.empty(4, N, dtype=torch.float32, device=y.device) if mod is not None else None
+            arr[i] = SmallBnT(_p(y).value if M else None, _p(out).value if M else None,
+                              _p(mod.weight.detach()).value if mod is not None else None,
+                              _p(mod.bias.detach()).value if mod is not None else None,
+                              _p(mod.running_mean).value if mod is not None else None,
+                              _p(mod.running_var).value if mod is not None else None,
+                              _p(st).value if st is not None else None, M, int(training), int(pro.relu), float(pro.p),
+                              int(pro.seed) & 0xFFFFFFFFFFFFFFFF, int(pro.site), int(pro.row_offset),
+                              _p(pro.seed_dev, torch.int64).value if pro.seed_dev is not None else None)
+            keep.append((out, st))
+            fold = None
+            if mod is not None:
+                fold = BNFold(st[0], st[1], st[2], st[3], M, training)
+                pro.scale, pro.shift = st[0], st[1]
+            res.append((out, fold))
+        check(lib.mmg_small_bn_act_group(arr, len(chunk), N, BN_MOMENTUM, BN_EPS, _stream()), "mmg_small_bn_act_group")
+    return res
+
+
+def small_bn_bwd_group(items):
+    """items: list of (g [M,N], y [M,N], Pro, BNFold or None) -> list of (dy, dbeta or None, dgamma or None)
+    (mmg_small_bn_bwd_group: the backward of small_bn_act_group, one launch)."""
+    lib = _lib.load()
+    res = []
+    if not items:
+        return res
+    N = items[0][1].shape[1]
+    for i0 in range(0, len(items), 8):
+        chunk = items[i0:i0 + 8]
+        arr = (SmallBnBwdT * len(chunk))()
+        for i, (g, y, pro, fold) in enumerate(chunk):
+            M = y.shape[0]
+            dy = torch.empty_like(y)
+            dbg = torch.empty(2, N, dtype=torch.float32, device=y.device) if fold is not None else None
+            arr[i] = SmallBnBwdT(_p(g).value if M else None, _p(y).value if M else None, _p(dy).value if M else None,
+                                 _p(fold.scale).value if fold is not None else None,
+                                 _p(fold.shift).value if fold is not None else None,
+                                 _p(fold.mean).value if fold is not None else None,
+                                 _p(fold.rstd).value if fold is not None else None,
+                                 _p(dbg[0]).value if dbg is not None else None, _p(dbg[1]).value if dbg is not None else None,
+                                 M, int(fold.training) if fold is not None else 0, int(pro.relu), float(pro.p),
+                                 int(pro.seed) & 0xFFFFFFFFFFFFFFFF, int(pro.site), int(pro.row_offset),
+                                 _p(pro.seed_dev, torch.int64).value if pro.seed_dev is not None else None)
+            res.append((dy, dbg[0] if dbg is not None else None, dbg[1] if dbg is not None else None))
+        check(lib.mmg_small_bn_bwd_group(arr, len(chunk), N, _stream()), "mmg_small_bn_bwd_group")
     return res

@@ -608,3 +608,67 @@ def test_small_fwd_and_wgrad_groups(dev):
                 assert float((db.double() - rb).abs().max()) <= 2e-6 * max(float(rb.abs().max()), 1e-30), (K, N, M)
             else:
                 assert db is None
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("act,p", [(1, 0.0), (1, 0.3), (3, 0.2), (2, 0.0)])
+def test_small_bn_groups_match_the_separate_kernels(dev, training, act, p):
+    """mmg_small_bn_act_group / mmg_small_bn_bwd_group against the kernels they fuse (column statistics, mmg_bn_finalize,
+    mmg_affine_act_drop; mmg_bn_bwd_stats, mmg_bn_bwd_apply): same outputs, same dropout masks, same running statistics,
+    same folded vectors -- for several small node types in one launch, with and without BatchNorm."""
+    import mmgnn  # noqa: F401
+    from mmgnn import ops
+    gen = torch.Generator().manual_seed(17)
+    N, seed = 128, 9001
+    Ms = [50, 114, 100, 2, 333]
+    items, refs = [], []
+    for i, M in enumerate(Ms):
+        y = (torch.randn(M, N, generator=gen) * 2 + 0.3).to(dev)
+        use_bn = i != 3
+        mod = torch.nn.BatchNorm1d(N).to(dev) if use_bn else None
+        if use_bn:
+            with torch.no_grad():
+                mod.weight.copy_(torch.rand(N, generator=gen) + 0.5); mod.bias.copy_(torch.randn(N, generator=gen) * 0.1)
+                mod.running_mean.copy_(torch.randn(N, generator=gen) * 0.1); mod.running_var.copy_(torch.rand(N, generator=gen) + 0.5)
+        site = 16 + i
+        # reference: the separate kernels on a copy of the module
+        if use_bn:
+            ref_mod = torch.nn.BatchNorm1d(N).to(dev)
+            ref_mod.load_state_dict(mod.state_dict())
+            sums = ops.col_reduce2(y) if training else None
+            fold = ops.bn_finalize(sums, M, ref_mod.weight.detach(), ref_mod.bias.detach(), ref_mod.running_mean,
+                                   ref_mod.running_var, training, 1)
+            pro_r = ops.Pro(fold.scale, fold.shift, act, p, seed, site, 0)
+        else:
+            ref_mod, fold = None, None
+            pro_r = ops.Pro(None, None, act, p, seed, site, 0)
+        out_r = ops.affine_act_drop(y, pro_r)
+        g = torch.randn(M, N, generator=gen).to(dev)
+        if fold is not None and training:
+            bs = ops.bn_bwd_stats(g, y, pro_r, fold)
+            dbg = torch.empty(2, N, device=dev)
+            dy_r = ops.bn_bwd_apply(g, y, pro_r, fold, bs, M, dbg[0], dbg[1])
+        elif fold is not None:
+            bs = ops.bn_bwd_stats(g, y, pro_r, fold)
+            dbg = bs.float()
+            dy_r = ops.bn_bwd_apply(g, y, pro_r, fold)
+        else:
+            dbg = None
+            dy_r = ops.bn_bwd_apply(g, y, pro_r, None)
+        items.append((y, mod, ops.Pro(None, None, act, p, seed, site, 0)))
+        refs.append((out_r, fold, ref_mod, g, dy_r, dbg))
+    res = ops.small_bn_act_group(items, training)
+    bitems = []
+    for (y, mod, pro), (out, fold), (out_r, fold_r, ref_mod, g, dy_r, dbg) in zip(items, res, refs):
+        assert torch.equal(out == 0, out_r == 0)                       # the same dropout / ReLU pattern
+        assert rel(out, out_r) <= 2e-6
+        if mod is not None:
+            assert rel(fold.scale, fold_r.scale) <= 1e-6 and rel(fold.mean, fold_r.mean) <= 1e-6 + 1e-6
+            assert rel(mod.running_mean, ref_mod.running_mean) <= 1e-6 and rel(mod.running_var, ref_mod.running_var) <= 1e-6
+        bitems.append((g, y, pro, fold))
+    for (dy, dbeta, dgamma), (out_r, fold_r, ref_mod, g, dy_r, dbg) in zip(ops.small_bn_bwd_group(bitems), refs):
+        assert rel(dy, dy_r) <= 5e-6
+        if dbg is not None:
+            assert rel(dbeta, dbg[0]) <= 2e-6 and rel(dgamma, dbg[1]) <= 2e-6
+        else:
+            assert dbeta is None and dgamma is None
