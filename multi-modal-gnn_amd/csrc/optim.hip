@@ -25,13 +25,22 @@ __global__ __launch_bounds__(256) void k_adam(AdamTable tb, float* __restrict__ 
   const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
   const float step_size = lr / bc1;
   const int total = tb.off[tb.n] - tb.off[0];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int e = tb.off[0] + i;
-    int lo = 0, hi = tb.n;                       // tensor of element e: last offset <= e
+  // every workgroup owns one contiguous chunk of the bucket, so a thread's elements (256 apart) cross a tensor boundary
+  // rarely: one binary search for its first element, then a linear advance
+  const int chunk = ((total + gridDim.x - 1) / gridDim.x + 255) & ~255;
+  const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
+  int lo = 0;
+  {
+    const int e0 = tb.off[0] + beg + threadIdx.x;
+    int hi = tb.n;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (tb.off[mid] <= e) lo = mid; else hi = mid;
+      if (tb.off[mid] <= e0) lo = mid; else hi = mid;
     }
+  }
+  for (int i = beg + threadIdx.x; i < end; i += 256) {
+    const int e = tb.off[0] + i;
+    while (lo + 1 < tb.n && tb.off[lo + 1] <= e) ++lo;
     const float* gp = tb.grad[lo];
     if (!gp) continue;
     float g = gp[e - tb.off[lo]];
@@ -85,9 +94,9 @@ extern "C" int mmg_adam_step(float* p, float* m, float* v, const float* const* g
     tb.off[n] = offsets[t0 + n];
     MMG_CHECK_ARG(tb.off[n] >= tb.off[0], "adam_step: offsets must ascend");
     const int total = tb.off[n] - tb.off[0];
-    int nb = (total + 256 * 4 - 1) / (256 * 4);
+    int nb = (total + 256 * 8 - 1) / (256 * 8);
     if (nb < 1) nb = 1;
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     const int last = t0 + MMG_ADAM_MAX_TENSORS >= n_tensors;
     hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, st, tb, p, m, v, lr, beta1, beta2, eps, weight_decay, step, ticket, last);
   }
