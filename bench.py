@@ -473,9 +473,13 @@ def main():
                     e["algorithmic_bytes"] = s_["alg_bytes"]
                     e["hbm_frac"] = s_["hbm_frac"]
                     assert 0.0 < e["hbm_frac"] <= 1.0, (name, e)
-                tr = traffic.get(op)
+                tr = traffic.get({"scatter_rowscale": "scatter_rows_rowscale"}.get(name, op))
                 if tr and s_["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / s_["alg_bytes"] < 2.0:
                     e["traffic"] = tr["hbm_bytes_per_launch"]
+                    fol = traffic.get({"scatter_rows": "scatter_reduce", "linear_wgrad": "linear_wgrad_reduce"}.get(op))
+                    if fol and "slab_sum_us" in e:
+                        e["traffic"] += fol["hbm_bytes_per_launch"]       # the slab sum that finishes the op
+                    e["traffic_kernel"] = tr["kernel"]
                 ks[name] = e
             out["kernels"] = ks
             out["kernel_ms_per_step_all_probed"] = sum(fam.values())

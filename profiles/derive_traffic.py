@@ -18,7 +18,9 @@ import sys
 from collections import defaultdict
 
 OP_OF_KERNEL = [("k_linear_fwd", "linear_fwd"), ("k_linear_small", "linear_fwd"), ("k_linear_wgrad", "linear_wgrad"),
-                ("k_gather", "gather_rows"), ("k_scatter_bits", "scatter_rows"), ("k_scatter_mfma", "scatter_rows"),
+                ("k_gather", "gather_rows"), ("k_scatter_strip", "scatter_rows"), ("k_scatter_units", "scatter_rows_rowscale"),
+                ("k_scatter_bits", "scatter_rows"), ("k_scatter_mfma", "scatter_rows"),
+                ("mmg_k_reduce_slabs<EpiScatter>", "scatter_reduce"), ("mmg_k_reduce_slabs<EpiStore>", "linear_wgrad_reduce"),
                 ("k_pair_fwd", "pair_head_fwd"), ("k_pair_bwd", "pair_head_bwd"), ("k_bn_bwd_apply", "bn_bwd_apply"),
                 ("k_col_reduce<1", "bn_bwd_stats"), ("k_col_reduce<0", "col_reduce2"), ("k_affine_act_drop", "affine_act_drop"),
                 ("k_l2norm_fwd", "l2norm_fwd"), ("k_l2norm_bwd", "l2norm_bwd"), ("k_pair_loss", "pair_loss"),
