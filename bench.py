@@ -291,6 +291,10 @@ def agg_extra(w, D):
             kg, ks = sum(r.n_cols for r in rels), sum((r.n_cols + 31) // 32 * 32 for r in rels)
             for acc in (0, 1):
                 extra[("gather_rows", kg, acc)] = rel_bytes(rels, True, False) + 4 * D * P * (2 if acc else 1)
+            # (the strip kernel packs the relations' items back to back: its padded row count is the instance's)
+            tiles = (kg + 31) // 32
+            k_strip = next((i * 32 for i in (4, 8, 9, 10) if tiles <= i), ks)
+            extra[("scatter_rows", k_strip, 0)] = rel_bytes(rels, False, True) + 4 * D * P
             extra[("scatter_rows", ks, 0)] = rel_bytes(rels, False, True) + 4 * D * P
             extra[("scatter_rows", ks, 8)] = rel_bytes(rels, True, False) + 4 * D * P
     return extra

@@ -405,26 +405,27 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   if (ns > 0) {
-    // this wave's tiles: mask pointer (lane = item row of the tile and patient half), words per stage.
-    // Padding tiles (no relation) read some valid word and select the all-zero LUT entry.
+    // The items of all relations are PACKED back to back (rp.r[r].acc_off = items in front of relation r): 264 items of
+    // the eICU vocabulary are 9 tiles, not the 10 that per-relation padding to 32 would need -- a tile may straddle two
+    // relations, so every LANE has its own bit-plane row (pointer and per-stage stride); lanes past the last item read
+    // some valid word and select the all-zero LUT entry.
     const uint64_t* mb[NT];
-    int ms[NT];
-    bool live[NT];
+    unsigned ms[NT], lm[NT];
     const uint64_t* any_mask = nullptr;
 #pragma unroll
     for (int r = 0; r < MMG_MAX_REL; ++r)
       if (r < rp.n && rp.r[r].mask && !any_mask) any_mask = rp.r[r].mask;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      mb[t] = any_mask; ms[t] = 0; live[t] = false;
-      const int c0 = t * 32;
+      mb[t] = any_mask; ms[t] = 0; lm[t] = 0u;
+      const int it = t * 32 + l31;
 #pragma unroll
       for (int r = 0; r < MMG_MAX_REL; ++r) {
         if (r >= rp.n) continue;
         const int padc = (rp.r[r].n_cols + 31) & ~31;
-        if (rp.r[r].mask && c0 >= rp.r[r].acc_off && c0 < rp.r[r].acc_off + padc) {
-          mb[t] = rp.r[r].mask + ((size_t)s_beg * padc + (c0 - rp.r[r].acc_off) + l31) * 2 + h;
-          ms[t] = 2 * padc; live[t] = true;
+        if (rp.r[r].mask && it >= rp.r[r].acc_off && it < rp.r[r].acc_off + rp.r[r].n_cols) {
+          mb[t] = rp.r[r].mask + ((size_t)s_beg * padc + (it - rp.r[r].acc_off)) * 2 + h;
+          ms[t] = 2u * (unsigned)padc; lm[t] = 0xFF0u;
         }
       }
     }
@@ -455,8 +456,7 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const unsigned w = (kq & 2) ? (unsigned)(mw[t] >> 32) : (unsigned)mw[t];
-        unsigned off = __builtin_amdgcn_ubfe(w, 16u * (kq & 1), 12u);
-        if (!live[t]) off = 0;
+        const unsigned off = (kq & 1) ? ((w >> 16) & lm[t]) : (w & lm[t]);       // field << 4, 0 for a lane without an item
         af[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
       }
     };
@@ -546,19 +546,20 @@ struct StripPlan { bool ok; int nt; int n_ranges; int total_pad; };
 StripPlan plan_strip(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
   StripPlan sp{};
   sp.ok = false;
-  int tiles = 0;
+  int items = 0;
   bool has_rs = false;
   for (int r = 0; r < n_rel; ++r) {
     if (rels[r].n_cols == 0) continue;
     if ((rels[r].flags & MMG_REL_SIMPLE) == 0 || rels[r].mask_t == nullptr) return sp;
-    tiles += pad32(rels[r].n_cols) / 32;
+    items += rels[r].n_cols;                         // relations packed back to back: tiles may straddle them
     has_rs |= rels[r].rowscale != nullptr;
   }
+  const int tiles = (items + 31) / 32;
   // (one wave holds every tile's accumulators + a double-buffered operand set: 10 tiles fill the 512 registers)
   if (tiles == 0 || tiles > 10 || n_rows < SB_SR) return sp;
   if (has_rs) return sp;
-  const int inst[] = {4, 8, 10};
-  for (int i = 0; i < 3; ++i)
+  const int inst[] = {4, 8, 9, 10};
+  for (int i = 0; i < 4; ++i)
     if (tiles <= inst[i]) { sp.nt = inst[i]; break; }
   sp.total_pad = sp.nt * 32;
   const int strips = D / 32;
@@ -1503,13 +1504,17 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
   const StripPlan sp = plan_strip(rels, n_rel, n_rows, D);
   if (sp.ok) {
     int rc2 = MMG_OK;
-    if (sp.nt == 4) rc2 = launch_scatter_strip<4>(rp, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-    else if (sp.nt == 8) rc2 = launch_scatter_strip<8>(rp, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-    else rc2 = launch_scatter_strip<10>(rp, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    RelPack rq;                                       // packed accumulator rows: acc_off = items in front of the relation
+    int rc3 = pack(rels, n_rel, &rq, false, true, false);
+    if (rc3) return rc3;
+    if (sp.nt == 4) rc2 = launch_scatter_strip<4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else if (sp.nt == 8) rc2 = launch_scatter_strip<8>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else if (sp.nt == 9) rc2 = launch_scatter_strip<9>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else rc2 = launch_scatter_strip<10>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     if (rc2) return rc2;
     const int64_t n = (int64_t)sp.total_pad * D;
     MMG_LAUNCH(MMG_PROBE_SCATTER_REDUCE, n_rows, D, sp.total_pad, 0, (mmg_k_reduce_slabs<EpiScatter>),
-               dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4, sp.n_ranges, EpiScatter{rp, D});
+               dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, slab, n / 4, sp.n_ranges, EpiScatter{rq, D});
     MMG_CHECK_LAUNCH("scatter_rows(strip)");
     return MMG_OK;
   }
