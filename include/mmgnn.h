@@ -394,8 +394,15 @@ int mmg_small_bn_bwd_group(const mmg_small_bn_bwd_t* probs, int n_probs, int N, 
  * wrote it.  Arithmetic of torch.optim.Adam (amsgrad / maximize off, L2 weight decay added to the gradient).  `step`
  * (device float, the number of steps taken so far) is advanced by the kernel -- hipGraph replays keep counting --
  * through `ticket` (device uint32, zero-initialised by the caller once).
- * mmg_vec_sums: dst_j = src_j0 + src_j1 (+ src_j2 + src_j3), fixed order, <= MMG_SUM_MAX_JOBS vectors per launch (the
- * three lin_r weights / lin_l biases that share x_patient in a HeteroConv layer, src/model.py:125-131).
+ * mmg_vec_sums: dst_j = src_j0 (+ src_j1 + src_j2 + src_j3), fixed order, <= MMG_SUM_MAX_JOBS jobs per launch (the
+ * three lin_r weights / lin_l biases that share x_patient in a HeteroConv layer, src/model.py:125-131; the gradient
+ * contributions of a parameter that is used twice).  A job is a [len / cols, cols] matrix with its own row stride on
+ * every side (cols = 0: a flat vector), so the same launch also takes the two halves of an edge head's first-layer
+ * weight W1[:, :D] | W1[:, D:] apart (src/model.py:375-382: the head's Linear(2D, H)) and puts their gradients together.
+ * mmg_counters_add: *counters[i] += incs[i] for <= MMG_SUM_MAX_JOBS * 4 int64 counters (BatchNorm1d.num_batches_tracked
+ * of every layer in one launch).  mmg_seed_advance: state[1] += 1 step of a SplitMix64 stream, state[0] = its output
+ * (< 2^62) -- the dropout seed the kernels read through mmg_prologue_t.seed_ptr, advanced inside a captured step.
+ * mmg_fill_zero: hipMemsetAsync under the library's error handling.
  * ------------------------------------------------------------------------------------- */
 #define MMG_ADAM_MAX_TENSORS 96
 #define MMG_SUM_MAX_JOBS 8
@@ -407,8 +414,15 @@ typedef struct {
   const float* src[4];
   int n_src;               /* 1..4 */
   int len;                 /* elements */
+  int cols;                /* 0: flat;  > 0: rows of `cols` elements (len % cols == 0) with the strides below */
+  int ld_dst;              /* row stride of dst (elements) */
+  int ld_src[4];           /* row stride of every source */
 } mmg_sum_job_t;
 int mmg_vec_sums(const mmg_sum_job_t* jobs, int n_jobs, void* stream);
+#define MMG_COUNTERS_MAX 32
+int mmg_counters_add(int64_t* const* counters, const int64_t* incs, int n, void* stream);
+int mmg_seed_advance(uint64_t* state /* [2]: seed | stream position */, void* stream);
+int mmg_fill_zero(void* ptr, size_t bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Evaluation reducers on the device (src/evaluate.py:36-82 metrics, :417-440 per-lab +-3 sigma winsorisation, :89-141

@@ -65,7 +65,8 @@ class SmallBnBwdT(C.Structure):
 
 
 class SumJobT(C.Structure):
-    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p * 4), ("n_src", C.c_int), ("len", C.c_int)]
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p * 4), ("n_src", C.c_int), ("len", C.c_int),
+                ("cols", C.c_int), ("ld_dst", C.c_int), ("ld_src", C.c_int * 4)]
 
 
 _vp, _i64, _i32, _f32, _sz, _u64, _u32 = (C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t,
@@ -124,6 +125,9 @@ SIGNATURES = {
     "mmg_small_bn_bwd_group": (C.c_int, [_P(SmallBnBwdT), _i32, _i32, _vp]),
     "mmg_adam_step": (C.c_int, [_vp, _vp, _vp, _P(C.c_void_p), _P(C.c_int32), _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
     "mmg_vec_sums": (C.c_int, [_P(SumJobT), _i32, _vp]),
+    "mmg_counters_add": (C.c_int, [_P(C.c_void_p), _P(C.c_int64), _i32, _vp]),
+    "mmg_seed_advance": (C.c_int, [_vp, _vp]),
+    "mmg_fill_zero": (C.c_int, [_vp, _sz, _vp]),
     "mmg_seg_reduce_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_seg_moments": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "mmg_seg_metrics": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _f32, _vp, _vp, _vp, _sz, _vp]),

@@ -376,6 +376,12 @@ __device__ inline void split8(const float* v, bf16x8& p0, bf16x8& p1, bf16x8& p2
 // on its SIMD hides at most ~24 cycles of other issue per 32-cycle MFMA (MI355X_MICROARCH.md), so the vector work is
 // dealt out between the MFMAs explicitly (sched_group_barrier) instead of left in clumps.
 constexpr int ST_TP = 5;                     // tiles per phase of the final cross-wave sum (80 registers x 4 waves = 80 KB)
+#ifdef MMG_STAMPS                             // diagnostic build only (scratch/): per-wave s_memtime stamps of the phases
+__device__ unsigned long long g_stamps[1024 * 8];
+#define MMG_STAMP(i) do { if (lane == 0) g_stamps[(size_t)(blockIdx.y * gridDim.x * 4 + blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MMG_STAMP(i) do { } while (0)
+#endif
 
 template <int NT>
 __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_rows, int n_stage_total, int D, int total_pad,
@@ -387,10 +393,12 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
   const int d0 = blockIdx.y * 32;
+  MMG_STAMP(0);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
     lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
   __syncthreads();
+  MMG_STAMP(1);
   // stages of this wave: the n_stage_total 64-row stages are dealt evenly over (workgroup, wave)
   const int q_id = blockIdx.x * 4 + wid, n_q = gridDim.x * 4;
   const int s_beg = (int)((int64_t)q_id * n_stage_total / n_q);
@@ -470,6 +478,7 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
     bf16x8 afc[NT], bc[3];
     make_af(mc, 0, afc);
     split8(xq[0], bc[0], bc[1], bc[2]);
+    MMG_STAMP(2);
 
     const int n2 = (ns + 1) / 2;
     for (int u = 0; u < n2; ++u) {
@@ -502,6 +511,7 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
       }
     }
   }
+  MMG_STAMP(3);
   // ---- fixed-order sum of the four waves' partial accumulators through LDS, ST_TP tiles at a time: every wave parks
   // its registers of the phase, then sums a QUARTER of them over the four copies (wave 0 + 1 + 2 + 3) and stores it
   float* dst = slab + (size_t)blockIdx.x * total_pad * D + d0 + l31;
@@ -528,6 +538,7 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
       dst[(size_t)vrow * D] = v;
     }
   }
+  MMG_STAMP(4);
 }
 
 template <int NT>
@@ -1557,6 +1568,12 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
   MMG_CHECK_LAUNCH("scatter_rows");
   return MMG_OK;
 }
+
+#ifdef MMG_STAMPS
+extern "C" int mmg_debug_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8);
+}
+#endif
 
 extern "C" size_t mmg_rel_mask_words(int64_t n_rows, int32_t n_cols) {
   if (n_rows <= 0 || n_cols <= 0) return 0;

@@ -65,17 +65,32 @@ struct SumJobs {
   float* dst[MMG_SUM_MAX_JOBS];
   const float* src[MMG_SUM_MAX_JOBS][4];
   int n_src[MMG_SUM_MAX_JOBS], len[MMG_SUM_MAX_JOBS];
+  int cols[MMG_SUM_MAX_JOBS], ld_dst[MMG_SUM_MAX_JOBS], ld_src[MMG_SUM_MAX_JOBS][4];
   int n;
 };
 
 __global__ __launch_bounds__(256) void k_vec_sums(SumJobs jb) {
   const int j = blockIdx.y;
-  const int n = jb.len[j];
+  const int n = jb.len[j], cols = jb.cols[j];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    float s = jb.src[j][0][i];
-    for (int q = 1; q < jb.n_src[j]; ++q) s += jb.src[j][q][i];      // fixed order
-    jb.dst[j][i] = s;
+    const int r = i / cols, c = i - r * cols;                         // (a flat job is one row)
+    float s = jb.src[j][0][(size_t)r * jb.ld_src[j][0] + c];
+    for (int q = 1; q < jb.n_src[j]; ++q) s += jb.src[j][q][(size_t)r * jb.ld_src[j][q] + c];      // fixed order
+    jb.dst[j][(size_t)r * jb.ld_dst[j] + c] = s;
   }
+}
+
+struct CounterTable { int64_t* p[MMG_COUNTERS_MAX]; int64_t inc[MMG_COUNTERS_MAX]; int n; };
+__global__ void k_counters_add(CounterTable tb) {
+  const int i = threadIdx.x;
+  if (i < tb.n) *tb.p[i] += tb.inc[i];
+}
+
+__global__ void k_seed_advance(uint64_t* state) {
+  uint64_t z = (state[1] += 0x9E3779B97F4A7C15ull);                   // SplitMix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  state[0] = (z ^ (z >> 31)) >> 2;
 }
 
 }  // namespace
@@ -112,7 +127,16 @@ extern "C" int mmg_vec_sums(const mmg_sum_job_t* jobs, int n_jobs, void* stream)
   for (int j = 0; j < n_jobs; ++j) {
     MMG_CHECK_ARG(jobs[j].dst && jobs[j].n_src >= 1 && jobs[j].n_src <= 4 && jobs[j].len >= 0, "vec_sums: bad job %d", j);
     jb.dst[j] = jobs[j].dst; jb.n_src[j] = jobs[j].n_src; jb.len[j] = jobs[j].len;
-    for (int q = 0; q < 4; ++q) jb.src[j][q] = q < jobs[j].n_src ? jobs[j].src[q] : nullptr;
+    const int cols = jobs[j].cols;
+    MMG_CHECK_ARG(cols >= 0 && (cols == 0 || jobs[j].len % cols == 0), "vec_sums: job %d: len is not a multiple of cols", j);
+    jb.cols[j] = cols > 0 ? cols : (jobs[j].len > 0 ? jobs[j].len : 1);
+    jb.ld_dst[j] = cols > 0 ? jobs[j].ld_dst : 0;
+    MMG_CHECK_ARG(cols == 0 || jobs[j].ld_dst >= cols, "vec_sums: job %d: ld_dst < cols", j);
+    for (int q = 0; q < 4; ++q) {
+      jb.src[j][q] = q < jobs[j].n_src ? jobs[j].src[q] : nullptr;
+      jb.ld_src[j][q] = cols > 0 ? jobs[j].ld_src[q] : 0;
+      MMG_CHECK_ARG(cols == 0 || q >= jobs[j].n_src || jobs[j].ld_src[q] >= cols, "vec_sums: job %d: ld_src < cols", j);
+    }
     for (int q = 0; q < jobs[j].n_src; ++q) MMG_CHECK_ARG(jobs[j].src[q], "vec_sums: job %d has a null source", j);
     if (jobs[j].len > maxlen) maxlen = jobs[j].len;
   }
@@ -121,5 +145,34 @@ extern "C" int mmg_vec_sums(const mmg_sum_job_t* jobs, int n_jobs, void* stream)
   if (nb > 64) nb = 64;
   hipLaunchKernelGGL(k_vec_sums, dim3(nb, n_jobs), dim3(256), 0, (hipStream_t)stream, jb);
   MMG_CHECK_LAUNCH("vec_sums");
+  return MMG_OK;
+}
+
+extern "C" int mmg_counters_add(int64_t* const* counters, const int64_t* incs, int n, void* stream) {
+  MMG_CHECK_ARG(n >= 0 && n <= MMG_COUNTERS_MAX, "counters_add: 0..%d counters", MMG_COUNTERS_MAX);
+  if (n == 0) return MMG_OK;
+  MMG_CHECK_ARG(counters && incs, "counters_add: null table");
+  CounterTable tb;
+  tb.n = n;
+  for (int i = 0; i < n; ++i) {
+    MMG_CHECK_ARG(counters[i], "counters_add: counter %d is null", i);
+    tb.p[i] = counters[i]; tb.inc[i] = incs[i];
+  }
+  hipLaunchKernelGGL(k_counters_add, dim3(1), dim3(64), 0, (hipStream_t)stream, tb);
+  MMG_CHECK_LAUNCH("counters_add");
+  return MMG_OK;
+}
+
+extern "C" int mmg_seed_advance(uint64_t* state, void* stream) {
+  MMG_CHECK_ARG(state, "seed_advance: null state");
+  hipLaunchKernelGGL(k_seed_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  MMG_CHECK_LAUNCH("seed_advance");
+  return MMG_OK;
+}
+
+extern "C" int mmg_fill_zero(void* ptr, size_t bytes, void* stream) {
+  if (bytes == 0) return MMG_OK;
+  MMG_CHECK_ARG(ptr, "fill_zero: null buffer");
+  MMG_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream), "fill_zero");
   return MMG_OK;
 }

@@ -284,6 +284,7 @@ class _Run:
         self.partial = set()         # param grads that are per-shard partial sums (need the final all-reduce)
         self.tape = {}
         self._nbt = {}               # BatchNorm step counters to advance: {id(module): [buffer, increment]}
+        self.pending = {}            # parameter name -> further gradient contributions, summed at the end of the backward
         self.pairs = None
         self.lazy_final = False      # predict mode: the final patient activations stay folded (see _LazyAct)
         # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
@@ -310,11 +311,23 @@ class _Run:
     def acc(self, name, g, partial=False):
         if name in self.grads:
             if g is not self.grads[name]:            # (a producer that accumulated in place hands the same tensor back)
-                self.grads[name] = self.grads[name] + g
+                self.pending.setdefault(name, []).append(g)      # summed by flush_grad_sums: one launch for all of them
         else:
             self.grads[name] = g
         if partial:
             self.partial.add(name)
+
+    def flush_grad_sums(self):
+        """grads[name] += every later contribution recorded by acc(), all parameters in ONE mmg_vec_sums launch per 8."""
+        jobs = []
+        for name, more in self.pending.items():
+            dst = self.grads[name]
+            while more:                               # (4 sources per job: dst itself + 3)
+                jobs.append((dst, [dst] + [m.reshape(dst.shape) for m in more[:3]]))
+                more = more[3:]
+        self.pending = {}
+        for j0 in range(0, len(jobs), 8):
+            ops.vec_sums(jobs[j0:j0 + 8])
 
     def allreduce(self, t):
         if self.comm is not None:
@@ -345,11 +358,9 @@ class _Run:
 
     # ======================================================================== forward driver
     def _bump_counters(self):
-        by_inc = {}
-        for buf, inc in self._nbt.values():
-            by_inc.setdefault(inc, []).append(buf)
-        for inc, bufs in by_inc.items():
-            torch._foreach_add_(bufs, inc)           # one multi-tensor launch for all num_batches_tracked buffers
+        ents = [e for e in self._nbt.values() if e[1]]
+        if ents:                                         # every num_batches_tracked buffer in ONE launch
+            ops.counters_add([b for b, _ in ents], [i for _, i in ents])
         self._nbt = {}
 
     def run_forward(self, mode):
@@ -449,6 +460,7 @@ class _Run:
                     self.acc(f"embeddings.{t}.weight", gt)
             if g_init.get("lab") is not None:
                 self.acc("embeddings.lab.weight", g_init["lab"])
+        self.flush_grad_sums()
         if self.comm is not None and self.partial:
             self.comm.all_reduce_list([self.grads[n] for n in sorted(self.partial)])
         out = []
@@ -1014,16 +1026,24 @@ class _Run:
         return g_in
 
     # ======================================================================== heads
-    def head_tensors(self, which, xP, xlab):
+    def head_weight_halves(self):
+        """W1[:, :D] | W1[:, D:] of both heads' first Linear(2D, H) as contiguous matrices: ONE launch for the four."""
+        D, out, jobs = self.D, {}, []
+        for which in ("edge_predictor", "tabular_mlp"):
+            w1 = getattr(self.m, which).mlp[0].weight.detach()
+            halves = torch.empty(2, w1.shape[0], D, device=self.dev)
+            jobs += [(halves[0], [w1[:, :D]]), (halves[1], [w1[:, D:]])]
+            out[which] = (halves[0], halves[1])
+        ops.vec_sums(jobs)
+        return out
+
+    def head_tensors(self, which, xP, xlab, w1a, w1b):
         """xP: the patient rows this head can see (all of them, or the compacted low-degree rows)."""
         mod = getattr(self.m, which)
-        D = self.D
-        w1 = mod.mlp[0].weight.detach()
-        w1a, w1b = w1[:, :D].contiguous(), w1[:, D:].contiguous()
         if isinstance(xP, _LazyAct):
             A = ops.linear_fwd(xP.y, w1a, pro=xP.pro)
         else:
-            A = ops.linear_fwd(xP, w1a) if xP.shape[0] else torch.zeros(1, w1a.shape[0], device=self.dev)
+            A = ops.linear_fwd(xP, w1a) if xP.shape[0] else ops.zeros(1, w1a.shape[0], device=self.dev)
         B = ops.linear_fwd(xlab, w1b, mod.mlp[0].bias.detach())
         head = ops.Head(A, B, mod.mlp[3].weight.detach(), mod.mlp[3].bias.detach(),
                         mod.mlp[6].weight.detach().reshape(-1).contiguous(), mod.mlp[6].bias.detach())
@@ -1037,13 +1057,14 @@ class _Run:
         thr = int(self.m.degree_threshold)
         pred = torch.empty(pi.numel(), device=self.dev)          # every pair belongs to exactly one head list
         rec = dict(init=init, fin=fin)
+        halves = self.head_weight_halves()
         for which, src, want_low in (("edge_predictor", fin, False), ("tabular_mlp", init, True)):
             # tabular_mlp: patient rows, ids and gate of the compacted low-degree patients (gate: all of them are low)
             if want_low and self._init_compact:
                 xP = src[ROW_TYPE]                                   # the first pass was evaluated on these rows only
             else:
                 xP = src[ROW_TYPE].index_select(0, low_rows) if want_low else src[ROW_TYPE]
-            head, w1a, w1b = self.head_tensors(which, xP, src["lab"])
+            head, w1a, w1b = self.head_tensors(which, xP, src["lab"], *halves[which])
             sel, n_sel, nb = (sel_low, counts[0:1], n_low) if want_low else (sel_high, counts[1:2], n_high)
             ops.pair_head_fwd(head, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr, want_low,
                               self.p, self.seed, ids, pred, self.seed_dev,
@@ -1067,8 +1088,11 @@ class _Run:
         # a sharded run sums them over the ranks with ONE all-reduce
         smalls = {w: [rec[w][0].B, rec[w][0].W2, rec[w][0].b2, rec[w][0].W3, rec[w][0].b3] for w, _, _ in order}
         n_b = sum(smalls[w][0].numel() for w, _, _ in order)
-        flat = torch.zeros(sum(t.numel() for w, _, _ in order for t in smalls[w]), device=self.dev)
-        views, ob, o = {}, 0, n_b
+        n_small = sum(t.numel() for w, _, _ in order for t in smalls[w])
+        n_small_pad = (n_small + 63) & ~63               # (the dA tables behind them start on a 256-byte boundary)
+        # ...and the per-patient tables dA of both heads behind them: ONE zero-fill for everything the kernels add into
+        flat = ops.zeros(n_small_pad + sum(rec[w][0].A.numel() for w, _, _ in order), device=self.dev)
+        views, ob, o, oa, dA = {}, 0, n_b, n_small_pad, {}
         for w, _, _ in order:
             tB = smalls[w][0]
             v = [flat[ob:ob + tB.numel()].view(tB.shape)]
@@ -1077,10 +1101,13 @@ class _Run:
                 v.append(flat[o:o + t.numel()].view(t.shape))
                 o += t.numel()
             views[w] = v
-        gs = {}
+            tA = rec[w][0].A
+            dA[w] = flat[oa:oa + tA.numel()].view(tA.shape)
+            oa += tA.numel()
+        gs, join = {}, []
         for which, src, want_low in order:
             head, w1a, w1b, xP = rec[which]
-            g = ops.Head(torch.zeros_like(head.A), *views[which])
+            g = ops.Head(dA[which], *views[which])
             sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
             ops.pair_head_bwd(head, g, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr,
                               want_low, n_lab, self.p, self.seed, ids, dsorted,
@@ -1097,10 +1124,13 @@ class _Run:
             elif xP.shape[0]:
                 dW1a = ops.linear_wgrad(g.A, xP)
             else:
-                dW1a = torch.zeros(w1a.shape, device=self.dev)
+                dW1a = ops.zeros(*w1a.shape, device=self.dev)
             dW1b, db1 = ops.linear_wgrad(g.B, src["lab"], with_bias=True)
-            self.acc(f"{which}.mlp.0.weight", torch.cat([dW1a, dW1b], dim=1), partial=True)
+            dW1 = torch.empty(w1a.shape[0], 2 * D, device=self.dev)
+            join += [(dW1[:, :D], [dW1a]), (dW1[:, D:], [dW1b])]
+            self.acc(f"{which}.mlp.0.weight", dW1, partial=True)
             self.acc(f"{which}.mlp.0.bias", db1, partial=True)
+        ops.vec_sums(join)                       # [dW1a | dW1b] of both heads: one launch
         self.allreduce(flat[:n_b])               # lab-side partials dB of both heads from the sharded pairs
         for which, src, want_low in order:
             head, w1a, w1b, xP = rec[which]

@@ -633,20 +633,72 @@ def seg_sums(pred: torch.Tensor, target: torch.Tensor, seg: torch.Tensor, n_seg:
     return sums, adj
 
 
+def _p_any(t: torch.Tensor):
+    """device pointer of an fp32 tensor that may be a strided view (the caller passes its strides on)."""
+    if not t.is_cuda:
+        raise _lib.MmgError(f"expected a HIP device tensor, got {t.device} (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected torch.float32, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _rows_view(t: torch.Tensor):
+    """(cols, row stride) of a tensor that is a flat vector or a 2-D matrix with unit column stride."""
+    if t.is_contiguous():
+        return 0, 0
+    if t.dim() == 2 and t.stride(1) == 1:
+        return t.shape[1], t.stride(0)
+    raise ValueError("vec_sums: tensors must be contiguous or 2-D with unit column stride")
+
+
 def vec_sums(jobs):
-    """jobs: list of (dst, [src tensors, 1..4]) -- dst = sum of the sources in list order, ONE launch (mmg_vec_sums)."""
+    """jobs: list of (dst, [src tensors, 1..4]) -- dst = sum of the sources in list order, ONE launch (mmg_vec_sums).
+    2-D tensors may be column slices of wider matrices (row stride > columns): the launch that sums gradient
+    contributions also splits / joins the halves of an edge head's first-layer weight."""
     lib = _lib.load()
     arr = (SumJobT * len(jobs))()
     for j, (dst, srcs) in enumerate(jobs):
         if not 1 <= len(srcs) <= 4:
             raise ValueError("vec_sums: 1..4 sources per job")
+        views = [_rows_view(t) for t in [dst] + list(srcs)]
+        strided = any(c for c, _ in views)
+        cols = 0
+        if strided:
+            if dst.dim() != 2 or any(t.shape != dst.shape for t in srcs):
+                raise ValueError("vec_sums: strided jobs take 2-D tensors of one shape")
+            cols = dst.shape[1]
         sp = (C.c_void_p * 4)()
+        ld = (C.c_int * 4)()
         for q, t in enumerate(srcs):
             if t.numel() != dst.numel():
                 raise ValueError("vec_sums: size mismatch")
-            sp[q] = _p(t).value
-        arr[j] = SumJobT(_p(dst).value, sp, len(srcs), dst.numel())
+            sp[q] = _p_any(t).value
+            ld[q] = (views[q + 1][1] or cols) if strided else 0
+        arr[j] = SumJobT(_p_any(dst).value, sp, len(srcs), dst.numel(), cols,
+                         (views[0][1] or cols) if strided else 0, ld)
     check(lib.mmg_vec_sums(arr, len(jobs), _stream()), "mmg_vec_sums")
+
+
+def counters_add(counters, incs):
+    """*counters[i] += incs[i] (int64 device scalars) in one launch (mmg_counters_add)."""
+    lib = _lib.load()
+    for i0 in range(0, len(counters), 32):
+        cs, ins = counters[i0:i0 + 32], incs[i0:i0 + 32]
+        ptrs = (C.c_void_p * len(cs))(*[_p(c, torch.int64).value for c in cs])
+        inc = (C.c_int64 * len(cs))(*[int(v) for v in ins])
+        check(lib.mmg_counters_add(ptrs, inc, len(cs), _stream()), "mmg_counters_add")
+
+
+def seed_advance(state: torch.Tensor):
+    """state: int64 [2] on the device = (dropout seed the kernels read, stream position); one SplitMix64 step."""
+    check(_lib.load().mmg_seed_advance(_p(state, torch.int64), _stream()), "mmg_seed_advance")
+
+
+def zeros(*shape, device, dtype=torch.float32):
+    """torch.zeros through mmg_fill_zero (hipMemsetAsync on the current stream)."""
+    t = torch.empty(*shape, device=device, dtype=dtype)
+    check(_lib.load().mmg_fill_zero(_p(t, dtype), t.numel() * t.element_size(), _stream()), "mmg_fill_zero")
+    return t
 
 
 # ------------------------------------------------------------------------------------------ grouped small launches

@@ -301,6 +301,16 @@ class _SupervisionState:
         self._set_den(n_sup_global)
 
 
+def _new_seed_state(dev) -> torch.Tensor:
+    """int64 [2] on the device: (dropout seed the kernels read, position of its SplitMix64 stream).  The stream starts
+    from the host generator (torch.manual_seed), so equally seeded ranks draw the same masks; mmg_seed_advance moves it
+    on inside the captured step -- nothing runs between two replays."""
+    from . import ops
+    st = torch.tensor([0, int(torch.randint(0, 2 ** 62, (1,)).item())], dtype=torch.int64, device=dev)
+    ops.seed_advance(st)
+    return st
+
+
 class GraphedTrainStep:
     """One whole training step -- zero_grad, predict_lab_values, weighted loss, backward, optimizer.step --
     captured ONCE into a hipGraph and replayed per epoch (the eICU-scale graph is launch-bound: ~250 kernel
@@ -322,7 +332,7 @@ class GraphedTrainStep:
         self.loss_fn = loss_fn
         if loss_fn not in ("mae", "mse"):
             raise ValueError(f"GraphedTrainStep supports 'mae'/'mse', got {loss_fn}")
-        model._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        model._seed_dev = _new_seed_state(dev)
         self.loss = torch.zeros((), device=dev)
         model.train()
         if len(model.embeddings) == 0:
@@ -348,14 +358,14 @@ class GraphedTrainStep:
         loss = ops.weighted_pair_loss(pred, self.y, self.wl, self.sup, 1.0, self.loss_fn, self._sv.inv_den)
         loss.backward()
         self.opt.step()
-        self.loss.copy_(loss.detach())
+        ops.seed_advance(self.model._seed_dev)       # fresh dropout masks for the next replay, drawn on the device
+        self.loss = loss.detach()                    # (lives in the graph's pool: the same address at every replay)
 
     def set_mask(self, sup_mask, n_sup_global=None):
         """New supervision subset; the normaliser 1 / n_sup follows it (device scalar read by the captured loss)."""
         self._sv.set_mask(sup_mask, n_sup_global)
 
     def step(self) -> torch.Tensor:
-        self.model._seed_dev.random_(0, 2 ** 62)     # fresh dropout masks for this replay
         self.graph.replay()
         return self.loss
 
@@ -388,7 +398,7 @@ class PiecewiseGraphedTrainStep:
         self.loss_fn = loss_fn
         self._ops, self._Run = ops, _Run
         dev = pi.device
-        model._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        model._seed_dev = _new_seed_state(dev)
         self.loss = torch.zeros((), device=dev)
         self.params = [p for p in model.parameters()]
         model.train()
@@ -450,7 +460,8 @@ class PiecewiseGraphedTrainStep:
                 if g is not None:
                     p.grad = g
             self.opt.step()
-            self.loss.copy_(loss.float())
+            ops.seed_advance(model._seed_dev)        # fresh dropout masks for the next replay, drawn on the device
+            self.loss = loss                         # fp64 scalar in the graph's pool: the same address at every replay
 
     # ---- replay
     def set_mask(self, sup_mask, n_sup_global=None):
@@ -458,7 +469,6 @@ class PiecewiseGraphedTrainStep:
         self._sv.set_mask(sup_mask, n_sup_global)
 
     def step(self) -> torch.Tensor:
-        self.model._seed_dev.random_(0, 2 ** 62)
         for kind, x in self.items:
             if kind == "graph":
                 x.replay()

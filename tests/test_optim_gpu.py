@@ -104,3 +104,91 @@ def test_vec_sums(dev):
     ops.vec_sums([(A, a), (B, b), (Cc, c), (Dd, c[:1])])
     assert torch.equal(A, (a[0] + a[1]) + a[2]) and torch.equal(B, (b[0] + b[1]) + b[2])
     assert torch.equal(Cc, ((c[0] + c[1]) + c[2]) + c[3]) and torch.equal(Dd, c[0])
+
+
+def test_vec_sums_takes_column_slices(dev):
+    """2-D jobs with their own row strides: the halves W1[:, :D] | W1[:, D:] of an edge head's Linear(2D, H) are split into
+    contiguous matrices and their gradients joined again in the launch that sums vectors; in-place accumulation."""
+    import mmgnn  # noqa: F401
+    from mmgnn import ops
+    gen = torch.Generator().manual_seed(3)
+    H, D = 64, 128
+    w1 = torch.randn(H, 2 * D, generator=gen).to(dev)
+    halves = torch.empty(2, H, D, device=dev)
+    ops.vec_sums([(halves[0], [w1[:, :D]]), (halves[1], [w1[:, D:]])])
+    assert torch.equal(halves[0], w1[:, :D]) and torch.equal(halves[1], w1[:, D:])
+    ga, gb = torch.randn(H, D, generator=gen).to(dev), torch.randn(H, D, generator=gen).to(dev)
+    g = torch.full((H, 2 * D), 7.0, device=dev)
+    ops.vec_sums([(g[:, :D], [ga]), (g[:, D:], [gb, gb])])
+    assert torch.equal(g, torch.cat([ga, gb + gb], dim=1))
+    acc = ga.clone()
+    ops.vec_sums([(acc, [acc, gb, w1[:, D:]])])                        # dst is also the first source
+    assert torch.equal(acc, (ga + gb) + w1[:, D:])
+    with pytest.raises(ValueError):
+        ops.vec_sums([(g[:, :D], [ga.reshape(-1)])])                   # strided jobs are 2-D on every side
+    with pytest.raises(ValueError):
+        ops.vec_sums([(g.t(), [g.t()])])                               # unit column stride only
+
+
+def test_counters_seed_and_zero_fill(dev):
+    import mmgnn  # noqa: F401
+    from mmgnn import ops
+    cs = [torch.tensor(v, dtype=torch.int64, device=dev) for v in (0, 5, 2 ** 40)]
+    ops.counters_add(cs, [1, 2, 3])
+    ops.counters_add(cs[:1], [4])
+    assert [int(c) for c in cs] == [5, 7, 2 ** 40 + 3]
+    many = [torch.zeros((), dtype=torch.int64, device=dev) for _ in range(40)]        # more than one table
+    ops.counters_add(many, list(range(40)))
+    assert [int(c) for c in many] == list(range(40))
+    # SplitMix64 stream: state[1] is the position, state[0] the seed the kernels read (< 2^62)
+    st = torch.tensor([0, 12345], dtype=torch.int64, device=dev)
+    seen = []
+    for _ in range(3):
+        ops.seed_advance(st)
+        seen.append(int(st[0]))
+    M = (1 << 64) - 1
+    pos, ref = 12345, []
+    for _ in range(3):
+        pos = (pos + 0x9E3779B97F4A7C15) & M
+        z = pos
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        ref.append((z ^ (z >> 31)) >> 2)
+    assert seen == ref and len(set(seen)) == 3 and all(0 <= v < 2 ** 62 for v in seen)
+    z = ops.zeros(3, 1000, device=dev)
+    assert z.shape == (3, 1000) and float(z.abs().max()) == 0.0
+    assert ops.zeros(0, 4, device=dev).numel() == 0
+
+
+def test_graphed_step_draws_new_masks_on_the_device(dev):
+    """A captured step advances its own dropout seed (mmg_seed_advance inside the graph): consecutive replays see
+    different masks, and nothing runs on the stream between two replays."""
+    import mmgnn  # noqa: F401
+    from mmgnn.data import build_plan
+    from mmgnn.model import build_model
+    from mmgnn.synth import make_graph
+    from mmgnn.train import PiecewiseGraphedTrainStep
+    g = make_graph(1, seed=0, device=dev)
+    cfg = {"model": {"architecture": "RGCN", "hidden_dim": 128, "num_layers": 2, "dropout": 0.2, "use_batch_norm": True,
+                     "activation": "relu"}}
+    torch.manual_seed(0)
+    m = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
+    m._init_embeddings(g)
+    plan = build_plan(g, dev, use_cache=False)
+    et = ("patient", "has_lab", "lab")
+    ei = g[et].edge_index
+    pi, li = ei[0].contiguous(), ei[1].contiguous()
+    y = g[et].edge_attr.squeeze(-1).contiguous()
+    sup = torch.arange(pi.numel(), device=dev) % 5 == 0
+    opt = torch.optim.SGD([p for n, p in m.named_parameters() if not n.startswith("embeddings.")], lr=0.0)
+    step = PiecewiseGraphedTrainStep(m, plan, pi, li, y, torch.ones(int(g["lab"].num_nodes), device=dev), opt, sup, None,
+                                     n_sup_global=float(sup.sum()), warmup=1)
+    seeds, losses = [], []
+    for _ in range(3):
+        seeds.append(int(m._seed_dev[0]))
+        losses.append(float(step.step()))
+    assert len(set(seeds)) == 3                        # lr = 0: the parameters stand still, only the masks change
+    assert len(set(losses)) == 3 and step.loss.dtype == torch.float64
+    nbt = int(m.patient_transform[1].num_batches_tracked)
+    step.step()
+    assert int(m.patient_transform[1].num_batches_tracked) > nbt      # BatchNorm counters advance inside the graph
