@@ -394,17 +394,37 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
   const int h = lane >> 5, l31 = lane & 31;
   const int d0 = blockIdx.y * 32;
   MMG_STAMP(0);
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
-  __syncthreads();
-  MMG_STAMP(1);
   // stages of this wave: the n_stage_total 64-row stages are dealt evenly over (workgroup, wave)
   const int q_id = blockIdx.x * 4 + wid, n_q = gridDim.x * 4;
   const int s_beg = (int)((int64_t)q_id * n_stage_total / n_q);
   const int s_end = (int)((int64_t)(q_id + 1) * n_stage_total / n_q);
   const int ns = s_end - s_beg;
   const int64_t r_beg = (int64_t)s_beg * SB_SR;
+  // x goes through a buffer descriptor that covers exactly this wave's rows: the range check returns 0 for rows past
+  // the end and for the run-ahead past the last k-step (no clamps, no exec-masked regions in the loop), and an address
+  // is  descriptor base + one 32-bit lane offset + a scalar row offset  (one VALU add per k-step).
+  const int64_t rows_here = ns <= 0 ? 0 : ((n_rows - r_beg) < (int64_t)ns * SB_SR ? (n_rows - r_beg) : (int64_t)ns * SB_SR);
+  const float* xw = x + (size_t)r_beg * D + d0;
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xw), 0, rows_here > 0 ? (int)((rows_here * D - d0) * 4) : 0, 0x00020000);
+  const unsigned row_bytes = (unsigned)D * 4u;
+  const unsigned voff0 = (unsigned)(8 * h) * row_bytes + (unsigned)l31 * 4u;
+  float xq[RING][8];                                   // ring of k-step operands: slot = k-step & 7
+  auto loadx = [&](int kg, float* dst) {
+    const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, j * row_bytes, 0));
+  };
+  // the ring is primed FIRST: the cold start of the kernel (every wave of the chip asks at once) then runs beside
+  // the LUT build, its barrier and the bit-plane address set-up instead of after them
+#pragma unroll
+  for (int q = 0; q < AHEAD; ++q) loadx(q, xq[q]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
+  __syncthreads();
+  MMG_STAMP(1);
 
   f32x16 acc[NT];
 #pragma unroll
@@ -437,22 +457,6 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
         }
       }
     }
-    // x goes through a buffer descriptor that covers exactly this wave's rows: the range check returns 0 for rows past
-    // the end and for the run-ahead past the last k-step (no clamps, no exec-masked regions in the loop), and an address
-    // is  descriptor base + one 32-bit lane offset + a scalar row offset  (one VALU add per k-step).
-    const int64_t rows_here = (n_rows - r_beg) < (int64_t)ns * SB_SR ? (n_rows - r_beg) : (int64_t)ns * SB_SR;
-    const float* xw = x + (size_t)r_beg * D + d0;
-    const __amdgpu_buffer_rsrc_t xsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xw), 0, (int)((rows_here * D - d0) * 4), 0x00020000);
-    const unsigned row_bytes = (unsigned)D * 4u;
-    const unsigned voff0 = (unsigned)(8 * h) * row_bytes + (unsigned)l31 * 4u;
-    float xq[RING][8];                                 // ring of k-step operands: slot = k-step & 7
-    auto loadx = [&](int kg, float* dst) {
-      const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, j * row_bytes, 0));
-    };
     auto loadm = [&](int s, uint64_t* dst) {           // past the end: re-read the last stage (its x reads as 0)
       const int sc = s < ns ? s : ns - 1;
 #pragma unroll
@@ -470,11 +474,9 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
     };
     uint64_t mc[NT], mn[NT];
     loadm(0, mc);
-    // drain before the ring is primed: the loop is then entered with exactly the loads its back edge carries, so
-    // the wait counts inside stay exact (otherwise every iteration starts by draining the whole ring)
+    // drained completely: the loop is then entered with no load in flight, a subset of what its back edge carries, so
+    // the wait counts inside stay exact
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
-#pragma unroll
-    for (int q = 0; q < AHEAD; ++q) loadx(q, xq[q]);
     bf16x8 afc[NT], bc[3];
     make_af(mc, 0, afc);
     split8(xq[0], bc[0], bc[1], bc[2]);
