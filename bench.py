@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--scale", type=int, default=100, help="eICU-shape multiples per GPU (weak) or in total (--strong)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--shape", choices=["eicu", "mimic"], default="eicu",
+                    help="vocabulary of the synthetic graph: eicu = 50 / 114 / 100 (BASELINE configs 1-4), mimic = 50 / 200 / "
+                         "100 (config 5: conf/config.yaml's MIMIC vocabulary caps)")
     ap.add_argument("--strong", action="store_true")
     ap.add_argument("--no-strong-x1000", action="store_true", help="skip the x1000 patient-sharded sub-record")
     ap.add_argument("--strong-scale", type=int, default=1000)
@@ -102,8 +105,10 @@ def build_workload(args, world, rank, dev, scale, strong):
     cfg = {"model": {"architecture": "RGCN", "hidden_dim": args.dim, "num_layers": 2, "dropout": args.dropout,
                      "use_batch_norm": True, "activation": "relu"}}
     comm = mdist.ShardComm() if world > 1 else None
+    from mmgnn.synth import EICU, MIMIC_LIKE
+    shape = MIMIC_LIKE if args.shape == "mimic" else EICU
     if strong and world > 1:
-        g_all = make_graph(scale, seed=0, device=dev)
+        g_all = make_graph(scale, seed=0, device=dev, shape=shape)
         w = mdist.patient_weights(g_all)
         b = mdist.partition_rows(w, world)
         lo, hi = b[rank], b[rank + 1]
@@ -111,7 +116,7 @@ def build_workload(args, world, rank, dev, scale, strong):
         n_global = int(g_all["patient"].num_nodes)
         del g_all, w
     else:
-        g = make_graph(scale, seed=(0 if strong else 1000 * rank), device=dev)   # this rank's shard of the global graph
+        g = make_graph(scale, seed=(0 if strong else 1000 * rank), device=dev, shape=shape)   # this rank's shard
         P = int(g["patient"].num_nodes)
         lo, hi, n_global = rank * P, (rank + 1) * P, world * P
     torch.manual_seed(42)
@@ -414,7 +419,8 @@ def main():
             "value": total_edges * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"eICU-shape synthetic hetero-graph x{args.scale}"
+            "config": {"workload": (("eICU-shape" if args.shape == "eicu" else "MIMIC-vocabulary (50 / 200 / 100)")
+                                    + f" synthetic hetero-graph x{args.scale}"
                                     + (" total, patient-sharded" if args.strong else " per GPU")
                                     + f", {args.dim}-d, 2 SAGE layers x 6 relations, dropout {args.dropout}"),
                        "patients_per_gpu": head["P_loc"], "has_lab_edges_total": int(total_edges),
