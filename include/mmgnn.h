@@ -196,6 +196,16 @@ int mmg_bn_bwd_apply(const float* G, const float* Y, const mmg_prologue_t* pro, 
                      const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
                      float* dY, int64_t M, int N, int accumulate, void* stream);
 
+/* mmg_bn_bwd_apply folded into the data-gradient GEMM that follows it (autograd of nn.Linear behind BatchNorm1d + relu +
+ * dropout, src/model.py:93-101,258-269):  dZ = pass 2 above at (G, Y)  and  dX[M,N] = dZ[M,K] . W  with W stored [K,N] (the
+ * forward weight in place, as MMG_LIN_W_KN), in ONE pass over G and Y -- dZ is written once for the weight gradient of
+ * the same layer.  Arguments as mmg_bn_bwd_apply (sums NULL: eval mode; pro->scale NULL: no BatchNorm, relu / dropout only);
+ * relu only.  mmg_linear_bnbwd_supported: M > 512, K and N in {64, 128} (one workgroup spans all N columns). */
+int mmg_linear_bnbwd_supported(int64_t M, int N, int K);
+int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean, const float* rstd,
+                     const double* sums, double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ,
+                     float* dX, int64_t M, int N, int K, void* stream);
+
 /* Two upstream gradients through the SAME BatchNorm + ReLU, each with its own dropout mask (pro2: only its dropout fields
  * are used) -- the two encode_nodes passes of a training step (src/model.py:294 and :301 -> :251) see the same
  * Linear + BatchNorm1d in front of their first Dropout (model.py:93-96), i.e. they share that layer:

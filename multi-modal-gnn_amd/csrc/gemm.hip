@@ -372,6 +372,188 @@ int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float*
              : launch_fwd_x6_v<K, WN, false, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial);
 }
 
+// ---------------------------------------------------------------------------- BatchNorm backward inside the data-gradient GEMM
+// dX = dZ . W  with  dZ = the backward of  dropout(relu(BN(y)))  at the upstream gradient G  (mmg_bn_bwd_apply's
+// arithmetic), computed WHILE the tile is staged: the kernel reads G and Y once, writes dZ once (the weight gradient of
+// the same layer reads it afterwards) and dX -- the separate apply pass read G and Y, wrote dZ, and this GEMM read dZ
+// again: 94 MB less per layer at the x100 shape.  Same skeleton as k_linear_fwd_x6 (W pieces in registers, three bf16
+// planes double-buffered in LDS, per-tile buffer descriptors, peeled tile pair); both inputs run ONE tile ahead in
+// registers (two tiles of two tensors would not fit 256 registers beside the W pieces).  One workgroup covers all N
+// output columns, so every dZ tile is produced exactly once.
+struct BnBwdDev {
+  const float* Y; const float* mean; const float* rstd; const double* sums; double inv_count;
+  float* dZ; float* dbeta; float* dgamma;
+};
+
+template <int K, int WN>
+__global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(const float* __restrict__ G, BnBwdDev bb, ProDev pr,
+                                                                const float* __restrict__ W, float* __restrict__ DX,
+                                                                int64_t M) {
+  pr.resolve();
+  constexpr int LDP = K + 8, N = 32 * WN, NK = K / 16, NTHR = 64 * WN, BM = 32;
+  extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int col = wn * 32 + l31;
+  xbf16x8 wb[NK][3];                       // W stored [K, N] (the forward weight, read in place)
+  {
+    const float* wp = W + (size_t)(8 * h) * N + col;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = wp[(size_t)(ks * 16 + j) * N];
+        const __bf16 a = (__bf16)v;
+        const float r1 = v - (float)a;
+        const __bf16 b = (__bf16)r1;
+        wb[ks][0][j] = a; wb[ks][1][j] = b; wb[ks][2][j] = (__bf16)(r1 - (float)b);
+      }
+  }
+  constexpr int K4 = K / 4;
+  const int kc4 = tid % K4, c = kc4 * 4;    // this thread always touches the same 4 columns of G / Y / dZ
+  constexpr int ROWS_PER_PASS = NTHR / K4;
+  constexpr int NP = BM / ROWS_PER_PASS;
+  const int prow = tid / K4;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 sc = one, sh = zero, mu = zero, rs = one, a0 = zero, a1 = zero;
+  if (pr.scale) {
+    sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c);
+    mu = *reinterpret_cast<const f32x4*>(bb.mean + c); rs = *reinterpret_cast<const f32x4*>(bb.rstd + c);
+    if (bb.sums) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] = (float)(bb.sums[c + j] * bb.inv_count);
+        a1[j] = (float)(bb.sums[K + c + j] * bb.inv_count);
+      }
+    }
+  }
+  if (bb.sums && blockIdx.y == 0 && tid < K4) {          // d beta / d gamma ride along
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (bb.dbeta) bb.dbeta[c + j] = (float)bb.sums[c + j];
+      if (bb.dgamma) bb.dgamma[c + j] = (float)bb.sums[K + c + j];
+    }
+  }
+  const bool relu = pr.relu == MMG_ACT_RELU, drop = pr.p > 0.f, has_bn = pr.scale != nullptr;
+  const int64_t n_tiles = (M + BM - 1) / BM;
+  const int64_t GY = gridDim.y, t0 = blockIdx.y;
+  if (t0 >= n_tiles) return;
+  const int n_my = (int)((n_tiles - t0 + GY - 1) / GY);
+  auto rows_of = [&](int64_t tile) __attribute__((always_inline)) -> int {
+    const int64_t r = M - tile * BM;
+    return r <= 0 ? 0 : (r < BM ? (int)r : BM);
+  };
+  f32x4 ng[NP], ny[NP];                     // the NEXT tile of G and Y
+  const int xvo = (prow * K + kc4 * 4) * 4;
+  auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int rows = rows_of(tile);
+    const size_t off = (size_t)(rows ? tile : 0) * BM * K;
+    const __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G) + off, 0, rows * K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.Y) + off, 0, rows * K * 4, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      ng[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
+      ny[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
+    }
+  };
+  auto stage = [&](int64_t tile, int buf) __attribute__((always_inline)) {   // BatchNorm backward of the tile in ng / ny, dZ out, split, three plane writes
+    const int64_t row0 = tile * BM;
+    const int rows = rows_of(tile);
+    const __amdgpu_buffer_rsrc_t zs = __builtin_amdgcn_make_buffer_rsrc(
+        bb.dZ + (size_t)(rows ? tile : 0) * BM * K, 0, rows * K * 4, 0x00020000);
+    __bf16* pb = planes + (size_t)buf * 3 * BM * LDP;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int r = p * ROWS_PER_PASS + prow;
+      const f32x4 y4 = ny[p];
+      f32x4 gm = ng[p], v;
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float act = has_bn ? fmaf(y4[j], sc[j], sh[j]) : y4[j];
+          if (!(act > 0.f)) gm[j] = 0.f;
+        }
+      }
+      if (drop)
+        mmg_drop4(gm, pr.key, (uint64_t)(pr.row_offset + row0 + r) * (uint64_t)K + (uint64_t)c, pr.thr, pr.inv_keep);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float g = gm[j];
+        if (has_bn) {
+          const float xh = (y4[j] - mu[j]) * rs[j];
+          g = sc[j] * (g - a0[j] - xh * a1[j]);
+        }
+        v[j] = g;
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xu32x4, v), zs, xvo, p * ROWS_PER_PASS * K * 4, 0);
+      xbf16x4 q0, q1, q2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        const float r1 = v[j] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        q0[j] = a; q1[j] = b; q2[j] = (__bf16)(r1 - (float)b);
+      }
+      *reinterpret_cast<xbf16x4*>(pb + (0 * BM + r) * LDP + kc4 * 4) = q0;
+      *reinterpret_cast<xbf16x4*>(pb + (1 * BM + r) * LDP + kc4 * 4) = q1;
+      *reinterpret_cast<xbf16x4*>(pb + (2 * BM + r) * LDP + kc4 * 4) = q2;
+    }
+  };
+  fetch(t0);
+  stage(t0, 0);
+  fetch(t0 + GY);
+  __syncthreads();
+  const int yvo = ((4 * h) * N + wn * 32 + l31) * 4;     // C/D map: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+  auto tile_body = [&](int64_t tt, int buf) __attribute__((always_inline)) {
+    const int rows = rows_of(tt);
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(
+        DX + (size_t)(rows ? tt : 0) * BM * N, 0, rows * N * 4, 0x00020000);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    stage(tt + GY, buf ^ 1);                   // the other buffer: its readers passed the barrier of the last tile
+    fetch(tt + 2 * GY);
+    __builtin_amdgcn_sched_barrier(0);         // keep the fetch ahead of the matrix loop
+    const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + l31 * LDP + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const xbf16x8 a1f = *reinterpret_cast<const xbf16x8*>(ap + ks * 16);
+      const xbf16x8 a2f = *reinterpret_cast<const xbf16x8*>(ap + BM * LDP + ks * 16);
+      const xbf16x8 a3f = *reinterpret_cast<const xbf16x8*>(ap + 2 * BM * LDP + ks * 16);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3f, wb[ks][0], acc, 0, 0, 0);   // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f, wb[ks][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2f, wb[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2f, wb[ks][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f, wb[ks][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f, wb[ks][0], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float v = acc[i];                // (a bit_cast straight from the vector element stored element 0 sixteen times)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), xs, yvo, ((i & 3) + 8 * (i >> 2)) * N * 4,
+                                            MMG_NT_ST);
+    }
+    __syncthreads();                         // buf fully read, buf^1 fully written
+  };
+  tile_body(t0, 0);
+  tile_body(t0 + GY, 1);
+  for (int i = 2; i < n_my; i += 2) {
+    tile_body(t0 + (int64_t)i * GY, 0);
+    tile_body(t0 + (int64_t)(i + 1) * GY, 1);
+  }
+}
+
+template <int K, int WN>
+int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const float* W, float* DX, int64_t M, hipStream_t st) {
+  constexpr int N = 32 * WN;
+  const int64_t gy = fwd_x6_rows(M, N, N, K);
+  constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN>, lds>::set()), "linear_bnbwd(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, 16, (k_linear_bnbwd_x6<K, WN>), dim3(1u, (unsigned)gy), dim3(64 * WN), lds, st,
+             G, bb, pr, W, DX, M);
+  return 0;
+}
+
 // Small M (the vocab-side tables: 50..200 rows): one 256-thread workgroup per 32x32 output tile, the k axis split
 // over its four waves (and over the lane halves inside a wave), every operand load issued up front straight from
 // L2 into registers, the four partial tiles summed through LDS.  These launches are pure latency (a dependent chain
@@ -964,6 +1146,30 @@ extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, c
   MMG_CHECK_LAUNCH("linear_fwd");
   if (col_sums && !stats_done)            // small-M / fp32 kernels: a separate pass over Y
     return mmg_col_reduce2(Y, nullptr, col_sums, M, N, ws, ws_bytes, stream);
+  return MMG_OK;
+}
+
+extern "C" int mmg_linear_bnbwd_supported(int64_t M, int N, int K) {
+  return (M > 512 && (K == 64 || K == 128) && (N == 64 || N == 128)) ? 1 : 0;
+}
+
+extern "C" int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
+                                const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
+                                const float* W, float* dZ, float* dX, int64_t M, int N, int K, void* stream) {
+  MMG_CHECK_ARG(mmg_linear_bnbwd_supported(M, N, K), "linear_bnbwd: M=%lld N=%d K=%d unsupported (M > 512, K and N in {64,128})",
+                (long long)M, N, K);
+  MMG_CHECK_ARG(G && Y && W && dZ && dX, "linear_bnbwd: null buffer");
+  MMG_CHECK_ARG(!pro || !pro->scale || (pro->shift && mean && rstd), "linear_bnbwd: BatchNorm fold without shift / mean / rstd");
+  MMG_CHECK_ARG(!pro || pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_bnbwd: relu only");
+  MMG_CHECK_ARG(!sums || (pro && pro->scale), "linear_bnbwd: sums without a BatchNorm fold");
+  const ProDev pr = mmg_pro_dev(pro);
+  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma};
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2>(G, bb, pr, W, dX, M, st);
+  else rc = N == 128 ? launch_bnbwd_x6<64, 4>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<64, 2>(G, bb, pr, W, dX, M, st);
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("linear_bnbwd");
   return MMG_OK;
 }
 

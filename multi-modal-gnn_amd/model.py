@@ -570,6 +570,26 @@ class _Run:
         self.acc(bn_prefix + ".weight", dbg[1])
         return dy
 
+    def bn_lin_bwd(self, g, y, pro: Pro, fold: Optional[ops.BNFold], bn_prefix: Optional[str], sharded: bool, sums, W):
+        """bn_bwd followed by the data gradient  dz @ W  through the linear in front of that BatchNorm, as ONE kernel
+        (mmg_linear_bnbwd: g and y are read once, dz is written once for the weight gradient).  -> (dz, dx), or None where
+        the fused kernel does not apply (the caller then runs bn_bwd and the GEMM)."""
+        if g is None or pro.relu not in (0, 1) or not ops.linear_bnbwd_supported(y.shape[0], W.shape[1], y.shape[1]):
+            return None
+        if fold is None:
+            return ops.linear_bnbwd(g, y, pro, None, W)
+        if sums is None:
+            sums = self.bn_bwd_sums(g, y, pro, fold, sharded)
+        dbg = torch.empty(2, y.shape[1], device=y.device)       # d beta | d gamma, written by the kernel
+        if fold.training:
+            out = ops.linear_bnbwd(g, y, pro, fold, W, sums, fold.count, dbg[0], dbg[1])
+        else:
+            dbg.copy_(sums)
+            out = ops.linear_bnbwd(g, y, pro, fold, W)
+        self.acc(bn_prefix + ".bias", dbg[0])
+        self.acc(bn_prefix + ".weight", dbg[1])
+        return out
+
     def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False, dx_into=None):
         """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one."""
         gw = self.grads.get(wname)       # a second contribution (the encoder runs twice) accumulates inside the kernel
@@ -623,6 +643,11 @@ class _Run:
             self.acc(f"{pt}.5.bias", dbg[0])
             self.acc(f"{pt}.5.weight", dbg[1])
         else:
+            fused = self.bn_lin_bwd(g, y, pro, fold, f"{pt}.5", True, sums, self.W(f"{pt}.4.weight"))
+            if fused is not None:                # BatchNorm backward inside the data-gradient GEMM of the second linear
+                dz2, dx = fused
+                self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", need_dx=False, partial=True)
+                return dx
             dz2 = self.bn_bwd(g, y, pro, fold, f"{pt}.5", sharded=True, sums=sums)
         return self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", partial=True)
 
@@ -930,13 +955,23 @@ class _Run:
 
         def patient_1(sums=None, reduce=True):
             """BN backward of the patient rows, their weight / data gradients, scatter of dy_P onto the vocab rows."""
-            bn_bwd_t(ROW_TYPE, sums)
+            gt, fused = g_out.get(ROW_TYPE), None
+            if gt is not None and ROW_TYPE in y and rec["rin"] and g_in[ROW_TYPE] is None:
+                # BatchNorm backward inside the data-gradient GEMM of the self-loop weights (sum of the three lin_r)
+                fused = self.bn_lin_bwd(gt.contiguous(), y[ROW_TYPE], rec["pros"][ROW_TYPE], rec["folds"][ROW_TYPE],
+                                        f"batch_norms.{l}.{ROW_TYPE}" if self.m.use_batch_norm else None, True, sums,
+                                        rec["Wsum"])
+            if fused is not None:
+                dy[ROW_TYPE], g_in[ROW_TYPE] = fused
+            else:
+                bn_bwd_t(ROW_TYPE, sums)
             dyP = dy.get(ROW_TYPE)
             if dyP is None or not rec["rin"]:
                 return None
             xP = x[ROW_TYPE]
             dWsum, dbsum = ops.linear_wgrad(dyP, xP, with_bias=True)
-            add_dgrad(ROW_TYPE, dyP, rec["Wsum"])
+            if fused is None:
+                add_dgrad(ROW_TYPE, dyP, rec["Wsum"])
             rels, dTs, off = [], [], 0
             buf = torch.empty(sum(r.n_cols for r in rec["rin"]), D, device=self.dev)
             for r in rec["rin"]:

@@ -473,6 +473,29 @@ def bn_bwd_apply(g: Optional[torch.Tensor], y: torch.Tensor, pro: Pro, fold: Opt
     return out
 
 
+def linear_bnbwd_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().mmg_linear_bnbwd_supported(int(M), int(N), int(K)))
+
+
+def linear_bnbwd(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFold], W: torch.Tensor, sums=None,
+                 count: float = 1.0, dbeta=None, dgamma=None):
+    """bn_bwd_apply(g, y, ...) and the data gradient dz @ W of the linear in front of that BatchNorm in ONE pass over g and
+    y (mmg_linear_bnbwd): -> (dz [M,K], dx [M,N]).  W [K, N] is the forward weight of the linear, read in place."""
+    lib = _lib.load()
+    M, K = y.shape
+    if W.shape[0] != K:
+        raise ValueError(f"linear_bnbwd: W has {W.shape[0]} rows, y has {K} columns")
+    N = W.shape[1]
+    dz = torch.empty_like(y)
+    dx = torch.empty(M, N, device=y.device)
+    _tok = _pb("linear_bnbwd")
+    check(lib.mmg_linear_bnbwd(_p(g), _p(y), _pro(pro), _p(fold.mean) if fold else None, _p(fold.rstd) if fold else None,
+                               _p(sums, torch.float64), 1.0 / float(count), _p(dbeta), _p(dgamma), _p(W), _p(dz), _p(dx),
+                               M, N, K, _stream()), "mmg_linear_bnbwd")
+    _pe(_tok, "linear_bnbwd", 4 * (3 * M * K + M * N), 2 * M * N * K)
+    return dz, dx
+
+
 def l2norm_fwd(z: torch.Tensor):
     lib = _lib.load()
     M, N = z.shape

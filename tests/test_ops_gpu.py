@@ -336,6 +336,40 @@ def test_bn_relu_dropout_backward(ops, dev, p):
     assert torch.equal(acc, dy + 0.5)
 
 
+@pytest.mark.parametrize("M,K,N", [(5003, 128, 128), (4100, 128, 64), (3333, 64, 128), (600, 64, 64)])
+@pytest.mark.parametrize("p,mode", [(0.0, "train"), (0.3, "train"), (0.3, "eval"), (0.3, "nobn")])
+def test_bn_backward_inside_the_data_gradient_gemm(ops, dev, M, K, N, p, mode):
+    """mmg_linear_bnbwd == mmg_bn_bwd_apply followed by mmg_linear_fwd(W_KN) on its output, bit for bit (the same
+    arithmetic in the same order: the BatchNorm backward is computed while the tile is staged), incl. d beta / d gamma,
+    the tail tile, a row offset of the dropout stream, eval mode and no BatchNorm at all."""
+    gen = torch.Generator().manual_seed(77 + M)
+    y = (torch.randn(M, K, generator=gen) * 1.5 + 0.2).to(dev)
+    g = torch.randn(M, K, generator=gen).to(dev)
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    gamma, beta = (torch.rand(K, generator=gen) + 0.5).to(dev), (torch.randn(K, generator=gen) * 0.2).to(dev)
+    assert ops.linear_bnbwd_supported(M, N, K) and not ops.linear_bnbwd_supported(200, N, K)
+    assert not ops.linear_bnbwd_supported(M, 256, K) and not ops.linear_bnbwd_supported(M, N, 256)
+    if mode == "nobn":
+        fold, pro, sums = None, ops.Pro(None, None, True, p, seed=9, site=3, row_offset=1000), None
+    else:
+        training = mode == "train"
+        rm, rv = torch.zeros(K, device=dev), torch.ones(K, device=dev)
+        fold = ops.bn_finalize(ops.col_reduce2(y) if training else None, M, gamma, beta, rm, rv, training)
+        pro = ops.Pro(fold.scale, fold.shift, True, p, seed=9, site=3, row_offset=1000)
+        sums = ops.bn_bwd_stats(g, y, pro, fold) if training else None
+    d0, d1 = torch.zeros(2, K, device=dev), torch.zeros(2, K, device=dev)
+    if sums is not None:
+        dz_ref = ops.bn_bwd_apply(g, y, pro, fold, sums, M, d0[0], d0[1])
+        dz, dx = ops.linear_bnbwd(g, y, pro, fold, W, sums, M, d1[0], d1[1])
+    else:
+        dz_ref = ops.bn_bwd_apply(g, y, pro, fold)
+        dz, dx = ops.linear_bnbwd(g, y, pro, fold, W)
+    dx_ref = ops.linear_fwd(dz_ref, W, w_kn=True)
+    assert torch.equal(dz, dz_ref) and torch.equal(d0, d1)
+    assert torch.equal(dx, dx_ref)
+    assert rel(dx, dz_ref.double() @ W.double()) <= 2e-6
+
+
 @pytest.mark.parametrize("p", [0.0, 0.3])
 def test_row_subset_variants_match_the_dense_kernels(ops, dev, p):
     """affine_act_drop_rows / bn_bwd_stats_rows / bn_bwd_apply(None) + bn_bwd_apply_rows == the dense kernels fed
