@@ -145,6 +145,12 @@ int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const float* W, co
                    float* Y, int64_t M, int N, int K, int flags, void* stream);
 /* the same, plus col_sums[2,N] (fp64) = (sum_m Y, sum_m Y^2): the batch statistics of the BatchNorm that follows
  * (src/model.py:95,99), taken in the GEMM epilogue instead of a second pass over Y */
+/* the same layer followed by the row L2 normalisation (patient_transform's last Linear + F.normalize(p=2, dim=1),
+ * src/model.py:103,232) in one kernel: Y = y / max(|y|_2, eps) per row, rnorm[row] = 1 / max(|y|_2, eps) (what
+ * mmg_l2norm_fwd returns; mmg_l2norm_bwd takes exactly these two).  Supported for M > 512, N and K in {64, 128}. */
+int mmg_linear_fwd_l2norm_supported(int64_t M, int N, int K);
+int mmg_linear_fwd_l2norm(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias, float* Y,
+                          float* rnorm, int64_t M, int N, int K, float eps, void* stream);
 size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N);
 int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
                          float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,

@@ -171,10 +171,15 @@ typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
 #define MMG_NT_WG 0
 #endif
 
-template <int K, int WN, bool PRO, bool ACC>   // WN waves along N (32 columns each) over a 32-row tile: 64 * WN threads
+// L2: the row L2 normalisation that follows the layer (F.normalize, src/model.py:232) in the epilogue -- the workgroup
+// holds whole rows (N == 32 * WN), so Y receives  y / max(|y|, eps)  and rn_out[row] = 1 / max(|y|, eps); the separate
+// pass read and wrote the [M, N] tensor once more.
+template <int K, int WN, bool PRO, bool ACC, bool L2 = false>   // WN waves along N (32 columns each) over a 32-row tile: 64 * WN threads
 __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_linear_fwd_x6(
     const float* __restrict__ X, ProDev pr, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Y, int64_t M, int N, int flags, double* __restrict__ stat_partial) {
+    float* __restrict__ Y, int64_t M, int N, int flags, double* __restrict__ stat_partial, float* __restrict__ rn_out,
+    float l2_eps) {
+  __shared__ float l2_part[L2 ? WN * 32 : 1], l2_rn[L2 ? 32 : 1];
   if (PRO) pr.resolve();
   double cs1 = 0.0, cs2 = 0.0;          // column statistics of the output (BatchNorm batch stats) ride along: lane = column
   constexpr int LDP = K + 8;            // plane row stride in bf16 (K*2 + 16 bytes: fragment reads hit 64 distinct banks)
@@ -303,6 +308,38 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][0], acc, 0, 0, 0);
     }
+    if constexpr (L2) {
+      // row sums of squares: 32 lanes of a half-wave hold the 32 columns of this wave for 16 rows each; the WN waves'
+      // partials meet in LDS, 32 threads turn them into 1 / max(norm, eps), every lane scales its 16 values
+      float vv[16], ss[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { vv[i] = acc[i] + bv; ss[i] = vv[i] * vv[i]; }
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ss[i] += __shfl_xor(ss[i], o, 64);
+      if (l31 == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) l2_part[wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = ss[i];
+      }
+      __syncthreads();                       // partials complete; also: buf fully read, buf^1 fully written
+      if (tid < 32) {
+        float tot = l2_part[tid];
+#pragma unroll
+        for (int w = 1; w < WN; ++w) tot += l2_part[w * 32 + tid];
+        const float rinv = 1.0f / fmaxf(sqrtf(tot), l2_eps);
+        l2_rn[tid] = rinv;
+        if (tid < rows) rn_out[tt * BM + tid] = rinv;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2);
+        const float v = vv[i] * l2_rn[r + 4 * h];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, yvo, r * N * 4, MMG_NT_ST);
+      }
+      return;
+    }
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -348,17 +385,17 @@ inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y 
   return gy;
 }
 
-template <int K, int WN, bool PRO, bool ACC>
+template <int K, int WN, bool PRO, bool ACC, bool L2 = false>
 int launch_fwd_x6_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
-                    int flags, hipStream_t st, double* stat_partial) {
+                    int flags, hipStream_t st, double* stat_partial, float* rn_out = nullptr, float l2_eps = 0.f) {
   constexpr int BN = 32 * WN;
   const int n_slices = N / BN;
   const int64_t gy = fwd_x6_rows(M, N, BN, K);
   constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
-  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_x6<K, WN, PRO, ACC>, lds>::set()), "linear_fwd(attr)");
-  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0),
-             (k_linear_fwd_x6<K, WN, PRO, ACC>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds, st, X,
-             pr, W, bias, Y, M, N, flags, stat_partial);
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_x6<K, WN, PRO, ACC, L2>, lds>::set()), "linear_fwd(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0) | (L2 ? 32 : 0),
+             (k_linear_fwd_x6<K, WN, PRO, ACC, L2>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds, st, X,
+             pr, W, bias, Y, M, N, flags, stat_partial, rn_out, l2_eps);
   return 0;
 }
 
@@ -1146,6 +1183,37 @@ extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, c
   MMG_CHECK_LAUNCH("linear_fwd");
   if (col_sums && !stats_done)            // small-M / fp32 kernels: a separate pass over Y
     return mmg_col_reduce2(Y, nullptr, col_sums, M, N, ws, ws_bytes, stream);
+  return MMG_OK;
+}
+
+extern "C" int mmg_linear_fwd_l2norm_supported(int64_t M, int N, int K) {
+  return (M > 512 && ((N == 128 && (K == 64 || K == 128)) || (N == 64 && (K == 64 || K == 128)))) ? 1 : 0;
+}
+
+extern "C" int mmg_linear_fwd_l2norm(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias, float* Y,
+                                     float* rnorm, int64_t M, int N, int K, float eps, void* stream) {
+  MMG_CHECK_ARG(mmg_linear_fwd_l2norm_supported(M, N, K), "linear_fwd_l2norm: M=%lld N=%d K=%d unsupported (M > 512, N and K in {64,128})",
+                (long long)M, N, K);
+  MMG_CHECK_ARG(X && W && Y && rnorm, "linear_fwd_l2norm: null buffer");
+  MMG_CHECK_ARG(!pro || !pro->scale || pro->shift, "linear_fwd_l2norm: prologue scale without shift");
+  MMG_CHECK_ARG(!pro || pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_fwd_l2norm: the prologue takes relu only");
+  const ProDev pr = mmg_pro_dev(pro);
+  const bool has_pro = pr.scale || pr.relu || pr.p > 0.f;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (N == 128) {
+    if (K == 128) rc = has_pro ? launch_fwd_x6_v<128, 4, true, false, true>(X, pr, W, bias, Y, M, N, 0, st, nullptr, rnorm, eps)
+                               : launch_fwd_x6_v<128, 4, false, false, true>(X, pr, W, bias, Y, M, N, 0, st, nullptr, rnorm, eps);
+    else rc = has_pro ? launch_fwd_x6_v<64, 4, true, false, true>(X, pr, W, bias, Y, M, N, 0, st, nullptr, rnorm, eps)
+                      : launch_fwd_x6_v<64, 4, false, false, true>(X, pr, W, bias, Y, M, N, 0, st, nullptr, rnorm, eps);
+  } else {
+    if (K == 128) rc = has_pro ? launch_fwd_x6_v<128, 2, true, false, true>(X, pr, W, bias, Y, M, N, 0, st, nullptr, rnorm, eps)
+                               : launch_fwd_x6_v<128, 2, false, false, true>(X, pr, W, bias, Y, M, N, 0, st, nullptr, rnorm, eps);
+    else rc = has_pro ? launch_fwd_x6_v<64, 2, true, false, true>(X, pr, W, bias, Y, M, N, 0, st, nullptr, rnorm, eps)
+                      : launch_fwd_x6_v<64, 2, false, false, true>(X, pr, W, bias, Y, M, N, 0, st, nullptr, rnorm, eps);
+  }
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("linear_fwd_l2norm");
   return MMG_OK;
 }
 

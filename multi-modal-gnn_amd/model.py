@@ -528,11 +528,9 @@ class _Run:
         pro2 = Pro(f2.scale, f2.shift, True, self.p, self.seed, 2 * call + 1, off, self.seed_dev)
         if rows is not None:
             act = ops.affine_act_drop_rows(z2, pro2, rows)       # the dropout masks of the ORIGINAL rows
-            z3 = ops.linear_fwd(act, pt[8].weight.detach(), pt[8].bias.detach())
-            x0, rn = ops.l2norm_fwd(z3)
+            x0, rn = ops.linear_l2norm_fwd(act, pt[8].weight.detach(), pt[8].bias.detach())
             return dict(E=E, z1=z1, z2=z2, x0=x0, rn=rn, f1=f1, f2=f2, pro1=pro1, pro2=pro2, rows=rows, act=act)
-        z3 = ops.linear_fwd(z2, pt[8].weight.detach(), pt[8].bias.detach(), pro=pro2)
-        x0, rn = ops.l2norm_fwd(z3)
+        x0, rn = ops.linear_l2norm_fwd(z2, pt[8].weight.detach(), pt[8].bias.detach(), pro=pro2)    # third linear + L2 norm
         return dict(E=E, z1=z1, z2=z2, x0=x0, rn=rn, f1=f1, f2=f2, pro1=pro1, pro2=pro2)
 
     def enc_dict(self, enc):

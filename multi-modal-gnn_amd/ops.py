@@ -473,6 +473,23 @@ def bn_bwd_apply(g: Optional[torch.Tensor], y: torch.Tensor, pro: Pro, fold: Opt
     return out
 
 
+def linear_l2norm_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, pro: Optional[Pro] = None):
+    """l2norm_fwd(linear_fwd(x, W, bias, pro)) -> (normalised rows, rn): ONE kernel where the GEMM's workgroup holds whole
+    rows (mmg_linear_fwd_l2norm: the norm is taken in the epilogue), the two launches elsewhere."""
+    lib = _lib.load()
+    M, K = x.shape
+    N = W.shape[0]
+    if not lib.mmg_linear_fwd_l2norm_supported(M, N, K):
+        return l2norm_fwd(linear_fwd(x, W, bias, pro=pro))
+    out = torch.empty(M, N, device=x.device)
+    rn = torch.empty(M, device=x.device)
+    _tok = _pb("linear_fwd")
+    check(lib.mmg_linear_fwd_l2norm(_p(x), _pro(pro), _p(W), _p(bias), _p(out), _p(rn), M, N, K, L2_EPS, _stream()),
+          "mmg_linear_fwd_l2norm")
+    _pe(_tok, "linear_fwd", 4 * (M * K + N * K + M * N), 2 * M * N * K)
+    return out, rn
+
+
 def linear_bnbwd_supported(M: int, N: int, K: int) -> bool:
     return bool(_lib.load().mmg_linear_bnbwd_supported(int(M), int(N), int(K)))
 

@@ -336,6 +336,31 @@ def test_bn_relu_dropout_backward(ops, dev, p):
     assert torch.equal(acc, dy + 0.5)
 
 
+@pytest.mark.parametrize("M,K,N", [(5003, 128, 128), (4100, 128, 64), (3333, 64, 128), (600, 64, 64), (300, 128, 128),
+                                   (2000, 256, 256)])
+@pytest.mark.parametrize("with_pro", [False, True])
+def test_l2_norm_inside_the_dense_forward(ops, dev, M, K, N, with_pro):
+    """mmg_linear_fwd_l2norm (row norm in the GEMM epilogue) == mmg_linear_fwd followed by mmg_l2norm_fwd up to the order
+    of the 128 squares of a row, and == F.normalize of an fp64 product; unsupported shapes take the two launches."""
+    gen = torch.Generator().manual_seed(5 + M)
+    x = torch.randn(M, K, generator=gen).to(dev)
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=gen).to(dev)
+    pro = None
+    if with_pro:
+        sc, sh = (torch.rand(K, generator=gen) + 0.5).to(dev), (torch.randn(K, generator=gen) * 0.3).to(dev)
+        pro = ops.Pro(sc, sh, True, 0.25, seed=11, site=4, row_offset=77)
+    out, rn = ops.linear_l2norm_fwd(x, W, b, pro)
+    z = ops.linear_fwd(x, W, b, pro=pro)
+    out_ref, rn_ref = ops.l2norm_fwd(z)
+    assert rel(out, out_ref) <= 5e-7 and rel(rn, rn_ref) <= 5e-7
+    assert rel(out, torch.nn.functional.normalize(z.double(), p=2, dim=1)) <= 5e-7
+    assert rel(out.norm(dim=1), torch.ones(M, device=dev)) <= 1e-6
+    zero = torch.zeros(M, K, device=dev)                           # a zero row: y = 0 -> out = 0, rn = 1 / eps (F.normalize's clamp)
+    o0, r0 = ops.linear_l2norm_fwd(zero, W, None)
+    assert float(o0.abs().max()) == 0.0 and torch.equal(r0, torch.full((M,), 1.0 / ops.L2_EPS, device=dev))
+
+
 @pytest.mark.parametrize("M,K,N", [(5003, 128, 128), (4100, 128, 64), (3333, 64, 128), (600, 64, 64)])
 @pytest.mark.parametrize("p,mode", [(0.0, "train"), (0.3, "train"), (0.3, "eval"), (0.3, "nobn")])
 def test_bn_backward_inside_the_data_gradient_gemm(ops, dev, M, K, N, p, mode):
