@@ -212,6 +212,12 @@ int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prologue_t* pro, 
                      const double* sums, double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ,
                      float* dX, int64_t M, int N, int K, void* stream);
 
+/* mmg_l2norm_bwd folded into the data-gradient GEMM of the linear in front of the normalisation the same way:
+ * dZ = rnorm * (G - out * <G, out>) (0 dot product where the norm was clamped), dX = dZ . W, W stored [K,N].  Shapes as
+ * mmg_linear_bnbwd_supported. */
+int mmg_linear_l2bwd(const float* G, const float* out, const float* rnorm, const float* W, float* dZ, float* dX,
+                     int64_t M, int N, int K, float eps, void* stream);
+
 /* Two upstream gradients through the SAME BatchNorm + ReLU, each with its own dropout mask (pro2: only its dropout fields
  * are used) -- the two encode_nodes passes of a training step (src/model.py:294 and :301 -> :251) see the same
  * Linear + BatchNorm1d in front of their first Dropout (model.py:93-96), i.e. they share that layer:

@@ -417,16 +417,19 @@ int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float*
 // planes double-buffered in LDS, per-tile buffer descriptors, peeled tile pair); both inputs run ONE tile ahead in
 // registers (two tiles of two tensors would not fit 256 registers beside the W pieces).  One workgroup covers all N
 // output columns, so every dZ tile is produced exactly once.
+// MODE 1: the same skeleton with the backward of the row L2 normalisation in the staging phase (mmg_l2norm_bwd's
+// arithmetic: dZ = rn * (G - out * <G, out>), the row dot product over the K / 4 lanes that hold a row): Y = the
+// normalised rows, mean = rn [M].
 struct BnBwdDev {
   const float* Y; const float* mean; const float* rstd; const double* sums; double inv_count;
-  float* dZ; float* dbeta; float* dgamma;
+  float* dZ; float* dbeta; float* dgamma; float l2_eps;
 };
 
-template <int K, int WN>
+template <int K, int WN, int MODE = 0>
 __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(const float* __restrict__ G, BnBwdDev bb, ProDev pr,
                                                                 const float* __restrict__ W, float* __restrict__ DX,
                                                                 int64_t M) {
-  pr.resolve();
+  if (MODE == 0) pr.resolve();
   constexpr int LDP = K + 8, N = 32 * WN, NK = K / 16, NTHR = 64 * WN, BM = 32;
   extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
   const int prow = tid / K4;
   const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 sc = one, sh = zero, mu = zero, rs = one, a0 = zero, a1 = zero;
-  if (pr.scale) {
+  if (MODE == 0 && pr.scale) {
     sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c);
     mu = *reinterpret_cast<const f32x4*>(bb.mean + c); rs = *reinterpret_cast<const f32x4*>(bb.rstd + c);
     if (bb.sums) {
@@ -464,14 +467,14 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
       }
     }
   }
-  if (bb.sums && blockIdx.y == 0 && tid < K4) {          // d beta / d gamma ride along
+  if (MODE == 0 && bb.sums && blockIdx.y == 0 && tid < K4) {          // d beta / d gamma ride along
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (bb.dbeta) bb.dbeta[c + j] = (float)bb.sums[c + j];
       if (bb.dgamma) bb.dgamma[c + j] = (float)bb.sums[K + c + j];
     }
   }
-  const bool relu = pr.relu == MMG_ACT_RELU, drop = pr.p > 0.f, has_bn = pr.scale != nullptr;
+  const bool relu = MODE == 0 && pr.relu == MMG_ACT_RELU, drop = MODE == 0 && pr.p > 0.f, has_bn = MODE == 0 && pr.scale != nullptr;
   const int64_t n_tiles = (M + BM - 1) / BM;
   const int64_t GY = gridDim.y, t0 = blockIdx.y;
   if (t0 >= n_tiles) return;
@@ -504,6 +507,18 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
       const int r = p * ROWS_PER_PASS + prow;
       const f32x4 y4 = ny[p];
       f32x4 gm = ng[p], v;
+      if constexpr (MODE == 1) {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dot = fmaf(gm[j], y4[j], dot);
+#pragma unroll
+        for (int o = 1; o < K4; o <<= 1) dot += __shfl_xor(dot, o, 64);      // the K / 4 lanes of a row are adjacent
+        const int64_t grow = row0 + r;
+        const float rr = grow < M ? bb.mean[grow] : 0.f;
+        if (!(rr * bb.l2_eps < 1.0f)) dot = 0.f;           // ||z|| <= eps: the denominator was the constant eps
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gm[j] = rr * (gm[j] - y4[j] * dot);
+      }
       if (relu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -580,14 +595,14 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
   }
 }
 
-template <int K, int WN>
+template <int K, int WN, int MODE = 0>
 int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const float* W, float* DX, int64_t M, hipStream_t st) {
   constexpr int N = 32 * WN;
   const int64_t gy = fwd_x6_rows(M, N, N, K);
   constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
-  MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN>, lds>::set()), "linear_bnbwd(attr)");
-  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, 16, (k_linear_bnbwd_x6<K, WN>), dim3(1u, (unsigned)gy), dim3(64 * WN), lds, st,
-             G, bb, pr, W, DX, M);
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN, MODE>, lds>::set()), "linear_bnbwd(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 0 ? 16 : 64, (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
+             dim3(64 * WN), lds, st, G, bb, pr, W, DX, M);
   return 0;
 }
 
@@ -1231,13 +1246,29 @@ extern "C" int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prolog
   MMG_CHECK_ARG(!pro || pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_bnbwd: relu only");
   MMG_CHECK_ARG(!sums || (pro && pro->scale), "linear_bnbwd: sums without a BatchNorm fold");
   const ProDev pr = mmg_pro_dev(pro);
-  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma};
+  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2>(G, bb, pr, W, dX, M, st);
   else rc = N == 128 ? launch_bnbwd_x6<64, 4>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<64, 2>(G, bb, pr, W, dX, M, st);
   if (rc) return rc;
   MMG_CHECK_LAUNCH("linear_bnbwd");
+  return MMG_OK;
+}
+
+extern "C" int mmg_linear_l2bwd(const float* G, const float* out, const float* rnorm, const float* W, float* dZ, float* dX,
+                                int64_t M, int N, int K, float eps, void* stream) {
+  MMG_CHECK_ARG(mmg_linear_bnbwd_supported(M, N, K), "linear_l2bwd: M=%lld N=%d K=%d unsupported (M > 512, K and N in {64,128})",
+                (long long)M, N, K);
+  MMG_CHECK_ARG(G && out && rnorm && W && dZ && dX, "linear_l2bwd: null buffer");
+  const ProDev pr = mmg_pro_dev(nullptr);
+  BnBwdDev bb{out, rnorm, nullptr, nullptr, 0.0, dZ, nullptr, nullptr, eps};
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4, 1>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2, 1>(G, bb, pr, W, dX, M, st);
+  else rc = N == 128 ? launch_bnbwd_x6<64, 4, 1>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<64, 2, 1>(G, bb, pr, W, dX, M, st);
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("linear_l2bwd");
   return MMG_OK;
 }
 

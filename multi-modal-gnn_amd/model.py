@@ -616,12 +616,13 @@ class _Run:
         pt = "patient_transform"
         if enc.get("rows") is not None:      # compact tail: g_x0 = (row ids, gradient rows)
             rows, g_rows = g_x0
-            dz3 = ops.l2norm_bwd(g_rows.contiguous(), enc["x0"], enc["rn"])
-            g = self.lin_bwd(dz3, enc["act"], None, f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
+            # L2-norm backward inside the data-gradient GEMM of the third linear; the weight gradient reads dz3 afterwards
+            dz3, g = ops.linear_l2bwd(g_rows.contiguous(), enc["x0"], enc["rn"], self.W(f"{pt}.8.weight"))
+            self.lin_bwd(dz3, enc["act"], None, f"{pt}.8.weight", f"{pt}.8.bias", need_dx=False, partial=True)
             sums = ops.bn_bwd_stats_rows(g, enc["z2"], rows, enc["pro2"], enc["f2"])
         else:
-            dz3 = ops.l2norm_bwd(g_x0.contiguous(), enc["x0"], enc["rn"])
-            g = self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", partial=True)
+            dz3, g = ops.linear_l2bwd(g_x0.contiguous(), enc["x0"], enc["rn"], self.W(f"{pt}.8.weight"))
+            self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", need_dx=False, partial=True)
             sums = ops.bn_bwd_stats(g, enc["z2"], enc["pro2"], enc["f2"])
         return g, sums
 

@@ -513,6 +513,25 @@ def linear_bnbwd(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFo
     return dz, dx
 
 
+def linear_l2bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor, W: torch.Tensor):
+    """l2norm_bwd(g, out, rn) and the data gradient dz @ W of the linear in front of the normalisation -> (dz, dx): ONE
+    kernel where mmg_linear_bnbwd_supported (W [K, N] = the forward weight in place), the two launches elsewhere."""
+    lib = _lib.load()
+    M, K = out.shape
+    N = W.shape[1]
+    if W.shape[0] != K:
+        raise ValueError(f"linear_l2bwd: W has {W.shape[0]} rows, out has {K} columns")
+    if not lib.mmg_linear_bnbwd_supported(M, N, K):
+        dz = l2norm_bwd(g, out, rn)
+        return dz, linear_fwd(dz, W, w_kn=True)
+    dz = torch.empty_like(out)
+    dx = torch.empty(M, N, device=out.device)
+    _tok = _pb("linear_l2bwd")
+    check(lib.mmg_linear_l2bwd(_p(g), _p(out), _p(rn), _p(W), _p(dz), _p(dx), M, N, K, L2_EPS, _stream()), "mmg_linear_l2bwd")
+    _pe(_tok, "linear_l2bwd", 4 * (3 * M * K + M * N), 2 * M * N * K)
+    return dz, dx
+
+
 def l2norm_fwd(z: torch.Tensor):
     lib = _lib.load()
     M, N = z.shape

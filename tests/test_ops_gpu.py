@@ -361,6 +361,27 @@ def test_l2_norm_inside_the_dense_forward(ops, dev, M, K, N, with_pro):
     assert float(o0.abs().max()) == 0.0 and torch.equal(r0, torch.full((M,), 1.0 / ops.L2_EPS, device=dev))
 
 
+@pytest.mark.parametrize("M,K,N", [(5003, 128, 128), (4100, 128, 64), (3333, 64, 128), (600, 64, 64), (300, 128, 128)])
+def test_l2_norm_backward_inside_the_data_gradient_gemm(ops, dev, M, K, N):
+    """mmg_linear_l2bwd == mmg_l2norm_bwd followed by mmg_linear_fwd(W_KN) (the row dot product is summed in another
+    order), against fp64 autograd of F.normalize; a clamped (all-zero) row keeps dz = g / eps."""
+    gen = torch.Generator().manual_seed(9 + M)
+    z = torch.randn(M, K, generator=gen)
+    z[7] = 0.0                                                           # norm <= eps: F.normalize divides by the constant eps
+    g = torch.randn(M, K, generator=gen).to(dev)
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    out, rn = ops.l2norm_fwd(z.to(dev))
+    dz, dx = ops.linear_l2bwd(g, out, rn, W)
+    dz_ref = ops.l2norm_bwd(g, out, rn)
+    assert rel(dz, dz_ref) <= 1e-6 and torch.equal(dz[7], dz_ref[7])
+    assert rel(dx, ops.linear_fwd(dz_ref, W, w_kn=True)) <= 2e-6
+    zd = z.double().requires_grad_(True)
+    torch.nn.functional.normalize(zd, p=2, dim=1, eps=ops.L2_EPS).backward(g.cpu().double())
+    keep = torch.ones(M, dtype=torch.bool); keep[7] = False              # (row 7: huge values, compared above)
+    assert rel(dz.cpu()[keep], zd.grad[keep]) <= 2e-6
+    assert rel(dx.cpu()[keep], zd.grad[keep] @ W.cpu().double()) <= 2e-6
+
+
 @pytest.mark.parametrize("M,K,N", [(5003, 128, 128), (4100, 128, 64), (3333, 64, 128), (600, 64, 64)])
 @pytest.mark.parametrize("p,mode", [(0.0, "train"), (0.3, "train"), (0.3, "eval"), (0.3, "nobn")])
 def test_bn_backward_inside_the_data_gradient_gemm(ops, dev, M, K, N, p, mode):
