@@ -212,6 +212,11 @@ int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prologue_t* pro, 
                      const double* sums, double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ,
                      float* dX, int64_t M, int N, int K, void* stream);
 
+/* ... and mmg_bn_bwd_apply2 (two upstream gradients, own dropout masks) the same way; K = N = 128. */
+int mmg_linear_bnbwd2(const float* G, const float* G2, const float* Y, const mmg_prologue_t* pro, const mmg_prologue_t* pro2,
+                      const float* mean, const float* rstd, const double* sums, double inv_count, float* dbeta,
+                      float* dgamma, const float* W, float* dZ, float* dX, int64_t M, int N, int K, void* stream);
+
 /* mmg_l2norm_bwd folded into the data-gradient GEMM of the linear in front of the normalisation the same way:
  * dZ = rnorm * (G - out * <G, out>) (0 dot product where the norm was clamped), dX = dZ . W, W stored [K,N].  Shapes as
  * mmg_linear_bnbwd_supported. */

@@ -420,16 +420,19 @@ int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float*
 // MODE 1: the same skeleton with the backward of the row L2 normalisation in the staging phase (mmg_l2norm_bwd's
 // arithmetic: dZ = rn * (G - out * <G, out>), the row dot product over the K / 4 lanes that hold a row): Y = the
 // normalised rows, mean = rn [M].
+// MODE 2: MODE 0 with TWO upstream gradients through the same BatchNorm + ReLU, each with its own dropout mask
+// (mmg_bn_bwd_apply2: the two encode_nodes passes of a training step share their first layer).
 struct BnBwdDev {
   const float* Y; const float* mean; const float* rstd; const double* sums; double inv_count;
-  float* dZ; float* dbeta; float* dgamma; float l2_eps;
+  float* dZ; float* dbeta; float* dgamma; float l2_eps; const float* G2;
 };
 
 template <int K, int WN, int MODE = 0>
 __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(const float* __restrict__ G, BnBwdDev bb, ProDev pr,
                                                                 const float* __restrict__ W, float* __restrict__ DX,
-                                                                int64_t M) {
-  if (MODE == 0) pr.resolve();
+                                                                int64_t M, ProDev pr2) {
+  if (MODE != 1) pr.resolve();
+  if (MODE == 2) pr2.resolve();
   constexpr int LDP = K + 8, N = 32 * WN, NK = K / 16, NTHR = 64 * WN, BM = 32;
   extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
   const int prow = tid / K4;
   const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 sc = one, sh = zero, mu = zero, rs = one, a0 = zero, a1 = zero;
-  if (MODE == 0 && pr.scale) {
+  if (MODE != 1 && pr.scale) {
     sc = *reinterpret_cast<const f32x4*>(pr.scale + c); sh = *reinterpret_cast<const f32x4*>(pr.shift + c);
     mu = *reinterpret_cast<const f32x4*>(bb.mean + c); rs = *reinterpret_cast<const f32x4*>(bb.rstd + c);
     if (bb.sums) {
@@ -467,14 +470,15 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
       }
     }
   }
-  if (MODE == 0 && bb.sums && blockIdx.y == 0 && tid < K4) {          // d beta / d gamma ride along
+  if (MODE != 1 && bb.sums && blockIdx.y == 0 && tid < K4) {          // d beta / d gamma ride along
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (bb.dbeta) bb.dbeta[c + j] = (float)bb.sums[c + j];
       if (bb.dgamma) bb.dgamma[c + j] = (float)bb.sums[K + c + j];
     }
   }
-  const bool relu = MODE == 0 && pr.relu == MMG_ACT_RELU, drop = MODE == 0 && pr.p > 0.f, has_bn = MODE == 0 && pr.scale != nullptr;
+  const bool relu = MODE != 1 && pr.relu == MMG_ACT_RELU, drop = MODE != 1 && pr.p > 0.f, has_bn = MODE != 1 && pr.scale != nullptr;
+  const bool drop2 = MODE == 2 && pr2.p > 0.f;
   const int64_t n_tiles = (M + BM - 1) / BM;
   const int64_t GY = gridDim.y, t0 = blockIdx.y;
   if (t0 >= n_tiles) return;
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
     const int64_t r = M - tile * BM;
     return r <= 0 ? 0 : (r < BM ? (int)r : BM);
   };
-  f32x4 ng[NP], ny[NP];                     // the NEXT tile of G and Y
+  f32x4 ng[NP], ny[NP], ng2[MODE == 2 ? NP : 1];      // the NEXT tile of G and Y (and G2)
   const int xvo = (prow * K + kc4 * 4) * 4;
   auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int rows = rows_of(tile);
@@ -494,6 +498,12 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
     for (int p = 0; p < NP; ++p) {
       ng[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
       ny[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
+    }
+    if constexpr (MODE == 2) {
+      const __amdgpu_buffer_rsrc_t g2s = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.G2) + off, 0, rows * K * 4, 0x00020000);
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        ng2[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g2s, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
     }
   };
   auto stage = [&](int64_t tile, int buf) __attribute__((always_inline)) {   // BatchNorm backward of the tile in ng / ny, dZ out, split, three plane writes
@@ -519,15 +529,22 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
 #pragma unroll
         for (int j = 0; j < 4; ++j) gm[j] = rr * (gm[j] - y4[j] * dot);
       }
+      f32x4 gm2 = zero;
+      if constexpr (MODE == 2) gm2 = ng2[p];
       if (relu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float act = has_bn ? fmaf(y4[j], sc[j], sh[j]) : y4[j];
-          if (!(act > 0.f)) gm[j] = 0.f;
+          if (!(act > 0.f)) { gm[j] = 0.f; gm2[j] = 0.f; }
         }
       }
       if (drop)
         mmg_drop4(gm, pr.key, (uint64_t)(pr.row_offset + row0 + r) * (uint64_t)K + (uint64_t)c, pr.thr, pr.inv_keep);
+      if constexpr (MODE == 2) {
+        if (drop2)
+          mmg_drop4(gm2, pr2.key, (uint64_t)(pr2.row_offset + row0 + r) * (uint64_t)K + (uint64_t)c, pr2.thr, pr2.inv_keep);
+        gm += gm2;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float g = gm[j];
@@ -596,13 +613,14 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
 }
 
 template <int K, int WN, int MODE = 0>
-int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const float* W, float* DX, int64_t M, hipStream_t st) {
+int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const float* W, float* DX, int64_t M, hipStream_t st,
+                    const ProDev& pr2 = mmg_pro_dev(nullptr)) {
   constexpr int N = 32 * WN;
   const int64_t gy = fwd_x6_rows(M, N, N, K);
   constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
   MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN, MODE>, lds>::set()), "linear_bnbwd(attr)");
-  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 0 ? 16 : 64, (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
-             dim3(64 * WN), lds, st, G, bb, pr, W, DX, M);
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 1 ? 64 : 16, (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
+             dim3(64 * WN), lds, st, G, bb, pr, W, DX, M, pr2);
   return 0;
 }
 
@@ -1246,7 +1264,7 @@ extern "C" int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prolog
   MMG_CHECK_ARG(!pro || pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_bnbwd: relu only");
   MMG_CHECK_ARG(!sums || (pro && pro->scale), "linear_bnbwd: sums without a BatchNorm fold");
   const ProDev pr = mmg_pro_dev(pro);
-  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f};
+  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, nullptr};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2>(G, bb, pr, W, dX, M, st);
@@ -1256,13 +1274,31 @@ extern "C" int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prolog
   return MMG_OK;
 }
 
+extern "C" int mmg_linear_bnbwd2(const float* G, const float* G2, const float* Y, const mmg_prologue_t* pro,
+                                 const mmg_prologue_t* pro2, const float* mean, const float* rstd, const double* sums,
+                                 double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ, float* dX,
+                                 int64_t M, int N, int K, void* stream) {
+  MMG_CHECK_ARG(mmg_linear_bnbwd_supported(M, N, K) && K == 128 && N == 128,
+                "linear_bnbwd2: M=%lld N=%d K=%d unsupported (M > 512, K = N = 128)", (long long)M, N, K);
+  MMG_CHECK_ARG(G && G2 && Y && W && dZ && dX && pro && pro2, "linear_bnbwd2: null buffer");
+  MMG_CHECK_ARG(!pro->scale || (pro->shift && mean && rstd), "linear_bnbwd2: BatchNorm fold without shift / mean / rstd");
+  MMG_CHECK_ARG(pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_bnbwd2: relu only");
+  MMG_CHECK_ARG(!sums || pro->scale, "linear_bnbwd2: sums without a BatchNorm fold");
+  const ProDev pr = mmg_pro_dev(pro), pr2 = mmg_pro_dev(pro2);
+  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, G2};
+  int rc = launch_bnbwd_x6<128, 4, 2>(G, bb, pr, W, dX, M, (hipStream_t)stream, pr2);
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("linear_bnbwd2");
+  return MMG_OK;
+}
+
 extern "C" int mmg_linear_l2bwd(const float* G, const float* out, const float* rnorm, const float* W, float* dZ, float* dX,
                                 int64_t M, int N, int K, float eps, void* stream) {
   MMG_CHECK_ARG(mmg_linear_bnbwd_supported(M, N, K), "linear_l2bwd: M=%lld N=%d K=%d unsupported (M > 512, K and N in {64,128})",
                 (long long)M, N, K);
   MMG_CHECK_ARG(G && out && rnorm && W && dZ && dX, "linear_l2bwd: null buffer");
   const ProDev pr = mmg_pro_dev(nullptr);
-  BnBwdDev bb{out, rnorm, nullptr, nullptr, 0.0, dZ, nullptr, nullptr, eps};
+  BnBwdDev bb{out, rnorm, nullptr, nullptr, 0.0, dZ, nullptr, nullptr, eps, nullptr};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4, 1>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2, 1>(G, bb, pr, W, dX, M, st);

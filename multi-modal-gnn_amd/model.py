@@ -681,6 +681,17 @@ class _Run:
             if self.comm is not None:
                 self.allreduce(sums)
             dbg = torch.empty(2, y.shape[1], device=y.device)
+            ename, W0 = f"embeddings.{ROW_TYPE}.weight", self.W(f"{pt}.0.weight")
+            if self.params[ename].requires_grad and ename not in self.grads and \
+                    ops.linear_bnbwd2_supported(y.shape[0], W0.shape[1], y.shape[1]):
+                # the joint BatchNorm backward inside the data-gradient GEMM of the first linear (dE)
+                dz1, dE = ops.linear_bnbwd2(g_a, g_b, y, enc_a["pro1"], enc_b["pro1"], fold, W0, sums, fold.count,
+                                            dbg[0], dbg[1])
+                self.acc(f"{pt}.1.bias", dbg[0])
+                self.acc(f"{pt}.1.weight", dbg[1])
+                self.lin_bwd(dz1, enc_a["E"], None, f"{pt}.0.weight", f"{pt}.0.bias", need_dx=False, partial=True)
+                self.acc(ename, dE)
+                return
             dz1 = ops.bn_bwd_apply2(g_a, g_b, y, enc_a["pro1"], enc_b["pro1"], fold, sums, fold.count, dbg[0], dbg[1])
             self.acc(f"{pt}.1.bias", dbg[0])
             self.acc(f"{pt}.1.weight", dbg[1])

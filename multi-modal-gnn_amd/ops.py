@@ -513,6 +513,26 @@ def linear_bnbwd(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFo
     return dz, dx
 
 
+def linear_bnbwd2_supported(M: int, N: int, K: int) -> bool:
+    return N == 128 and K == 128 and linear_bnbwd_supported(M, N, K)
+
+
+def linear_bnbwd2(g: torch.Tensor, g2: torch.Tensor, y: torch.Tensor, pro: Pro, pro2: Pro, fold: BNFold, W: torch.Tensor,
+                  sums, count, dbeta=None, dgamma=None):
+    """bn_bwd_apply2 (two upstream gradients, own dropout masks) + the data gradient dz @ W in one pass -> (dz, dx)."""
+    lib = _lib.load()
+    M, K = y.shape
+    N = W.shape[1]
+    dz = torch.empty_like(y)
+    dx = torch.empty(M, N, device=y.device)
+    _tok = _pb("linear_bnbwd")
+    check(lib.mmg_linear_bnbwd2(_p(g), _p(g2), _p(y), _pro(pro), _pro(pro2), _p(fold.mean), _p(fold.rstd),
+                                _p(sums, torch.float64), 1.0 / float(count), _p(dbeta), _p(dgamma), _p(W), _p(dz), _p(dx),
+                                M, N, K, _stream()), "mmg_linear_bnbwd2")
+    _pe(_tok, "linear_bnbwd", 4 * (4 * M * K + M * N), 2 * M * N * K)
+    return dz, dx
+
+
 def linear_l2bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor, W: torch.Tensor):
     """l2norm_bwd(g, out, rn) and the data gradient dz @ W of the linear in front of the normalisation -> (dz, dx): ONE
     kernel where mmg_linear_bnbwd_supported (W [K, N] = the forward weight in place), the two launches elsewhere."""

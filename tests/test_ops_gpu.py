@@ -361,6 +361,27 @@ def test_l2_norm_inside_the_dense_forward(ops, dev, M, K, N, with_pro):
     assert float(o0.abs().max()) == 0.0 and torch.equal(r0, torch.full((M,), 1.0 / ops.L2_EPS, device=dev))
 
 
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_joint_bn_backward_inside_the_data_gradient_gemm(ops, dev, p):
+    """mmg_linear_bnbwd2 == mmg_bn_bwd_apply2 followed by mmg_linear_fwd(W_KN), bit for bit."""
+    gen = torch.Generator().manual_seed(123)
+    M, K, N = 4999, 128, 128
+    y = (torch.randn(M, K, generator=gen) * 1.5 + 0.2).to(dev)
+    g, g2 = torch.randn(M, K, generator=gen).to(dev), torch.randn(M, K, generator=gen).to(dev)
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    gamma, beta = (torch.rand(K, generator=gen) + 0.5).to(dev), (torch.randn(K, generator=gen) * 0.2).to(dev)
+    fold = ops.bn_finalize(ops.col_reduce2(y), M, gamma, beta, None, None, True)
+    pro = ops.Pro(fold.scale, fold.shift, True, p, seed=9, site=0, row_offset=10)
+    pro2 = ops.Pro(fold.scale, fold.shift, True, p, seed=9, site=2, row_offset=10)
+    sums = ops.bn_bwd_stats2(g, g2, y, pro, pro2, fold)
+    d0, d1 = torch.zeros(2, K, device=dev), torch.zeros(2, K, device=dev)
+    dz_ref = ops.bn_bwd_apply2(g, g2, y, pro, pro2, fold, sums, M, d0[0], d0[1])
+    assert ops.linear_bnbwd2_supported(M, N, K) and not ops.linear_bnbwd2_supported(M, 64, K)
+    dz, dx = ops.linear_bnbwd2(g, g2, y, pro, pro2, fold, W, sums, M, d1[0], d1[1])
+    assert torch.equal(dz, dz_ref) and torch.equal(d0, d1)
+    assert torch.equal(dx, ops.linear_fwd(dz_ref, W, w_kn=True))
+
+
 @pytest.mark.parametrize("M,K,N", [(5003, 128, 128), (4100, 128, 64), (3333, 64, 128), (600, 64, 64), (300, 128, 128)])
 def test_l2_norm_backward_inside_the_data_gradient_gemm(ops, dev, M, K, N):
     """mmg_linear_l2bwd == mmg_l2norm_bwd followed by mmg_linear_fwd(W_KN) (the row dot product is summed in another
