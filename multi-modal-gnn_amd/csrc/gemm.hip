@@ -314,11 +314,20 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
       float vv[16], ss[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) { vv[i] = acc[i] + bv; ss[i] = vv[i] * vv[i]; }
+      // 32-lane sums on the vector ALU's data-parallel primitives (five v_add_f32 with a DPP operand per value; the
+      // first version went through 80 ds_bpermute round trips per tile): xor 1, xor 2 inside a quad, mirror inside 8,
+      // mirror inside 16, then the row total of lanes 0..15 broadcast onto lanes 16..31 -- those hold the half's sum
 #pragma unroll
-      for (int o = 1; o < 32; o <<= 1)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ss[i] += __shfl_xor(ss[i], o, 64);
-      if (l31 == 0) {
+      for (int i = 0; i < 16; ++i) {
+        float v = ss[i];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast:15 -> rows 1, 3
+        ss[i] = v;
+      }
+      if (l31 == 31) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) l2_part[wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = ss[i];
       }
