@@ -285,6 +285,9 @@ class _Run:
         self.tape = {}
         self._nbt = {}               # BatchNorm step counters to advance: {id(module): [buffer, increment]}
         self.pending = {}            # parameter name -> further gradient contributions, summed at the end of the backward
+        # (sel_low, sel_high, counts) of the pairs the backward must visit, when the caller knows them in advance (a
+        # captured step with a per-epoch supervision mask: train.PiecewiseGraphedTrainStep); None: selected from dpred != 0
+        self.static_select = None
         self.pairs = None
         self.lazy_final = False      # predict mode: the final patient activations stay folded (see _LazyAct)
         # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
@@ -1126,8 +1129,15 @@ class _Run:
         gsets = {}
         # pairs with a zero upstream gradient (everything outside the supervision subset, train.py:366-370) add
         # exactly nothing: visit only the others, split by head
-        dsorted = torch.empty_like(dps)          # dpred in sorted pair order: the one random pass, made by the selection
-        bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps, io_perm=perm, dpred_sorted=dsorted)
+        if self.static_select is not None:
+            # the supervision subset is known (and a pair of it whose gradient happens to be 0 adds exactly nothing):
+            # no selection pass in the step; the kernels read dpred through the pair permutation
+            bsel_low, bsel_high, bcounts = self.static_select
+            dsrc, dio = dps, perm
+        else:
+            dsorted = torch.empty_like(dps)      # dpred in sorted pair order: the one random pass, made by the selection
+            bsel_low, bsel_high, bcounts = ops.pair_select(pi, plan.lab_deg, thr, dps, io_perm=perm, dpred_sorted=dsorted)
+            dsrc, dio = dsorted, None
         order = (("edge_predictor", rec["fin"], False), ("tabular_mlp", rec["init"], True))
         # one zero-fill for the small gradients of BOTH heads; the two lab-side tables dB sit first and adjacent, so that
         # a sharded run sums them over the ranks with ONE all-reduce
@@ -1155,8 +1165,8 @@ class _Run:
             g = ops.Head(dA[which], *views[which])
             sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
             ops.pair_head_bwd(head, g, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr,
-                              want_low, n_lab, self.p, self.seed, ids, dsorted,
-                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb)
+                              want_low, n_lab, self.p, self.seed, ids, dsrc,
+                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb, io_perm=dio)
             gs[which] = g
             self.acc(f"{which}.mlp.3.weight", g.W2, partial=True)
             self.acc(f"{which}.mlp.3.bias", g.b2, partial=True)

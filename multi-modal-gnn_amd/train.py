@@ -397,6 +397,8 @@ class PiecewiseGraphedTrainStep:
         self.sup = self._sv.sup
         self.loss_fn = loss_fn
         self._ops, self._Run = ops, _Run
+        self._sel = None
+        self._select()                 # the pair lists of the backward: fixed until set_mask, not part of the step
         dev = pi.device
         model._seed_dev = _new_seed_state(dev)
         self.loss = torch.zeros((), device=dev)
@@ -453,6 +455,7 @@ class PiecewiseGraphedTrainStep:
                                      self.plan.lab_deg, int(model.degree_threshold))
             run.n_pairs = self.pi.numel()
             run.need_grad = True
+            run.static_select = self._sel
             (pred,) = run.run_forward("predict")
             loss, dpred = ops.pair_loss(pred, self.y, self.wl, self.sup, 1.0, self.loss_fn, self._sv.inv_den)
             grads = run.run_backward((dpred,))
@@ -464,9 +467,25 @@ class PiecewiseGraphedTrainStep:
             self.loss = loss                         # fp64 scalar in the graph's pool: the same address at every replay
 
     # ---- replay
+    def _select(self):
+        """Pair lists of the backward (per head: the positions of the supervised pairs in patient order) from the
+        supervision mask: the loss gradient is exactly 0 outside it (train.py:366-370), so the lists only change with
+        set_mask -- the captured step holds their addresses, they are refreshed in place."""
+        ops, model = self._ops, self.model
+        pairs = model._pairs(self.pi, self.li, self.plan.n_rows,
+                             getattr(self.comm, "pair_ids", None) if self.comm else None,
+                             self.plan.lab_deg, int(model.degree_threshold))
+        new = ops.pair_select(pairs[0], self.plan.lab_deg, int(model.degree_threshold), self.sup, io_perm=pairs[2])
+        if self._sel is None:
+            self._sel = new
+        else:
+            for old_t, new_t in zip(self._sel, new):
+                old_t.copy_(new_t)
+
     def set_mask(self, sup_mask, n_sup_global=None):
-        """New supervision subset; 1 / n_sup (summed over the shards) follows it on the device."""
+        """New supervision subset; 1 / n_sup (summed over the shards) and the backward's pair lists follow it on the device."""
         self._sv.set_mask(sup_mask, n_sup_global)
+        self._select()
 
     def step(self) -> torch.Tensor:
         for kind, x in self.items:

@@ -278,6 +278,22 @@ def test_piecewise_graph_chain_matches_eager_steps(overlap, monkeypatch):
     for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         if not n.startswith("embeddings."):
             assert float((p1 - p2).detach().abs().max()) <= 1e-4 * float(p1.detach().abs().max()) + 1e-6, n
+    # a new per-epoch supervision subset (train.py:150-176): the normaliser AND the backward's pair lists (selected once
+    # per mask, outside the captured step) follow it -- the next replay still trains like the eager step on that mask
+    sup2 = (torch.arange(sel.numel(), device=dev) % 3 == 1)
+    step.set_mask(sup2, float(sup2.sum()))
+    assert int(step._sel[2].sum()) == int(sup2.sum())                # both heads' lists together = the supervised pairs
+    m1.train()
+    m1.zero_grad(set_to_none=True)
+    pred = m1.predict_lab_values(plan1, pi, li)
+    loss = ops.weighted_pair_loss(pred, y, wlab[li].contiguous(), sup2.float(), 1.0 / float(sup2.sum()), "mae")
+    loss.backward()
+    opt1.step()
+    l2 = float(step.step())
+    assert abs(float(loss) - l2) <= 2e-5 * abs(l2)
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if not n.startswith("embeddings."):
+            assert float((p1 - p2).detach().abs().max()) <= 1e-4 * float(p1.detach().abs().max()) + 1e-6, n
 
 
 @pytest.mark.parametrize("overlap", ["1", "2"])
