@@ -230,6 +230,10 @@ def cpu_baseline(args):
 def alg_of(tag, M, N, K, fl, extra):
     """Algorithmic (compulsory) bytes and flops of one launch of a probed kernel family."""
     if tag == "linear_fwd":
+        if fl & (16 | 64):
+            # BatchNorm / L2-norm backward inside the data-gradient GEMM: reads G and Y (and a second G: flag 128), writes
+            # dZ and dX
+            return 4 * ((4 if fl & 128 else 3) * M * K + N * K + M * N), 2 * M * N * K
         return 4 * (M * K + N * K + M * N * (2 if fl & 1 else 1)), 2 * M * N * K
     if tag == "linear_wgrad":
         return 4 * (M * N + M * K + N * K), 2 * M * N * K
@@ -451,7 +455,7 @@ def main():
             else:
                 roof = {"bound": "hbm", "achieved": d["alg_bytes"] / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": hbm_frac, "traffic": None}
-            tr = traffic.get(dominant)
+            tr = traffic.get("linear_bnbwd" if dominant == "linear_fwd" and d["flags"] & (16 | 64) else dominant)
             if tr and d["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / d["alg_bytes"] < 2.0:
                 roof["traffic"] = tr["hbm_bytes_per_launch"]
                 roof["traffic_source"] = tsrc
@@ -468,7 +472,8 @@ def main():
             out["roofline"] = roof
             ks = {}
             for name, op, fm, fv in (("gather", "gather_rows", None, None), ("scatter", "scatter_rows", 8, 0),
-                                     ("scatter_rowscale", "scatter_rows", 8, 8), ("linear_fwd", "linear_fwd", None, None),
+                                     ("scatter_rowscale", "scatter_rows", 8, 8), ("linear_fwd", "linear_fwd", 16 | 64, 0),
+                                     ("linear_bnbwd", "linear_fwd", 16, 16),
                                      ("linear_wgrad", "linear_wgrad", None, None), ("pair_head_fwd", "pair_head_fwd", None, None),
                                      ("pair_head_bwd", "pair_head_bwd", None, None)):
                 s_ = op_summary(table, op, fm, fv)
@@ -483,7 +488,7 @@ def main():
                     e["algorithmic_bytes"] = s_["alg_bytes"]
                     e["hbm_frac"] = s_["hbm_frac"]
                     assert 0.0 < e["hbm_frac"] <= 1.0, (name, e)
-                tr = traffic.get({"scatter_rowscale": "scatter_rows_rowscale"}.get(name, op))
+                tr = traffic.get({"scatter_rowscale": "scatter_rows_rowscale", "linear_bnbwd": "linear_bnbwd"}.get(name, op))
                 if tr and s_["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / s_["alg_bytes"] < 2.0:
                     e["traffic"] = tr["hbm_bytes_per_launch"]
                     fol = traffic.get({"scatter_rows": "scatter_reduce", "linear_wgrad": "linear_wgrad_reduce"}.get(op))

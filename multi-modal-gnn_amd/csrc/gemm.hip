@@ -628,7 +628,7 @@ int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const 
   const int64_t gy = fwd_x6_rows(M, N, N, K);
   constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
   MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN, MODE>, lds>::set()), "linear_bnbwd(attr)");
-  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 1 ? 64 : 16, (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 1 ? 64 : (MODE == 2 ? 16 | 128 : 16), (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
              dim3(64 * WN), lds, st, G, bb, pr, W, DX, M, pr2);
   return 0;
 }

@@ -97,7 +97,7 @@ def probe_arm(n: int):
 
 
 def probe_read(cap: int = 1 << 18):
-    """-> list of (ms, family name, M, N, K, flags) of the probed launches (flags: 1 accumulate, 4 prologue, 8 rowscale)."""
+    """-> list of (ms, family name, M, N, K, flags) of the probed launches (flags: 1 accumulate, 4 prologue, 8 rowscale, 16 BatchNorm backward staged in the GEMM, 32 L2-norm epilogue, 64 L2-norm backward staged, 128 two upstream gradients)."""
     import numpy as np
     ms = np.zeros(cap, np.float32); tag = np.zeros(cap, np.int32); M = np.zeros(cap, np.int64)
     N = np.zeros(cap, np.int32); K = np.zeros(cap, np.int32); fl = np.zeros(cap, np.int32)

@@ -17,7 +17,7 @@ import statistics
 import sys
 from collections import defaultdict
 
-OP_OF_KERNEL = [("k_linear_fwd", "linear_fwd"), ("k_linear_small", "linear_fwd"), ("k_linear_wgrad", "linear_wgrad"),
+OP_OF_KERNEL = [("k_linear_bnbwd", "linear_bnbwd"), ("k_linear_fwd", "linear_fwd"), ("k_linear_small", "linear_fwd"), ("k_linear_wgrad", "linear_wgrad"),
                 ("k_gather", "gather_rows"), ("k_scatter_strip", "scatter_rows"), ("k_scatter_units", "scatter_rows_rowscale"),
                 ("k_scatter_bits", "scatter_rows"), ("k_scatter_mfma", "scatter_rows"),
                 ("mmg_k_reduce_slabs<EpiScatter>", "scatter_reduce"), ("mmg_k_reduce_slabs<EpiStore>", "linear_wgrad_reduce"),
