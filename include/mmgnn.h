@@ -217,6 +217,13 @@ int mmg_linear_bnbwd2(const float* G, const float* G2, const float* Y, const mmg
                       const float* mean, const float* rstd, const double* sums, double inv_count, float* dbeta,
                       float* dgamma, const float* W, float* dZ, float* dX, int64_t M, int N, int K, void* stream);
 
+/* ... and the row-list form (mmg_bn_bwd_apply with G = NULL + mmg_bn_bwd_apply_rows): G_rows [n_sel, K] holds the listed
+ * rows of the upstream gradient back to back, row_pos[row] (int32, [M]) = position of `row` in that list or -1. */
+int mmg_linear_bnbwd_rows(const float* G_rows, const int32_t* row_pos, int64_t n_sel, const float* Y,
+                          const mmg_prologue_t* pro, const float* mean, const float* rstd, const double* sums,
+                          double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ, float* dX, int64_t M,
+                          int N, int K, void* stream);
+
 /* mmg_l2norm_bwd folded into the data-gradient GEMM of the linear in front of the normalisation the same way:
  * dZ = rnorm * (G - out * <G, out>) (0 dot product where the norm was clamped), dX = dZ . W, W stored [K,N].  Shapes as
  * mmg_linear_bnbwd_supported. */

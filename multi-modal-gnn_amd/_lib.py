@@ -113,6 +113,8 @@ SIGNATURES = {
     "mmg_linear_fwd_l2norm": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "mmg_linear_bnbwd_supported": (C.c_int, [_i64, _i32, _i32]),
     "mmg_linear_l2bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "mmg_linear_bnbwd_rows": (C.c_int, [_vp, _vp, _i64, _vp, _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp,
+                                        _i64, _i32, _i32, _vp]),
     "mmg_linear_bnbwd2": (C.c_int, [_vp, _vp, _vp, _P(PrologueT), _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp,
                                     _vp, _vp, _i64, _i32, _i32, _vp]),
     "mmg_linear_bnbwd": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _i64, _i32,

@@ -431,9 +431,11 @@ int launch_fwd_x6(const float* X, const ProDev& pr, const float* W, const float*
 // normalised rows, mean = rn [M].
 // MODE 2: MODE 0 with TWO upstream gradients through the same BatchNorm + ReLU, each with its own dropout mask
 // (mmg_bn_bwd_apply2: the two encode_nodes passes of a training step share their first layer).
+// MODE 3: MODE 0 with an upstream gradient that is ZERO outside a short list of rows (mmg_bn_bwd_apply with G = NULL +
+// mmg_bn_bwd_apply_rows): G holds the listed rows back to back, row_pos[row] = position in that list or -1.
 struct BnBwdDev {
   const float* Y; const float* mean; const float* rstd; const double* sums; double inv_count;
-  float* dZ; float* dbeta; float* dgamma; float l2_eps; const float* G2;
+  float* dZ; float* dbeta; float* dgamma; float l2_eps; const float* G2; const int32_t* row_pos; int64_t n_sel;
 };
 
 template <int K, int WN, int MODE = 0>
@@ -498,11 +500,32 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
   };
   f32x4 ng[NP], ny[NP], ng2[MODE == 2 ? NP : 1];      // the NEXT tile of G and Y (and G2)
   const int xvo = (prow * K + kc4 * 4) * 4;
+  int ridx[MODE == 3 ? NP : 1];             // MODE 3: list positions of the rows of the tile the NEXT fetch serves
+  auto fetch_idx = [&](int64_t tile) __attribute__((always_inline)) {
+    const int rows = rows_of(tile);
+    const __amdgpu_buffer_rsrc_t ps = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int32_t*>(bb.row_pos) + (size_t)(rows ? tile : 0) * BM, 0, rows * 4, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) ridx[p] = rows ? (int)__builtin_amdgcn_raw_buffer_load_b32(ps, (p * ROWS_PER_PASS + prow) * 4, 0, 0) : -1;
+  };
   auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int rows = rows_of(tile);
     const size_t off = (size_t)(rows ? tile : 0) * BM * K;
-    const __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G) + off, 0, rows * K * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bb.Y) + off, 0, rows * K * 4, 0x00020000);
+    if constexpr (MODE == 3) {
+      // the listed rows through one descriptor over the whole list: a row that is not listed (or past the end) gets an
+      // offset behind the list and reads 0
+      const __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G), 0, (int)(bb.n_sel * K * 4), 0x00020000);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const unsigned vo = ridx[p] >= 0 && p * ROWS_PER_PASS + prow < rows ? (unsigned)ridx[p] * (unsigned)(K * 4) + (unsigned)(kc4 * 16) : 0xFFFFFF00u;
+        ng[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs, vo, 0, 0));
+        ny[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
+      }
+      fetch_idx(tile + GY);
+      return;
+    }
+    const __amdgpu_buffer_rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G) + off, 0, rows * K * 4, 0x00020000);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       ng[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gs, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
@@ -577,6 +600,7 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
       *reinterpret_cast<xbf16x4*>(pb + (2 * BM + r) * LDP + kc4 * 4) = q2;
     }
   };
+  if constexpr (MODE == 3) fetch_idx(t0);
   fetch(t0);
   stage(t0, 0);
   fetch(t0 + GY);
@@ -628,7 +652,7 @@ int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const 
   const int64_t gy = fwd_x6_rows(M, N, N, K);
   constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
   MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN, MODE>, lds>::set()), "linear_bnbwd(attr)");
-  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 1 ? 64 : (MODE == 2 ? 16 | 128 : 16), (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 1 ? 64 : (MODE == 2 ? 16 | 128 : (MODE == 3 ? 16 | 256 : 16)), (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
              dim3(64 * WN), lds, st, G, bb, pr, W, DX, M, pr2);
   return 0;
 }
@@ -1273,7 +1297,7 @@ extern "C" int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prolog
   MMG_CHECK_ARG(!pro || pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_bnbwd: relu only");
   MMG_CHECK_ARG(!sums || (pro && pro->scale), "linear_bnbwd: sums without a BatchNorm fold");
   const ProDev pr = mmg_pro_dev(pro);
-  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, nullptr};
+  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, nullptr, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2>(G, bb, pr, W, dX, M, st);
@@ -1294,10 +1318,29 @@ extern "C" int mmg_linear_bnbwd2(const float* G, const float* G2, const float* Y
   MMG_CHECK_ARG(pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_bnbwd2: relu only");
   MMG_CHECK_ARG(!sums || pro->scale, "linear_bnbwd2: sums without a BatchNorm fold");
   const ProDev pr = mmg_pro_dev(pro), pr2 = mmg_pro_dev(pro2);
-  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, G2};
+  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, G2, nullptr, 0};
   int rc = launch_bnbwd_x6<128, 4, 2>(G, bb, pr, W, dX, M, (hipStream_t)stream, pr2);
   if (rc) return rc;
   MMG_CHECK_LAUNCH("linear_bnbwd2");
+  return MMG_OK;
+}
+
+extern "C" int mmg_linear_bnbwd_rows(const float* G_rows, const int32_t* row_pos, int64_t n_sel, const float* Y,
+                                     const mmg_prologue_t* pro, const float* mean, const float* rstd, const double* sums,
+                                     double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ, float* dX,
+                                     int64_t M, int N, int K, void* stream) {
+  MMG_CHECK_ARG(mmg_linear_bnbwd_supported(M, N, K) && K == 128 && N == 128,
+                "linear_bnbwd_rows: M=%lld N=%d K=%d unsupported (M > 512, K = N = 128)", (long long)M, N, K);
+  MMG_CHECK_ARG(Y && W && dZ && dX && pro && row_pos, "linear_bnbwd_rows: null buffer");
+  MMG_CHECK_ARG(n_sel >= 0 && n_sel * (int64_t)K * 4 < (int64_t)0x7FFFFFFF && (G_rows || n_sel == 0), "linear_bnbwd_rows: bad row list");
+  MMG_CHECK_ARG(!pro->scale || (pro->shift && mean && rstd), "linear_bnbwd_rows: BatchNorm fold without shift / mean / rstd");
+  MMG_CHECK_ARG(pro->relu == MMG_ACT_NONE || pro->relu == MMG_ACT_RELU, "linear_bnbwd_rows: relu only");
+  MMG_CHECK_ARG(!sums || pro->scale, "linear_bnbwd_rows: sums without a BatchNorm fold");
+  const ProDev pr = mmg_pro_dev(pro);
+  BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, nullptr, row_pos, n_sel};
+  int rc = launch_bnbwd_x6<128, 4, 3>(G_rows ? G_rows : Y, bb, pr, W, dX, M, (hipStream_t)stream);
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("linear_bnbwd_rows");
   return MMG_OK;
 }
 
@@ -1307,7 +1350,7 @@ extern "C" int mmg_linear_l2bwd(const float* G, const float* out, const float* r
                 (long long)M, N, K);
   MMG_CHECK_ARG(G && out && rnorm && W && dZ && dX, "linear_l2bwd: null buffer");
   const ProDev pr = mmg_pro_dev(nullptr);
-  BnBwdDev bb{out, rnorm, nullptr, nullptr, 0.0, dZ, nullptr, nullptr, eps, nullptr};
+  BnBwdDev bb{out, rnorm, nullptr, nullptr, 0.0, dZ, nullptr, nullptr, eps, nullptr, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4, 1>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2, 1>(G, bb, pr, W, dX, M, st);

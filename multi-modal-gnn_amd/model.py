@@ -223,7 +223,7 @@ class HeteroRGCN(nn.Module):
             pi_low = low_pos[pi_sorted.to(torch.int64)].contiguous() if n else pi_sorted
             deg_low = torch.zeros(max(int(low_rows.numel()), 1), dtype=torch.int32, device=pi.device)
             lists = (sel_low[:max(n_low, 1)].clone(), sel_high[:max(n_high, 1)].clone(), counts, n_low, n_high,
-                     low_rows, pi_low, deg_low)
+                     low_rows, pi_low, deg_low, low_pos)
         out = (pi_sorted, li_sorted, perm64, ids, lists)
         if len(self._pair_cache) >= 6:
             self._pair_cache.clear()
@@ -397,6 +397,7 @@ class _Run:
                 self.allreduce(both)
                 m0[2], m1[2], m0[3], m1[3] = both[0], both[1], True, True
             enc0 = self.enc_fwd(0, 1, first, rows=self.pairs[4][5], mid=m0)   # feeds the tabular head only: low-degree rows
+            enc0["row_pos"] = self.pairs[4][8]
             enc1 = self.enc_fwd(1, 1, first, mid=m1)
         else:
             enc0 = enc1 = self.enc_fwd(0, 2)
@@ -640,6 +641,15 @@ class _Run:
             # an upstream gradient that is zero outside the listed rows (training statistics): the dense apply pass never
             # reads a gradient tensor, the listed rows are patched afterwards
             dbg = torch.empty(2, y.shape[1], device=y.device)   # d beta | d gamma, written by the apply kernel
+            W4 = self.W(f"{pt}.4.weight")
+            if enc.get("row_pos") is not None and pro.relu in (0, 1) and fold.training and \
+                    ops.linear_bnbwd2_supported(y.shape[0], W4.shape[1], y.shape[1]):
+                # dense pass, row patch and the data-gradient GEMM of the second linear in ONE kernel
+                dz2, dx = ops.linear_bnbwd_rows(g, enc["row_pos"], y, pro, fold, W4, sums, fold.count, dbg[0], dbg[1])
+                self.acc(f"{pt}.5.bias", dbg[0])
+                self.acc(f"{pt}.5.weight", dbg[1])
+                self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", need_dx=False, partial=True)
+                return dx
             dz2 = ops.bn_bwd_apply(None, y, pro, fold, sums, fold.count, dbg[0], dbg[1])
             ops.bn_bwd_apply_rows(g, y, enc["rows"], pro, dz2)
             self.acc(f"{pt}.5.bias", dbg[0])
@@ -1101,7 +1111,7 @@ class _Run:
         plan = self.plan
         if LAB_EDGE not in plan.rels:
             raise KeyError(f"graph has no {LAB_EDGE} relation (model.py:297)")
-        pi, li, perm, ids, (sel_low, sel_high, counts, n_low, n_high, low_rows, pi_low, deg_low) = self.pairs
+        pi, li, perm, ids, (sel_low, sel_high, counts, n_low, n_high, low_rows, pi_low, deg_low, _) = self.pairs
         thr = int(self.m.degree_threshold)
         pred = torch.empty(pi.numel(), device=self.dev)          # every pair belongs to exactly one head list
         rec = dict(init=init, fin=fin)
@@ -1122,7 +1132,7 @@ class _Run:
 
     def heads_bwd(self, rec, dpred):
         plan, D = self.plan, self.D
-        pi, li, perm, ids, (_, _, _, n_low, n_high, low_rows, pi_low, deg_low) = self.pairs
+        pi, li, perm, ids, (_, _, _, n_low, n_high, low_rows, pi_low, deg_low, _) = self.pairs
         thr = int(self.m.degree_threshold)
         dps = dpred.contiguous()                 # caller's pair order: the kernels read it through perm
         n_lab = plan.num_nodes["lab"]

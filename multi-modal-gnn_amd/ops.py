@@ -533,6 +533,24 @@ def linear_bnbwd2(g: torch.Tensor, g2: torch.Tensor, y: torch.Tensor, pro: Pro, 
     return dz, dx
 
 
+def linear_bnbwd_rows(g_rows: torch.Tensor, row_pos: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold, W: torch.Tensor,
+                      sums, count, dbeta=None, dgamma=None):
+    """bn_bwd_apply(None, ...) + bn_bwd_apply_rows(g_rows, ...) + the data gradient dz @ W in one pass -> (dz, dx): the
+    upstream gradient is zero outside the listed rows; row_pos [M] int32 = position of a row in the list or -1."""
+    lib = _lib.load()
+    M, K = y.shape
+    N = W.shape[1]
+    dz = torch.empty_like(y)
+    dx = torch.empty(M, N, device=y.device)
+    _tok = _pb("linear_bnbwd")
+    check(lib.mmg_linear_bnbwd_rows(_p(g_rows) if g_rows.numel() else None, _p(row_pos, torch.int32), g_rows.shape[0], _p(y),
+                                    _pro(pro), _p(fold.mean), _p(fold.rstd), _p(sums, torch.float64), 1.0 / float(count),
+                                    _p(dbeta), _p(dgamma), _p(W), _p(dz), _p(dx), M, N, K, _stream()),
+          "mmg_linear_bnbwd_rows")
+    _pe(_tok, "linear_bnbwd", 4 * (2 * M * K + M * N), 2 * M * N * K)
+    return dz, dx
+
+
 def linear_l2bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor, W: torch.Tensor):
     """l2norm_bwd(g, out, rn) and the data gradient dz @ W of the linear in front of the normalisation -> (dz, dx): ONE
     kernel where mmg_linear_bnbwd_supported (W [K, N] = the forward weight in place), the two launches elsewhere."""

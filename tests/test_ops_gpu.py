@@ -362,6 +362,40 @@ def test_l2_norm_inside_the_dense_forward(ops, dev, M, K, N, with_pro):
 
 
 @pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("n_sel", [0, 1, 157])
+def test_row_list_bn_backward_inside_the_data_gradient_gemm(ops, dev, p, n_sel):
+    """mmg_linear_bnbwd_rows == mmg_bn_bwd_apply(G = NULL) + mmg_bn_bwd_apply_rows + mmg_linear_fwd(W_KN): the upstream
+    gradient is zero outside a row list (rows of the last, partial tile included)."""
+    gen = torch.Generator().manual_seed(321 + n_sel)
+    M, K, N = 4999, 128, 128
+    y = (torch.randn(M, K, generator=gen) * 1.5 + 0.2).to(dev)
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    rows = torch.randperm(M, generator=gen)[:n_sel].sort().values
+    if n_sel > 1:
+        rows[-1] = M - 1                                                # a row of the tail tile
+        rows = rows.unique()
+    rows = rows.to(dev)
+    g_rows = torch.randn(rows.numel(), K, generator=gen).to(dev)
+    row_pos = torch.full((M,), -1, dtype=torch.int32, device=dev)
+    row_pos[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=dev)
+    gamma, beta = (torch.rand(K, generator=gen) + 0.5).to(dev), (torch.randn(K, generator=gen) * 0.2).to(dev)
+    fold = ops.bn_finalize(ops.col_reduce2(y), M, gamma, beta, None, None, True)
+    pro = ops.Pro(fold.scale, fold.shift, True, p, seed=9, site=1, row_offset=10)
+    sums = ops.bn_bwd_stats_rows(g_rows, y, rows, pro, fold) if rows.numel() else torch.zeros(2, K, dtype=torch.float64, device=dev)
+    d0, d1 = torch.zeros(2, K, device=dev), torch.zeros(2, K, device=dev)
+    dz_ref = ops.bn_bwd_apply(None, y, pro, fold, sums, M, d0[0], d0[1])
+    if rows.numel():
+        ops.bn_bwd_apply_rows(g_rows, y, rows, pro, dz_ref)
+    dz, dx = ops.linear_bnbwd_rows(g_rows, row_pos, y, pro, fold, W, sums, M, d1[0], d1[1])
+    assert torch.equal(d0, d1)
+    mask = torch.ones(M, dtype=torch.bool, device=dev)
+    mask[rows] = False
+    assert torch.equal(dz[mask], dz_ref[mask])                          # rows without a gradient: the same arithmetic
+    assert rel(dz, dz_ref) <= 1e-6                                      # listed rows: scale * (g' - ...) in one expression
+    assert rel(dx, ops.linear_fwd(dz_ref, W, w_kn=True)) <= 2e-6
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
 def test_joint_bn_backward_inside_the_data_gradient_gemm(ops, dev, p):
     """mmg_linear_bnbwd2 == mmg_bn_bwd_apply2 followed by mmg_linear_fwd(W_KN), bit for bit."""
     gen = torch.Generator().manual_seed(123)
