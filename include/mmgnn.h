@@ -161,6 +161,24 @@ int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, const float*
 size_t mmg_linear_wgrad_ws_bytes(int64_t M, int N, int K);
 int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, float* dbias,
                      int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The weight gradient is the fixed-order sum of per-workgroup partial slabs; that sum is a launch of a few microseconds
+ * behind every layer.  mmg_linear_wgrad_deferred leaves the slabs in `ws` (which then has to stay untouched) and fills
+ * `job`; mmg_wgrad_reduce_group sums the slabs of up to MMG_WGRAD_REDUCE_MAX layers in ONE launch (nobody reads a weight
+ * gradient before the optimizer).  Two jobs of one launch must not write the same dW (an accumulating second
+ * contribution goes into a later launch); job.slab == NULL (a small-M launch wrote dW directly) is skipped. */
+#define MMG_WGRAD_REDUCE_MAX 16
+typedef struct {
+  const float* slab; int64_t n4; int n_split;     /* n_split slabs of n4 float4 each */
+  float* dW; float* dbias; int64_t nk4;           /* float4s [0, nk4) -> dW, the rest -> dbias */
+  int accumulate;
+} mmg_wgrad_reduce_t;
+int mmg_linear_wgrad_deferred(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, float* dbias,
+                              int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream,
+                              mmg_wgrad_reduce_t* job);
+int mmg_wgrad_reduce_group(const mmg_wgrad_reduce_t* jobs, int n_jobs, void* stream);
+/* 1: a launch of this shape writes / accumulates dW itself (one row range: no slabs) -- an accumulating call of that kind
+ * must not overtake a deferred job of the same gradient */
+int mmg_linear_wgrad_is_direct(int64_t M, int N, int K);
 
 /* column reductions over rows: out[0,:] = sum_m A[m,:], out[1,:] = sum_m A[m,:]*B[m,:] (fp64 out) */
 size_t mmg_col_reduce2_ws_bytes(int64_t M, int N);

@@ -64,6 +64,11 @@ class SmallBnBwdT(C.Structure):
                 ("row_offset", C.c_int64), ("seed_ptr", C.c_void_p)]
 
 
+class WgradReduceT(C.Structure):
+    _fields_ = [("slab", C.c_void_p), ("n4", C.c_int64), ("n_split", C.c_int), ("dW", C.c_void_p), ("dbias", C.c_void_p),
+                ("nk4", C.c_int64), ("accumulate", C.c_int)]
+
+
 class SumJobT(C.Structure):
     _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p * 4), ("n_src", C.c_int), ("len", C.c_int),
                 ("cols", C.c_int), ("ld_dst", C.c_int), ("ld_src", C.c_int * 4)]
@@ -93,6 +98,10 @@ SIGNATURES = {
     "mmg_linear_fwd_stats": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "mmg_linear_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32]),
     "mmg_linear_wgrad": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "mmg_linear_wgrad_deferred": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp,
+                                            _P(WgradReduceT)]),
+    "mmg_wgrad_reduce_group": (C.c_int, [_P(WgradReduceT), _i32, _vp]),
+    "mmg_linear_wgrad_is_direct": (C.c_int, [_i64, _i32, _i32]),
     "mmg_col_reduce2_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_col_reduce2": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp, _sz, _vp]),
     "mmg_bn_finalize": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp,

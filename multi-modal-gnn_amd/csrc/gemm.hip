@@ -1366,8 +1366,10 @@ extern "C" size_t mmg_linear_wgrad_ws_bytes(int64_t M, int N, int K) {
   return (size_t)p.n_split * ((size_t)N * K + N) * 4 + 256;       // + N: the optional bias sums behind every slab
 }
 
-extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, float* dbias,
-                                int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+static int linear_wgrad_impl(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, float* dbias,
+                             int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream,
+                             mmg_wgrad_reduce_t* job) {
+  if (job) { job->slab = nullptr; job->n4 = 0; job->n_split = 0; job->dW = dW; job->dbias = dbias; job->nk4 = (int64_t)N * K / 4; job->accumulate = accumulate; }
   MMG_CHECK_ARG(M >= 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "linear_wgrad: N=%d K=%d must be multiples of 64", N, K);
   MMG_CHECK_ARG(dW, "linear_wgrad: dW is null");
   hipStream_t st = (hipStream_t)stream;
@@ -1407,10 +1409,84 @@ extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prolo
     if (rc) return rc;
   }
   if (!direct) {
-    MMG_LAUNCH(MMG_PROBE_LINEAR_WGRAD_REDUCE, M, N, K, 0, (mmg_k_reduce_slabs<EpiStore>),
-               dim3((unsigned)((stride / 4 + 15) / 16)), dim3(256), 0, st, slab, stride / 4, p.n_split,
-               EpiStore{dW, accumulate, dbias, (int64_t)N * K / 4});
+    if (job) {                      // the caller sums the slabs later, together with those of other layers
+      job->slab = slab; job->n4 = stride / 4; job->n_split = p.n_split;
+    } else {
+      MMG_LAUNCH(MMG_PROBE_LINEAR_WGRAD_REDUCE, M, N, K, 0, (mmg_k_reduce_slabs<EpiStore>),
+                 dim3((unsigned)((stride / 4 + 15) / 16)), dim3(256), 0, st, slab, stride / 4, p.n_split,
+                 EpiStore{dW, accumulate, dbias, (int64_t)N * K / 4});
+    }
   }
   MMG_CHECK_LAUNCH("linear_wgrad");
+  return MMG_OK;
+}
+
+extern "C" int mmg_linear_wgrad(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, float* dbias,
+                                int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  return linear_wgrad_impl(dY, X, pro, dW, dbias, M, N, K, accumulate, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int mmg_linear_wgrad_is_direct(int64_t M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 64) return 1;
+  return plan_wgrad(M, N, K).n_split == 1 ? 1 : 0;
+}
+
+extern "C" int mmg_linear_wgrad_deferred(const float* dY, const float* X, const mmg_prologue_t* pro, float* dW, float* dbias,
+                                         int64_t M, int N, int K, int accumulate, void* ws, size_t ws_bytes, void* stream,
+                                         mmg_wgrad_reduce_t* job) {
+  MMG_CHECK_ARG(job, "linear_wgrad_deferred: job is null");
+  return linear_wgrad_impl(dY, X, pro, dW, dbias, M, N, K, accumulate, ws, ws_bytes, stream, job);
+}
+
+namespace {
+struct WgradReduceTable { mmg_wgrad_reduce_t j[MMG_WGRAD_REDUCE_MAX]; };
+// the slab sums of several weight gradients in ONE launch: blockIdx.y = job, the body of mmg_k_reduce_slabs<EpiStore>
+__global__ __launch_bounds__(256) void k_wgrad_reduce_group(WgradReduceTable tb) {
+  __shared__ mmg_f4 part[16][16];
+  const mmg_wgrad_reduce_t jb = tb.j[blockIdx.y];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t i4 = (int64_t)blockIdx.x * 16 + e;
+  if ((int64_t)blockIdx.x * 16 >= jb.n4) return;               // (uniform per block)
+  mmg_f4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (i4 < jb.n4) {
+    const mmg_f4* base = reinterpret_cast<const mmg_f4*>(jb.slab) + i4;
+    int sidx = g;
+    for (; sidx + 7 * 16 < jb.n_split; sidx += 8 * 16) {
+      mmg_f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(sidx + u * 16) * jb.n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; sidx < jb.n_split; sidx += 16) acc += base[(size_t)sidx * jb.n4];
+  }
+  part[g][e] = acc;
+  __syncthreads();
+  if (g == 0 && i4 < jb.n4) {
+    mmg_f4 t = part[0][e];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) t += part[q][e];
+    EpiStore{jb.dW, jb.accumulate, jb.dbias, jb.nk4}(i4, t);
+  }
+}
+}  // namespace
+
+extern "C" int mmg_wgrad_reduce_group(const mmg_wgrad_reduce_t* jobs, int n_jobs, void* stream) {
+  MMG_CHECK_ARG(jobs && n_jobs >= 1 && n_jobs <= MMG_WGRAD_REDUCE_MAX, "wgrad_reduce_group: 1..%d jobs", MMG_WGRAD_REDUCE_MAX);
+  WgradReduceTable tb;
+  int64_t max_n4 = 0;
+  int n = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    if (!jobs[j].slab) continue;                                // (a small-M launch wrote its gradient directly)
+    MMG_CHECK_ARG(jobs[j].dW && jobs[j].n4 > 0 && jobs[j].n_split > 0, "wgrad_reduce_group: bad job %d", j);
+    for (int q = 0; q < n; ++q)
+      MMG_CHECK_ARG(tb.j[q].dW != jobs[j].dW, "wgrad_reduce_group: two jobs of one launch write the same gradient (job %d)", j);
+    tb.j[n++] = jobs[j];
+    if (jobs[j].n4 > max_n4) max_n4 = jobs[j].n4;
+  }
+  if (n == 0) return MMG_OK;
+  MMG_LAUNCH(MMG_PROBE_LINEAR_WGRAD_REDUCE, 0, 0, 0, 0, (k_wgrad_reduce_group), dim3((unsigned)((max_n4 + 15) / 16), (unsigned)n),
+             dim3(256), 0, (hipStream_t)stream, tb);
+  MMG_CHECK_LAUNCH("wgrad_reduce_group");
   return MMG_OK;
 }

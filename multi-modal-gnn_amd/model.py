@@ -285,6 +285,7 @@ class _Run:
         self.tape = {}
         self._nbt = {}               # BatchNorm step counters to advance: {id(module): [buffer, increment]}
         self.pending = {}            # parameter name -> further gradient contributions, summed at the end of the backward
+        self.wgrad_jobs = []         # deferred slab sums of the big weight gradients: one launch at the end of the backward
         # (sel_low, sel_high, counts) of the pairs the backward must visit, when the caller knows them in advance (a
         # captured step with a per-epoch supervision mask: train.PiecewiseGraphedTrainStep); None: selected from dpred != 0
         self.static_select = None
@@ -321,7 +322,9 @@ class _Run:
             self.partial.add(name)
 
     def flush_grad_sums(self):
-        """grads[name] += every later contribution recorded by acc(), all parameters in ONE mmg_vec_sums launch per 8."""
+        """The deferred slab sums of the weight gradients (one launch), then grads[name] += every later contribution
+        recorded by acc(), all parameters in ONE mmg_vec_sums launch per 8."""
+        ops.wgrad_reduce_flush(self.wgrad_jobs)
         jobs = []
         for name, more in self.pending.items():
             dst = self.grads[name]
@@ -598,14 +601,14 @@ class _Run:
         if bname is not None:            # the bias gradient (column sums of dy) comes out of the same pass over dy
             gb = self.grads.get(bname)
             if gw is not None and gb is not None:
-                ops.linear_wgrad(dy, x, pro, out=gw, accumulate=True, with_bias=True, bias_out=gb)
+                ops.linear_wgrad(dy, x, pro, out=gw, accumulate=True, with_bias=True, bias_out=gb, defer=self.wgrad_jobs)
                 dW, db = gw, gb
             else:
-                dW, db = ops.linear_wgrad(dy, x, pro, with_bias=True)
+                dW, db = ops.linear_wgrad(dy, x, pro, with_bias=True, defer=self.wgrad_jobs)
             self.acc(wname, dW, partial)
             self.acc(bname, db, partial)
         else:
-            self.acc(wname, ops.linear_wgrad(dy, x, pro, out=gw, accumulate=gw is not None), partial)
+            self.acc(wname, ops.linear_wgrad(dy, x, pro, out=gw, accumulate=gw is not None, defer=self.wgrad_jobs), partial)
         if need_dx:
             if dx_into is not None:
                 return ops.linear_fwd(dy, self.W(wname), w_kn=True, out=dx_into, accumulate=True)
@@ -992,7 +995,7 @@ class _Run:
             if dyP is None or not rec["rin"]:
                 return None
             xP = x[ROW_TYPE]
-            dWsum, dbsum = ops.linear_wgrad(dyP, xP, with_bias=True)
+            dWsum, dbsum = ops.linear_wgrad(dyP, xP, with_bias=True, defer=self.wgrad_jobs)
             if fused is None:
                 add_dgrad(ROW_TYPE, dyP, rec["Wsum"])
             rels, dTs, off = [], [], 0

@@ -13,7 +13,8 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import HeadGradT, HeadT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, check
+from ._lib import (HeadGradT, HeadT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, WgradReduceT,
+                   check)
 
 BN_MOMENTUM = 0.1
 BN_EPS = 1e-5
@@ -314,9 +315,13 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, out: Optional[torch.Tensor] = None,
-                 accumulate: bool = False, with_bias: bool = False, bias_out: Optional[torch.Tensor] = None):
+                 accumulate: bool = False, with_bias: bool = False, bias_out: Optional[torch.Tensor] = None,
+                 defer: Optional[list] = None):
     """out[N,K] (+)= dy[M,N]^T @ pro(x)[M,K].  with_bias: also return the column sums of dy ([N] float, the bias
-    gradient of the same layer), computed in the same pass over dy."""
+    gradient of the same layer), computed in the same pass over dy.
+    defer (a list): the partial slabs are NOT summed now -- a job is appended to the list and `out` is complete only after
+    wgrad_reduce_flush(list), which sums the slabs of many layers in one launch (nobody reads a weight gradient before the
+    optimizer does)."""
     lib = _lib.load()
     M, N = dy.shape
     K = x.shape[1]
@@ -329,12 +334,41 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, pro: Optional[Pro] = None, o
     if with_bias:
         dbias = bias_out if (bias_out is not None and accumulate) else torch.empty(N, dtype=torch.float32, device=x.device)
     nb = lib.mmg_linear_wgrad_ws_bytes(M, N, K)
-    ws = workspace(nb, x.device)
     _tok = _pb("linear_wgrad")
-    check(lib.mmg_linear_wgrad(_p(dy), _p(x), _pro(pro), _p(out), _p(dbias), M, N, K, int(accumulate),
-                               _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_linear_wgrad")
+    if defer is None:
+        ws = workspace(nb, x.device)
+        check(lib.mmg_linear_wgrad(_p(dy), _p(x), _pro(pro), _p(out), _p(dbias), M, N, K, int(accumulate),
+                                   _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_linear_wgrad")
+    else:
+        if accumulate and lib.mmg_linear_wgrad_is_direct(M, N, K) and any(j[2] is out for j in defer):
+            wgrad_reduce_flush(defer)        # a small launch adds into `out` in place: its earlier slabs must be summed first
+        ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device=x.device)      # its own slabs: they live until the flush
+        job = WgradReduceT()
+        check(lib.mmg_linear_wgrad_deferred(_p(dy), _p(x), _pro(pro), _p(out), _p(dbias), M, N, K, int(accumulate),
+                                            _p(ws, torch.uint8), ws.numel(), _stream(), C.byref(job)),
+              "mmg_linear_wgrad_deferred")
+        defer.append((job, ws, out, dbias))
     _pe(_tok, "linear_wgrad", 4 * (M * N + M * K + N * K), 2 * M * N * K)
     return (out, dbias) if with_bias else out
+
+
+def wgrad_reduce_flush(jobs: list):
+    """Sum the slabs of every deferred weight gradient (linear_wgrad(defer=...)): one launch per <= 16 jobs; a job that
+    accumulates into a gradient an earlier job of the list writes goes into a later launch.  Empties the list."""
+    lib = _lib.load()
+    todo = [j for j in jobs if j[0].slab]
+    jobs.clear()
+    while todo:
+        group, later, seen = [], [], set()
+        for j in todo:
+            if j[0].dW in seen or len(group) == 16:
+                later.append(j)
+            else:
+                group.append(j)
+            seen.add(j[0].dW)            # (also blocks every LATER job of that gradient: the order of its sums is kept)
+        arr = (WgradReduceT * len(group))(*[j[0] for j in group])
+        check(lib.mmg_wgrad_reduce_group(arr, len(group), _stream()), "mmg_wgrad_reduce_group")
+        todo = later
 
 
 def col_reduce2(a: torch.Tensor, b: Optional[torch.Tensor] = None):

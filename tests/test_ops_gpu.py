@@ -807,3 +807,28 @@ def test_small_bn_groups_match_the_separate_kernels(dev, training, act, p):
             assert rel(dbeta, dbg[0]) <= 2e-6 and rel(dgamma, dbg[1]) <= 2e-6
         else:
             assert dbeta is None and dgamma is None
+
+
+def test_deferred_weight_gradient_sums(ops, dev):
+    """linear_wgrad(defer=list) + wgrad_reduce_flush == the immediate form, bit for bit: several layers in one launch, an
+    accumulating second contribution to the same gradient (a later launch), a small direct launch behind a deferred one,
+    bias gradients riding along."""
+    gen = torch.Generator().manual_seed(4242)
+
+    def mk(M, N, K):
+        return torch.randn(M, N, generator=gen).to(dev), torch.randn(M, K, generator=gen).to(dev)
+
+    a, b, c, d = mk(5000, 128, 128), mk(3000, 64, 128), mk(4200, 128, 128), mk(100, 128, 128)
+    ref1, refb1 = ops.linear_wgrad(a[0], a[1], with_bias=True)
+    ref2 = ops.linear_wgrad(b[0], b[1])
+    ops.linear_wgrad(c[0], c[1], out=ref1, accumulate=True, with_bias=True, bias_out=refb1)
+    ops.linear_wgrad(d[0], d[1], out=ref1, accumulate=True, with_bias=True, bias_out=refb1)
+    jobs = []
+    g1, gb1 = ops.linear_wgrad(a[0], a[1], with_bias=True, defer=jobs)
+    g2 = ops.linear_wgrad(b[0], b[1], defer=jobs)
+    ops.linear_wgrad(c[0], c[1], out=g1, accumulate=True, with_bias=True, bias_out=gb1, defer=jobs)
+    assert len(jobs) == 3
+    ops.linear_wgrad(d[0], d[1], out=g1, accumulate=True, with_bias=True, bias_out=gb1, defer=jobs)   # direct: flushes first
+    ops.wgrad_reduce_flush(jobs)
+    assert not jobs
+    assert torch.equal(g1, ref1) and torch.equal(gb1, refb1) and torch.equal(g2, ref2)
