@@ -39,4 +39,4 @@ for i, nm in enumerate(names):
     print(f"{nm:48s} median {np.median(d):9.0f}  p10 {np.percentile(d,10):9.0f}  p90 {np.percentile(d,90):9.0f} ticks")
 tot = st[:, 4] - st[:, 0]
 print("wave total median", np.median(tot), "max", tot.max(), "; kernel span (first start -> last end)", st[:, 4].max() - t0, "; start skew p90", np.percentile(st[:,0]-t0, 90))
-print("(s_memtime ticks: 100 MHz constant clock -> 10 ns per tick)")
+print("(s_memtime tick rate not calibrated here: only the RATIOS of the phases are used)")
