@@ -100,9 +100,24 @@ int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
                     float* out, int accumulate, void* stream);
 /* the same, plus col_sums[2,D] (fp64) = (sum_rows out, sum_rows out^2) of the FINAL output: the batch statistics of
  * the per-type BatchNorm that follows the HeteroConv sum (src/model.py:258-262), from the gather epilogue */
+/* Training-mode BatchNorm1d fold (what mmg_bn_finalize computes from the column sums: scale / shift / mean / rstd, running
+ * statistics advanced n_updates times) taken in the SAME launch that sums the producers' partial statistics rows:
+ * mmg_linear_fwd_stats_bn / mmg_gather_rows_stats_bn = mmg_linear_fwd_stats / mmg_gather_rows_stats + mmg_bn_finalize
+ * (training = 1) with one launch less (col_sums still receives the sums).  Single-GPU form: a patient-sharded run has to
+ * all-reduce the sums between the two. */
+typedef struct {
+  int64_t count;
+  const float* gamma; const float* beta;      /* [N], nullable: 1 / 0 */
+  float* running_mean; float* running_var;    /* [N], nullable: not advanced */
+  int n_updates;
+  float momentum; float eps;
+  float* scale; float* shift; float* mean; float* rstd;   /* [N] outputs; mean / rstd nullable */
+} mmg_bn_fin_t;
 size_t mmg_gather_rows_stats_ws_bytes(int64_t n_rows, int D);
 int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
                           double* col_sums, void* ws, size_t ws_bytes, void* stream);
+int mmg_gather_rows_stats_bn(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                             double* col_sums, void* ws, size_t ws_bytes, const mmg_bn_fin_t* fin, void* stream);
 
 size_t mmg_scatter_rows_ws_bytes(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D);
 int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D,
@@ -155,6 +170,9 @@ size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N);
 int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
                          float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,
                          size_t ws_bytes, void* stream);
+int mmg_linear_fwd_stats_bn(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias, float* Y,
+                            int64_t M, int N, int K, int flags, double* col_sums, void* ws, size_t ws_bytes,
+                            const mmg_bn_fin_t* fin, void* stream);
 
 /* dW[N,K] (+)= dY[M,N]^T . prologue(X)[M,K]   (reduction over the M rows);
  * dbias (nullable, [N]) (+)= the column sums of dY -- the bias gradient of the same layer, from the same pass */

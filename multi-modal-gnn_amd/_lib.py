@@ -64,6 +64,12 @@ class SmallBnBwdT(C.Structure):
                 ("row_offset", C.c_int64), ("seed_ptr", C.c_void_p)]
 
 
+class BnFinT(C.Structure):
+    _fields_ = [("count", C.c_int64), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("n_updates", C.c_int), ("momentum", C.c_float), ("eps", C.c_float),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p)]
+
+
 class WgradReduceT(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("n4", C.c_int64), ("n_split", C.c_int), ("dW", C.c_void_p), ("dbias", C.c_void_p),
                 ("nk4", C.c_int64), ("accumulate", C.c_int)]
@@ -91,11 +97,13 @@ SIGNATURES = {
     "mmg_gather_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _i32, _vp]),
     "mmg_gather_rows_stats_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_gather_rows_stats": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "mmg_gather_rows_stats_bn": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _P(BnFinT), _vp]),
     "mmg_scatter_rows_ws_bytes": (_sz, [_P(RelT), _i32, _i64, _i32]),
     "mmg_scatter_rows": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _vp, _sz, _vp]),
     "mmg_linear_fwd": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "mmg_linear_fwd_stats_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_linear_fwd_stats": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "mmg_linear_fwd_stats_bn": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _P(BnFinT), _vp]),
     "mmg_linear_wgrad_ws_bytes": (_sz, [_i64, _i32, _i32]),
     "mmg_linear_wgrad": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "mmg_linear_wgrad_deferred": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp,

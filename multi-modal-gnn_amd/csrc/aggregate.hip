@@ -1341,6 +1341,10 @@ int pack(const mmg_rel_t* rels, int n_rel, RelPack* rp, bool need_table, bool ne
 }  // namespace
 
 extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream);
+extern "C" int mmg_partial_sum_bn(const double* partial, double* col_sums, int N, int n_rows, const mmg_bn_fin_t* fin, void* stream);
+extern "C" int mmg_bn_finalize(const double* sums, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int training, int n_updates, float momentum, float eps, float* scale,
+                               float* shift, float* mean, float* rstd, int N, void* stream);
 extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
                                      double* col_sums, void* ws, size_t ws_bytes, void* stream);
 
@@ -1355,8 +1359,8 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
   return mmg_gather_rows_stats(rels, n_rel, n_rows, D, out, accumulate, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
-                                     double* col_sums, void* ws, size_t ws_bytes, void* stream) {
+static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                                  double* col_sums, void* ws, size_t ws_bytes, void* stream, const mmg_bn_fin_t* fin) {
   if (col_sums) {
     MMG_CHECK_ARG(n_rows > 0 && ws && ws_bytes >= mmg_gather_rows_stats_ws_bytes(n_rows, D),
                   "gather_rows_stats: workspace too small");
@@ -1365,7 +1369,12 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
 #define MMG_GATHER_TAIL(what)                                                                                 \
   do {                                                                                                        \
     MMG_CHECK_LAUNCH(what);                                                                                   \
-    if (col_sums) return mmg_col_reduce2(out, nullptr, col_sums, n_rows, D, ws, ws_bytes, stream);            \
+    if (col_sums) {                                                                                           \
+      int rc_ = mmg_col_reduce2(out, nullptr, col_sums, n_rows, D, ws, ws_bytes, stream);                     \
+      if (rc_ || !fin) return rc_;                                                                            \
+      return mmg_bn_finalize(col_sums, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var, 1, \
+                             fin->n_updates, fin->momentum, fin->eps, fin->scale, fin->shift, fin->mean, fin->rstd, D, stream); \
+    }                                                                                                         \
     return MMG_OK;                                                                                            \
   } while (0)
   MMG_CHECK_ARG(mmg_valid_D(D), "gather_rows: D=%d unsupported (64|128|256)", D);
@@ -1395,7 +1404,7 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
       if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       MMG_CHECK_LAUNCH("gather_rows(bits)");
-      if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
+      if (col_sums) return mmg_partial_sum_bn(partial, col_sums, D, g, fin, stream);
       return MMG_OK;
     }
     if (okb) {
@@ -1407,7 +1416,7 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
       if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
       MMG_CHECK_LAUNCH("gather_rows(bits)");
-      if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
+      if (col_sums) return mmg_partial_sum_bn(partial, col_sums, D, g, fin, stream);
       return MMG_OK;
     }
   }
@@ -1433,7 +1442,7 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
                    gp.gu, rp, n_rows, n_tiles, D, out, partial);
       }
       MMG_CHECK_LAUNCH("gather_rows(units)");
-      if (col_sums) return mmg_partial_sum(partial, col_sums, 2 * D, g, stream);
+      if (col_sums) return mmg_partial_sum_bn(partial, col_sums, D, g, fin, stream);
       return MMG_OK;
     }
   }
@@ -1465,6 +1474,17 @@ extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n
   else hipLaunchKernelGGL(k_gather<4>, dim3(nb), dim3(256), 0, st, rp, n_rows, out, accumulate);
   MMG_GATHER_TAIL("gather_rows");
 #undef MMG_GATHER_TAIL
+}
+
+extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                                     double* col_sums, void* ws, size_t ws_bytes, void* stream) {
+  return gather_rows_stats_impl(rels, n_rel, n_rows, D, out, accumulate, col_sums, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int mmg_gather_rows_stats_bn(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                                        double* col_sums, void* ws, size_t ws_bytes, const mmg_bn_fin_t* fin, void* stream) {
+  MMG_CHECK_ARG(col_sums && fin && fin->count > 0 && fin->scale && fin->shift, "gather_rows_stats_bn: col_sums and a fold descriptor are required");
+  return gather_rows_stats_impl(rels, n_rel, n_rows, D, out, accumulate, col_sums, ws, ws_bytes, stream, fin);
 }
 
 extern "C" size_t mmg_scatter_rows_ws_bytes(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {

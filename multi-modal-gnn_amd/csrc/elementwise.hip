@@ -134,17 +134,14 @@ __global__ __launch_bounds__(256) void k_partial_sum(const double* __restrict__ 
   if (lane == 0) out[i] = s;
 }
 
-__global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ sums, int64_t count,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* running_mean, float* running_var, int training,
-                                                     int n_updates, float momentum, float eps, float* scale,
-                                                     float* shift, float* mean_out, float* rstd_out, int N) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
+// one column of the BatchNorm fold (shared by k_bn_finalize and k_partial_sum_bn: the same arithmetic, bit for bit)
+__device__ inline void bn_fold_col(double sum1, double sum2, int64_t count, int i, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, int training, int n_updates, float momentum,
+                                   float eps, float* scale, float* shift, float* mean_out, float* rstd_out) {
   float mean, var;
   if (training) {
-    const double m = sums[i] / (double)count;
-    double v = sums[N + i] / (double)count - m * m;
+    const double m = sum1 / (double)count;
+    double v = sum2 / (double)count - m * m;
     if (v < 0) v = 0;
     mean = (float)m; var = (float)v;
     if (running_mean) {
@@ -166,6 +163,38 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ 
   shift[i] = b - mean * sc;
   if (mean_out) mean_out[i] = mean;
   if (rstd_out) rstd_out[i] = rstd;
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const double* __restrict__ sums, int64_t count,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* running_mean, float* running_var, int training,
+                                                     int n_updates, float momentum, float eps, float* scale,
+                                                     float* shift, float* mean_out, float* rstd_out, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  bn_fold_col(training ? sums[i] : 0.0, training ? sums[N + i] : 0.0, count, i, gamma, beta, running_mean, running_var,
+              training, n_updates, momentum, eps, scale, shift, mean_out, rstd_out);
+}
+
+// the partial statistics rows of a producer kernel ([nblk][2][N] fp64) summed in fixed order -- one wave per column, as
+// k_partial_sum -- and folded at once (training mode)
+__global__ __launch_bounds__(256) void k_partial_sum_bn(const double* __restrict__ partial, double* __restrict__ out, int N,
+                                                        int nblk, mmg_bn_fin_t f) {
+  const int lane = threadIdx.x & 63;
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  if (i >= N) return;
+  double s1 = 0, s2 = 0;
+  for (int b = lane; b < nblk; b += 64) {
+    s1 += partial[(size_t)b * 2 * N + i];
+    s2 += partial[(size_t)b * 2 * N + N + i];
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    out[i] = s1; out[N + i] = s2;
+    bn_fold_col(s1, s2, f.count, i, f.gamma, f.beta, f.running_mean, f.running_var, 1, f.n_updates, f.momentum, f.eps,
+                f.scale, f.shift, f.mean, f.rstd);
+  }
 }
 
 // Both passes are pure HBM streams: the per-column constants are hoisted into registers (the grid stride is a
@@ -468,6 +497,16 @@ int run_col_reduce(const float* A, const float* B, const ProDev& pr, const float
 extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream) {
   hipLaunchKernelGGL(k_partial_sum, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, out, n, n_rows);
   MMG_CHECK_LAUNCH("partial_sum");
+  return MMG_OK;
+}
+
+// internal (gemm.hip, aggregate.hip): the same with the BatchNorm fold of the summed statistics (fin != NULL)
+extern "C" int mmg_partial_sum_bn(const double* partial, double* col_sums, int N, int n_rows, const mmg_bn_fin_t* fin,
+                                  void* stream) {
+  if (!fin) return mmg_partial_sum(partial, col_sums, 2 * N, n_rows, stream);
+  MMG_CHECK_ARG(fin->count > 0 && fin->scale && fin->shift, "partial_sum_bn: bad BatchNorm fold descriptor");
+  hipLaunchKernelGGL(k_partial_sum_bn, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, col_sums, N, n_rows, *fin);
+  MMG_CHECK_LAUNCH("partial_sum_bn");
   return MMG_OK;
 }
 

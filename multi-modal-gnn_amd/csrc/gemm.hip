@@ -1182,6 +1182,10 @@ int launch_small(const float* X, const ProDev& pr, const float* W, const float* 
 extern "C" int mmg_col_reduce2(const float* A, const float* B, double* out, int64_t M, int N, void* ws, size_t ws_bytes,
                                void* stream);
 extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream);
+extern "C" int mmg_partial_sum_bn(const double* partial, double* col_sums, int N, int n_rows, const mmg_bn_fin_t* fin, void* stream);
+extern "C" int mmg_bn_finalize(const double* sums, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, int training, int n_updates, float momentum, float eps, float* scale,
+                               float* shift, float* mean, float* rstd, int N, void* stream);
 
 extern "C" size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N) {
   if (M < 0 || N <= 0) return 0;
@@ -1199,9 +1203,9 @@ extern "C" int mmg_linear_fwd(const float* X, const mmg_prologue_t* pro, const f
   return mmg_linear_fwd_stats(X, pro, W, bias, Y, M, N, K, flags, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
-                                    float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,
-                                    size_t ws_bytes, void* stream) {
+static int linear_fwd_stats_impl(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
+                                 float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,
+                                 size_t ws_bytes, void* stream, const mmg_bn_fin_t* fin) {
   const int accumulate = flags;           // the launchers forward the whole flag word
   if (col_sums) {
     MMG_CHECK_ARG(ws && ws_bytes >= mmg_linear_fwd_stats_ws_bytes(M, N), "linear_fwd_stats: workspace too small");
@@ -1238,7 +1242,7 @@ extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, c
     if (rc) return rc;
     if (col_sums) {     // partial[gy][2][N] -> col_sums[2][N]
       const int rows = (int)fwd_x6_rows(M, N, N % 128 == 0 ? 128 : 64, K);
-      int rc2 = mmg_partial_sum(partial, col_sums, 2 * N, rows, stream);
+      int rc2 = mmg_partial_sum_bn(partial, col_sums, N, rows, fin, stream);     // (+ the BatchNorm fold when asked for)
       if (rc2) return rc2;
       stats_done = true;
     }
@@ -1247,9 +1251,26 @@ extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, c
     launch_fwd<256, 1, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
   }
   MMG_CHECK_LAUNCH("linear_fwd");
-  if (col_sums && !stats_done)            // small-M / fp32 kernels: a separate pass over Y
-    return mmg_col_reduce2(Y, nullptr, col_sums, M, N, ws, ws_bytes, stream);
+  if (col_sums && !stats_done) {          // small-M / fp32 kernels: a separate pass over Y
+    int rc3 = mmg_col_reduce2(Y, nullptr, col_sums, M, N, ws, ws_bytes, stream);
+    if (rc3 || !fin) return rc3;
+    return mmg_bn_finalize(col_sums, fin->count, fin->gamma, fin->beta, fin->running_mean, fin->running_var, 1, fin->n_updates,
+                           fin->momentum, fin->eps, fin->scale, fin->shift, fin->mean, fin->rstd, N, stream);
+  }
   return MMG_OK;
+}
+
+extern "C" int mmg_linear_fwd_stats(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
+                                    float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,
+                                    size_t ws_bytes, void* stream) {
+  return linear_fwd_stats_impl(X, pro, W, bias, Y, M, N, K, flags, col_sums, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int mmg_linear_fwd_stats_bn(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias,
+                                       float* Y, int64_t M, int N, int K, int flags, double* col_sums, void* ws,
+                                       size_t ws_bytes, const mmg_bn_fin_t* fin, void* stream) {
+  MMG_CHECK_ARG(col_sums && fin && fin->count > 0 && fin->scale && fin->shift, "linear_fwd_stats_bn: col_sums and a fold descriptor are required");
+  return linear_fwd_stats_impl(X, pro, W, bias, Y, M, N, K, flags, col_sums, ws, ws_bytes, stream, fin);
 }
 
 extern "C" int mmg_linear_fwd_l2norm_supported(int64_t M, int N, int K) {

@@ -479,10 +479,25 @@ class _Run:
         return out
 
     # ======================================================================== encode_nodes
+    def bn_spec(self, mod: nn.BatchNorm1d, n_updates: int, rows: int, sharded: bool):
+        """(gamma, beta, running_mean, running_var, n_updates) for a producer that folds the training-mode BatchNorm of its
+        output in the launch that sums its statistics -- or None where that is not possible (eval mode; a patient-sharded
+        tensor, whose sums are all-reduced first; a single row, which raises like torch)."""
+        if not self.T or rows <= 1 or (sharded and self.comm is not None):
+            return None
+        return (mod.weight.detach(), mod.bias.detach(), mod.running_mean, mod.running_var, int(n_updates))
+
+    def count_bn(self, mod: nn.BatchNorm1d, n_updates: int):
+        ent = self._nbt.setdefault(id(mod), [mod.num_batches_tracked, 0])           # bumped once, together
+        ent[1] += int(n_updates)
+
     def bn_fold(self, y, mod: nn.BatchNorm1d, n_updates=1, sharded=False, sums=None, reduced=False) -> ops.BNFold:
         """Batch statistics (train) or running statistics (eval) folded to scale/shift.  sums: the column sums of
         y and y^2 when the producing kernel already took them (reduced: already summed over the shards)."""
         count = y.shape[0]
+        if isinstance(sums, ops.BNFold):         # the producer already folded it (bn_spec)
+            self.count_bn(mod, n_updates)
+            return sums
         if self.T:
             if sums is None:
                 sums = ops.col_reduce2(y)
@@ -507,18 +522,27 @@ class _Run:
         pt = self.m.patient_transform
         E = self.W(f"embeddings.{ROW_TYPE}.weight")
         # the batch statistics of z1 / z2 come out of the GEMM epilogue (training mode)
-        z1, s1 = ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach(), with_stats=True) if self.T else \
-            (ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach()), None)
+        spec = self.bn_spec(pt[1], n_updates, E.shape[0], True)
+        if spec is not None:                     # ... and so does the BatchNorm fold (single GPU)
+            z1, _, s1 = ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach(), bn=spec)
+        else:
+            z1, s1 = ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach(), with_stats=True) if self.T else \
+                (ops.linear_fwd(E, pt[0].weight.detach(), pt[0].bias.detach()), None)
         f1 = self.bn_fold(z1, pt[1], n_updates, sharded=True, sums=s1)
         return E, z1, f1
 
-    def enc_mid(self, call, first):
-        """Second linear of pass `call` with the BatchNorm statistics of its output (not yet summed over the shards)."""
+    def enc_mid(self, call, first, n_updates=1):
+        """Second linear of pass `call` with the BatchNorm statistics of its output (not yet summed over the shards; on a
+        single GPU already folded: a BNFold instead of the sums)."""
         pt = self.m.patient_transform
         E, z1, f1 = first
         pro1 = Pro(f1.scale, f1.shift, True, self.p, self.seed, 2 * call, self.plan.row_offset, self.seed_dev)
-        z2, s2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1, with_stats=True) if self.T else \
-            (ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1), None)
+        spec = self.bn_spec(pt[5], n_updates, z1.shape[0], True)
+        if spec is not None:
+            z2, _, s2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1, bn=spec)
+        else:
+            z2, s2 = ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1, with_stats=True) if self.T else \
+                (ops.linear_fwd(z1, pt[4].weight.detach(), pt[4].bias.detach(), pro=pro1), None)
         return [pro1, z2, s2, False]
 
     def enc_fwd(self, call, n_updates, first=None, rows=None, mid=None):
@@ -530,7 +554,7 @@ class _Run:
         if first is None:
             first = self.enc_first(n_updates)
         E, z1, f1 = first
-        pro1, z2, s2, reduced = mid if mid is not None else self.enc_mid(call, first)
+        pro1, z2, s2, reduced = mid if mid is not None else self.enc_mid(call, first, n_updates)
         f2 = self.bn_fold(z2, pt[5], n_updates, sharded=True, sums=s2, reduced=reduced)
         pro2 = Pro(f2.scale, f2.shift, True, self.p, self.seed, 2 * call + 1, off, self.seed_dev)
         if rows is not None:
@@ -848,7 +872,10 @@ class _Run:
             rels = [ops.Rel(r.rowptr, r.col, r.n_cols, rowscale=r.inv_row, table=Tv, simple=r.simple, mask_r=r.mask_r)
                     for r, Tv in zip(rin, tables)]
             ysums = None
-            if self.T and self.m.use_batch_norm and P > 0:       # BatchNorm statistics of y_P from the gather epilogue
+            spec = self.bn_spec(self.m.batch_norms[l][ROW_TYPE], 1, P, True) if self.m.use_batch_norm else None
+            if spec is not None:                     # BatchNorm statistics AND fold of y_P from the gather's launches
+                _, _, ysums = ops.gather_rows(rels, P, D, yP, accumulate=True, bn=spec)
+            elif self.T and self.m.use_batch_norm and P > 0:       # BatchNorm statistics of y_P from the gather epilogue
                 _, ysums = ops.gather_rows(rels, P, D, yP, accumulate=True, with_stats=True)
             else:
                 ops.gather_rows(rels, P, D, yP, accumulate=True)

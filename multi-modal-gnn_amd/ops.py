@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (HeadGradT, HeadT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, WgradReduceT,
+from ._lib import (BnFinT, HeadGradT, HeadT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, WgradReduceT,
                    check)
 
 BN_MOMENTUM = 0.1
@@ -244,8 +244,21 @@ def rel_mask_build(rowptr: torch.Tensor, col: torch.Tensor, n_cols: int):
     return mask_t, mask_r
 
 
-def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, accumulate: bool, with_stats: bool = False):
-    """with_stats: also return fp64 [2,D] = (column sums, column sums of squares) of the final `out`."""
+def _bn_fin(count: int, N: int, device, bn):
+    """bn = (gamma, beta, running_mean, running_var, n_updates) -> (mmg_bn_fin_t, the BNFold its launch fills)."""
+    gamma, beta, rm, rv, n_updates = bn
+    st = torch.empty(4, N, dtype=torch.float32, device=device)
+    fin = BnFinT(int(count), _p(gamma).value, _p(beta).value, _p(rm).value if rm is not None else None,
+                 _p(rv).value if rv is not None else None, int(n_updates), BN_MOMENTUM, BN_EPS,
+                 _p(st[0]).value, _p(st[1]).value, _p(st[2]).value, _p(st[3]).value)
+    return fin, BNFold(st[0], st[1], st[2], st[3], int(count), True)
+
+
+def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, accumulate: bool, with_stats: bool = False,
+                bn=None):
+    """with_stats: also return fp64 [2,D] = (column sums, column sums of squares) of the final `out`.
+    bn = (gamma, beta, running_mean, running_var, n_updates): also fold the training-mode BatchNorm of `out` in the launch
+    that sums the statistics (mmg_gather_rows_stats_bn) -> (out, sums, BNFold)."""
     lib = _lib.load()
     if tuple(out.shape) != (n_rows, D):
         raise ValueError("gather_rows: out shape")
@@ -254,7 +267,14 @@ def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, acc
             raise ValueError("gather_rows: rowptr length")
     arr = _rels(rels, D, need_table=True)
     _tok = _pb("gather_rows")
-    if with_stats:
+    fold = None
+    if bn is not None:
+        sums = torch.empty(2, D, dtype=torch.float64, device=out.device)
+        ws = workspace(lib.mmg_gather_rows_stats_ws_bytes(n_rows, D), out.device)
+        fin, fold = _bn_fin(n_rows, D, out.device, bn)
+        check(lib.mmg_gather_rows_stats_bn(arr, len(rels), n_rows, D, _p(out), int(accumulate), _p(sums, torch.float64),
+                                           _p(ws, torch.uint8), ws.numel(), C.byref(fin), _stream()), "mmg_gather_rows_stats_bn")
+    elif with_stats:
         sums = torch.empty(2, D, dtype=torch.float64, device=out.device)
         ws = workspace(lib.mmg_gather_rows_stats_ws_bytes(n_rows, D), out.device)
         check(lib.mmg_gather_rows_stats(arr, len(rels), n_rows, D, _p(out), int(accumulate), _p(sums, torch.float64),
@@ -262,6 +282,8 @@ def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, acc
     else:
         check(lib.mmg_gather_rows(arr, len(rels), n_rows, D, _p(out), int(accumulate), _stream()), "mmg_gather_rows")
     _pe(_tok, "gather_rows", _agg_bytes(rels, n_rows, D, accumulate), 0)
+    if bn is not None:
+        return out, sums, fold
     return (out, sums) if with_stats else out
 
 
@@ -285,9 +307,11 @@ def scatter_rows(rels: Sequence[Rel], n_rows: int, D: int, x: torch.Tensor):
 # ------------------------------------------------------------------------------------------ dense
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, pro: Optional[Pro] = None,
                out: Optional[torch.Tensor] = None, accumulate: bool = False, w_kn: bool = False,
-               with_stats: bool = False):
+               with_stats: bool = False, bn=None):
     """out[M,N] (+)= pro(x)[M,K] @ W[N,K]^T + bias;  w_kn: W is stored [K,N] (out = x @ W), read in place.
-    with_stats: also return fp64 [2,N] = (column sums, column sums of squares) of out, from the GEMM epilogue."""
+    with_stats: also return fp64 [2,N] = (column sums, column sums of squares) of out, from the GEMM epilogue.
+    bn = (gamma, beta, running_mean, running_var, n_updates): also fold the training-mode BatchNorm of `out` in the launch
+    that sums the statistics (mmg_linear_fwd_stats_bn) -> (out, sums, BNFold)."""
     lib = _lib.load()
     M, K = x.shape
     N = W.shape[1] if w_kn else W.shape[0]
@@ -301,7 +325,15 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
         raise ValueError("linear_fwd: out shape")
     _tok = _pb("linear_fwd")
     flags = int(accumulate) | (2 if w_kn else 0)
-    if with_stats:
+    fold = None
+    if bn is not None:
+        sums = torch.empty(2, N, dtype=torch.float64, device=x.device)
+        ws = workspace(lib.mmg_linear_fwd_stats_ws_bytes(M, N), x.device)
+        fin, fold = _bn_fin(M, N, x.device, bn)
+        check(lib.mmg_linear_fwd_stats_bn(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"),
+                                          _p(out, name="out"), M, N, K, flags, _p(sums, torch.float64), _p(ws, torch.uint8),
+                                          ws.numel(), C.byref(fin), _stream()), "mmg_linear_fwd_stats_bn")
+    elif with_stats:
         sums = torch.empty(2, N, dtype=torch.float64, device=x.device)
         ws = workspace(lib.mmg_linear_fwd_stats_ws_bytes(M, N), x.device)
         check(lib.mmg_linear_fwd_stats(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"),
@@ -311,6 +343,8 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
         check(lib.mmg_linear_fwd(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"), _p(out, name="out"),
                                  M, N, K, flags, _stream()), "mmg_linear_fwd")
     _pe(_tok, "linear_fwd", 4 * (M * K + N * K + M * N * (2 if accumulate else 1)), 2 * M * N * K)
+    if bn is not None:
+        return out, sums, fold
     return (out, sums) if with_stats else out
 
 

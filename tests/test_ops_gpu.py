@@ -832,3 +832,24 @@ def test_deferred_weight_gradient_sums(ops, dev):
     ops.wgrad_reduce_flush(jobs)
     assert not jobs
     assert torch.equal(g1, ref1) and torch.equal(gb1, refb1) and torch.equal(g2, ref2)
+
+
+@pytest.mark.parametrize("M", [5003, 300])
+def test_batchnorm_fold_in_the_statistics_launch(ops, dev, M):
+    """linear_fwd(bn=...) == linear_fwd(with_stats) + bn_finalize, bit for bit (fold, running statistics, sums), on the
+    epilogue-statistics path (M > 512) and on the separate-reduction path (small M)."""
+    gen = torch.Generator().manual_seed(31 + M)
+    K = N = 128
+    x = torch.randn(M, K, generator=gen).to(dev)
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=gen).to(dev)
+    gamma, beta = (torch.rand(N, generator=gen) + 0.5).to(dev), torch.randn(N, generator=gen).to(dev)
+    rm0, rv0 = torch.randn(N, generator=gen).to(dev), (torch.rand(N, generator=gen) + 0.5).to(dev)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    y0, s0 = ops.linear_fwd(x, W, b, with_stats=True)
+    f0 = ops.bn_finalize(s0, M, gamma, beta, rm0, rv0, True, 2)
+    y1, s1, f1 = ops.linear_fwd(x, W, b, bn=(gamma, beta, rm1, rv1, 2))
+    assert torch.equal(y0, y1) and torch.equal(s0, s1)
+    for a, c in ((f0.scale, f1.scale), (f0.shift, f1.shift), (f0.mean, f1.mean), (f0.rstd, f1.rstd), (rm0, rm1), (rv0, rv1)):
+        assert torch.equal(a, c)
+    assert f1.count == M and f1.training
