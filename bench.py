@@ -58,8 +58,8 @@ FOLLOWERS = {"scatter_reduce": "scatter_rows", "linear_wgrad_reduce": "linear_wg
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--scale", type=int, default=100, help="eICU-shape multiples per GPU (weak) or in total (--strong)")
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--dropout", type=float, default=0.2)
