@@ -365,6 +365,26 @@ def measure(args, world, rank, dev, scale, strong, steps, warmup, want_kernels):
     dt = time.perf_counter() - t0
     loss_value = float(loss.detach())
 
+    # ---- the same K steps with a NEW supervision mask before every step (train.py:150-176 redraws the 20 % subset every
+    # epoch, and an epoch of the full-batch reference is one step): set_mask uploads nothing (the masks are resident) but
+    # re-derives 1 / n_sup and the backward's pair lists, which the captured step does not contain.  Reported beside the
+    # headline, never as it.
+    dt_newmask = None
+    if gstep is not None and world == 1 and hasattr(gstep, "set_mask"):
+        gen = torch.Generator(device=dev).manual_seed(77)
+        masks = [torch.rand(w["pi"].numel(), generator=gen, device=dev) < 0.2 for _ in range(4)]
+        counts = [float(m.sum()) for m in masks]
+        gstep.set_mask(masks[0], counts[0])
+        gstep.step()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            gstep.set_mask(masks[i % 4], counts[i % 4])
+            gstep.step()
+        barrier()
+        dt_newmask = time.perf_counter() - t1
+        gstep.set_mask(w["sup"], w["n_sup"])
+
     # ---- per-kernel durations: eager steps of the same kernels, every big launch with its own HIP event pair.  Each
     # step is queued behind a ~10 ms spin on the device, so that the host (~25 us of Python per launch) runs ahead and the
     # kernels execute back to back, as they do inside the graph.
@@ -397,6 +417,7 @@ def measure(args, world, rank, dev, scale, strong, steps, warmup, want_kernels):
               f"{sum(1 for k, _ in gstep.items if k == 'graph')} hipGraph segments + "
               f"{sum(1 for k, _ in gstep.items if k == 'all_reduce')} all-reduces per step")
     rec = dict(dt=float(tmax), edges=float(edges), loss=loss_value, rows=rows, n_probe=n_probe, launch=launch,
+               dt_newmask=dt_newmask,
                P_loc=int(w["plan"].n_rows), pairs=int(w["pi"].numel()), extra=agg_extra(w, args.dim))
     del w, gstep, step_fn
     gc.collect()
@@ -433,6 +454,12 @@ def main():
                        "launch": head["launch"]},
             "loss": head["loss"],
         }
+        if head.get("dt_newmask") is not None:
+            out["new_supervision_mask_every_step"] = {
+                "ms_per_step": 1e3 * head["dt_newmask"] / args.steps,
+                "note": "the same replays with set_mask(a resident random 20 % mask) before every step: the reference redraws "
+                        "the supervision subset every epoch = every full-batch step (train.py:150-176); the normaliser and "
+                        "the backward's pair lists are re-derived outside the captured step"}
         if head["rows"]:
             table = kernel_table(head["rows"], head["n_probe"], head["extra"])
             traffic, tsrc = load_traffic(args, args.scale, args.strong)

@@ -683,15 +683,19 @@ class Head:
         return HeadT(_p(self.A), _p(self.B), _p(self.W2), _p(self.b2), _p(self.W3), _p(self.b3))
 
 
-def pair_select(pi, deg, thr: int, dpred=None, io_perm=None, dpred_sorted=None):
+def pair_select(pi, deg, thr: int, dpred=None, io_perm=None, dpred_sorted=None, out=None):
     """Stable compaction of pair positions by head (mmg_pair_select) -> (sel_low, sel_high, counts[2] on device).
     With `dpred`, positions whose upstream gradient is exactly 0 are dropped (dpred is read through io_perm; if
-    `dpred_sorted` ([n] float) is given it receives dpred in pair order)."""
+    `dpred_sorted` ([n] float) is given it receives dpred in pair order).  out: the three tensors of an earlier call, to
+    be overwritten in place (a captured step holds their addresses)."""
     lib = _lib.load()
     n = pi.numel()
-    sel_low = torch.empty(max(n, 1), dtype=torch.int32, device=pi.device)
-    sel_high = torch.empty(max(n, 1), dtype=torch.int32, device=pi.device)
-    counts = torch.empty(2, dtype=torch.int32, device=pi.device)
+    if out is not None:
+        sel_low, sel_high, counts = out
+    else:
+        sel_low = torch.empty(max(n, 1), dtype=torch.int32, device=pi.device)
+        sel_high = torch.empty(max(n, 1), dtype=torch.int32, device=pi.device)
+        counts = torch.empty(2, dtype=torch.int32, device=pi.device)
     ws = workspace(lib.mmg_pair_select_ws_bytes(n), pi.device)
     _tok = _pb("pair_select")
     check(lib.mmg_pair_select(_p(pi, torch.int32), _p(deg, torch.int32), thr, _p(dpred), _p(io_perm, torch.int64),

@@ -297,7 +297,7 @@ class _SupervisionState:
         torch.reciprocal(n.clamp_(min=1.0), out=self.inv_den)
 
     def set_mask(self, sup_mask, n_sup_global=None):
-        self.sup.copy_(sup_mask.to(torch.float32))
+        self.sup.copy_(sup_mask)                 # (bool -> float inside the copy)
         self._set_den(n_sup_global)
 
 
@@ -475,12 +475,8 @@ class PiecewiseGraphedTrainStep:
         pairs = model._pairs(self.pi, self.li, self.plan.n_rows,
                              getattr(self.comm, "pair_ids", None) if self.comm else None,
                              self.plan.lab_deg, int(model.degree_threshold))
-        new = ops.pair_select(pairs[0], self.plan.lab_deg, int(model.degree_threshold), self.sup, io_perm=pairs[2])
-        if self._sel is None:
-            self._sel = new
-        else:
-            for old_t, new_t in zip(self._sel, new):
-                old_t.copy_(new_t)
+        self._sel = ops.pair_select(pairs[0], self.plan.lab_deg, int(model.degree_threshold), self.sup, io_perm=pairs[2],
+                                    out=self._sel)
 
     def set_mask(self, sup_mask, n_sup_global=None):
         """New supervision subset; 1 / n_sup (summed over the shards) and the backward's pair lists follow it on the device."""
