@@ -147,3 +147,47 @@ def test_edge_masker_splits_match_the_reference(E):
         EdgeMasker(g, 0.7, 0.2, 0.2)
     m.to(g, "cpu")
     assert m._cache == {} and m.edge_index is g["patient", "has_lab", "lab"].edge_index
+
+
+def test_strided_job_views_of_vec_sums():
+    """Host side of mmg_vec_sums' 2-D jobs: a contiguous tensor is a flat vector, a column slice of a wider matrix is
+    (columns, row stride), anything else is refused (no silent copy)."""
+    import mmgnn  # noqa: F401
+    from mmgnn import ops
+    w = torch.zeros(6, 10)
+    assert ops._rows_view(w) == (0, 0) and ops._rows_view(w[2]) == (0, 0)
+    assert ops._rows_view(w[:, :4]) == (4, 10) and ops._rows_view(w[:, 4:]) == (6, 10)
+    with pytest.raises(ValueError):
+        ops._rows_view(w.t())
+    with pytest.raises(ValueError):
+        ops._rows_view(w[:, ::2])
+
+
+def test_deferred_weight_gradient_jobs_keep_their_order(monkeypatch):
+    """wgrad_reduce_flush: jobs of different gradients share a launch; a second contribution to a gradient that an earlier
+    job of the list writes waits for a later launch (and so does everything behind it for that gradient); jobs without
+    slabs (small direct launches) are dropped; at most 16 jobs per launch."""
+    import mmgnn  # noqa: F401
+    from mmgnn import _lib, ops
+    from mmgnn._lib import WgradReduceT
+    calls = []
+
+    class FakeLib:
+        def mmg_wgrad_reduce_group(self, arr, n, stream):
+            calls.append([(arr[i].dW, arr[i].accumulate) for i in range(n)])
+            return 0
+
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib())
+    monkeypatch.setattr(ops, "_stream", lambda: None)
+
+    def job(dW, acc, slab=1):
+        return (WgradReduceT(slab, 4, 2, dW, None, 4, acc), None, None, None)
+
+    jobs = [job(100, 0), job(200, 0), job(100, 1), job(300, 0, slab=None), job(100, 1), job(400, 0)]
+    ops.wgrad_reduce_flush(jobs)
+    assert jobs == []
+    assert calls == [[(100, 0), (200, 0), (400, 0)], [(100, 1)], [(100, 1)]]
+    calls.clear()
+    many = [job(1000 + i, 0) for i in range(20)]
+    ops.wgrad_reduce_flush(many)
+    assert [len(c) for c in calls] == [16, 4]
