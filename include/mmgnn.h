@@ -320,7 +320,8 @@ int mmg_l2norm_bwd(const float* G, const float* out, const float* rnorm, float* 
  * (src/train.py:366-386 of the reference: mean(|p - y| * w[lab]) over the supervision subset):
  *   loss = inv_den * sum_k sup[k] * w[k] * (|p_k - y_k|  or  (p_k - y_k)^2)        (fp64 accumulation)
  *   dpred[k] = inv_den * sup[k] * w[k] * (sign(p_k - y_k)  or  2 (p_k - y_k))
- * sup / w may be NULL (= 1).  loss_type 0 = mae, 1 = mse.  `loss` is ONE double on the device.
+ * sup / w may be NULL (= 1).  loss_type 0 = mae, 1 = mse, 2 = huber with delta 1 (compute_regression_loss,
+ * src/model.py:579-612: 0.5 d^2 for |d| <= 1, |d| - 0.5 beyond).  `loss` is ONE double on the device.
  * inv_den_ptr (nullable, DEVICE): when non-NULL the normaliser is read from it at run time instead of `inv_den` -- the
  * reference divides by the size of the per-epoch supervision subset (.mean() over pred[mask], train.py:366-386), which
  * changes every epoch while a captured hipGraph keeps its launch arguments. */
@@ -328,6 +329,16 @@ size_t mmg_pair_loss_ws_bytes(int64_t n);
 int mmg_pair_loss(const float* pred, const float* y, const float* w, const float* sup, int64_t n, double inv_den,
                   const double* inv_den_ptr, int loss_type, float* dpred, double* loss, void* ws, size_t ws_bytes,
                   void* stream);
+
+/* The per-epoch supervision subset (src/train.py:150-176: supervision_mask = torch.rand(n) < mask_fraction, redrawn every
+ * epoch from a wall-clock seed) drawn on the device: sup[k] = 1.0f with probability `fraction` (quantised to 1/65536),
+ * else 0.0f, from the counter RNG keyed on (seed, a site of its own, ids[k] or k) -- partition-invariant when ids holds
+ * global pair ids.  seed_ptr (nullable, DEVICE) overrides `seed` at run time (the dropout seed stream a captured step
+ * advances).  count / inv_den (nullable, DEVICE doubles) receive the subset size and 1 / max(size, 1) -- the normaliser
+ * mmg_pair_loss reads through inv_den_ptr. */
+size_t mmg_sup_mask_ws_bytes(int64_t n);
+int mmg_sup_mask_draw(const uint64_t* seed_ptr, uint64_t seed, const int64_t* ids, int64_t n, float fraction, float* sup,
+                      double* count, double* inv_den, void* ws, size_t ws_bytes, void* stream);
 
 /* keep-mask of the dropout RNG, for injected-mask parity tests: mask[i] in {0,1}     */
 int mmg_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_t site, int64_t first_elem, int64_t n_elems,
@@ -373,8 +384,13 @@ typedef struct {
  * launch.  Forward: the per-head lists (static per pair set) replace the predicated sweep over all pairs.
  * Backward: pairs whose upstream gradient is exactly 0 (the ~80 % of train pairs outside the supervision
  * subset, src/train.py:366-370) contribute exactly 0 to every gradient and are skipped. */
+/* Sizes: n_total = length of pi / li / pair_id / io_perm / pred / dpred; n_patients = rows of A and entries of deg;
+ * n_labs = rows of B; n_pairs <= n_total sizes the launch (the list bound, or n_total without a list).  Every indexed
+ * access inside the kernels is range-checked against these (buffer descriptors): an index outside its array reads 0 /
+ * is not written, it can never become an address.  Limits: n_total < 2^29, n_patients < 2^24, n_labs < 2^24. */
 int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li,
-                      const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
+                      const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total,
+                      int64_t n_patients, int n_labs,
                       float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
                       float* pred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream);
 /* Backward: the weight-side gradients (dW2, db2, dW3, db3, dB) leave every workgroup as ONE partial slab in `ws` and are
@@ -383,7 +399,8 @@ int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* 
 size_t mmg_pair_head_bwd_ws_bytes(int64_t n_pairs, int n_labs);
 int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,
                       const int32_t* pi, const int32_t* li, const int32_t* deg, int degree_threshold,
-                      int want_low, int64_t n_pairs, int n_labs, float drop_p, uint64_t seed,
+                      int want_low, int64_t n_pairs, int64_t n_total, int64_t n_patients, int n_labs, float drop_p,
+                      uint64_t seed,
                       const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred,
                       const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
                       void* ws, size_t ws_bytes, void* stream);
@@ -479,6 +496,12 @@ int mmg_small_bn_bwd_group(const mmg_small_bn_bwd_t* probs, int n_probs, int N, 
 int mmg_adam_step(float* p, float* m, float* v, const float* const* grads, const int32_t* offsets, int n_tensors,
                   float lr, float beta1, float beta2, float eps, float weight_decay, float* step, uint32_t* ticket,
                   void* stream);
+/* The same step with its hyper-parameters read from DEVICE memory at run time: hyper[5] = (lr, beta1, beta2, eps,
+ * weight_decay).  A captured hipGraph keeps its launch arguments, so a learning-rate scheduler (src/train.py:271-291:
+ * ReduceLROnPlateau / StepLR acting on optimizer.param_groups) would be silently ignored by mmg_adam_step under replay;
+ * the caller refreshes `hyper` between replays instead. */
+int mmg_adam_step_dev(float* p, float* m, float* v, const float* const* grads, const int32_t* offsets, int n_tensors,
+                      const float* hyper, float* step, uint32_t* ticket, void* stream);
 typedef struct {
   float* dst;
   const float* src[4];

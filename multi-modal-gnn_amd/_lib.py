@@ -140,17 +140,20 @@ SIGNATURES = {
     "mmg_l2norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "mmg_pair_loss_ws_bytes": (_sz, [_i64]),
     "mmg_pair_loss": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_double, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "mmg_sup_mask_ws_bytes": (_sz, [_i64]),
+    "mmg_sup_mask_draw": (C.c_int, [_vp, _u64, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmg_dropout_mask": (C.c_int, [_u64, _vp, _u32, _i64, _i64, _f32, _vp, _vp]),
-    "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64, _vp, _vp, _vp, _vp,
-                                    _vp, _vp, _vp]),
+    "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _f32, _u64, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp]),
     "mmg_pair_head_bwd_ws_bytes": (_sz, [_i64, _i32]),
-    "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _u64,
-                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _f32,
+                                    _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmg_small_fwd_group": (C.c_int, [_P(SmallFwdT), _i32, _i32, _i32, _vp]),
     "mmg_small_wgrad_group": (C.c_int, [_P(SmallWgradT), _i32, _i32, _i32, _vp]),
     "mmg_small_bn_act_group": (C.c_int, [_P(SmallBnT), _i32, _i32, _f32, _f32, _vp]),
     "mmg_small_bn_bwd_group": (C.c_int, [_P(SmallBnBwdT), _i32, _i32, _vp]),
     "mmg_adam_step": (C.c_int, [_vp, _vp, _vp, _P(C.c_void_p), _P(C.c_int32), _i32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp]),
+    "mmg_adam_step_dev": (C.c_int, [_vp, _vp, _vp, _P(C.c_void_p), _P(C.c_int32), _i32, _vp, _vp, _vp, _vp]),
     "mmg_vec_sums": (C.c_int, [_P(SumJobT), _i32, _vp]),
     "mmg_counters_add": (C.c_int, [_P(C.c_void_p), _P(C.c_int64), _i32, _vp]),
     "mmg_seed_advance": (C.c_int, [_vp, _vp]),

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/mmgnn.h"
 
 #define WAVE 64
@@ -38,12 +39,19 @@ void mmg_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
-// Dynamic-LDS limit of a kernel, raised ONCE per process (a function-local static: thread-safe, immutable afterwards).
+// Dynamic-LDS limit of a kernel, raised once per (kernel, DEVICE): the attribute belongs to the device's code object, so
+// a process that drives a second GPU has to raise it there too.  Only successes are remembered (a transient failure is
+// retried by the next launch).
 template <auto Kernel, int Bytes>
 struct MmgMaxLds {
   static hipError_t set() {
-    static const hipError_t rc =
-        hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Bytes);
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) return rc;
+    if (dev >= 0 && dev < 64 && ((done.load(std::memory_order_relaxed) >> dev) & 1ull)) return hipSuccess;
+    rc = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Bytes);
+    if (rc == hipSuccess && dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_relaxed);
     return rc;
   }
 };

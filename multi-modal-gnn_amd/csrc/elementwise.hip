@@ -449,7 +449,11 @@ __global__ __launch_bounds__(256) void k_pair_loss(const float* __restrict__ pre
     const float ws = (w ? w[k] : 1.f) * (sup ? sup[k] : 1.f);
     float per, g;
     if (loss_type == 0) { per = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
-    else { per = d * d; g = 2.f * d; }
+    else if (loss_type == 1) { per = d * d; g = 2.f * d; }
+    else {                                           // huber, delta = 1 (F.huber_loss default)
+      const float a = fabsf(d);
+      if (a <= 1.f) { per = 0.5f * d * d; g = d; } else { per = a - 0.5f; g = d > 0.f ? 1.f : -1.f; }
+    }
     s += (double)(per * ws);
     if (dpred) dpred[k] = g * ws * invf;
   }
@@ -457,6 +461,37 @@ __global__ __launch_bounds__(256) void k_pair_loss(const float* __restrict__ pre
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * inv_den;
+}
+
+// Supervision subset of one epoch (src/train.py:150-176: torch.rand(n) < mask_fraction, redrawn every epoch): drawn on
+// the device from the counter RNG, keyed on (the seed the captured step reads, a site of its own, the pair's id).
+constexpr uint32_t SUP_SITE = 0x53555031u;
+__global__ __launch_bounds__(256) void k_sup_mask_draw(const uint64_t* __restrict__ seed_ptr, uint64_t seed,
+                                                       const int64_t* __restrict__ ids, int64_t n, float keep_p,
+                                                       float* __restrict__ sup, double* __restrict__ partial) {
+  __shared__ double red[4];
+  if (seed_ptr) seed = *seed_ptr;
+  double s = 0;
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+    const uint64_t e = ids ? (uint64_t)ids[k] : (uint64_t)k;
+    const float m = mmg_keep(seed, SUP_SITE, e, keep_p) ? 1.f : 0.f;
+    sup[k] = m;
+    s += (double)m;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void k_sup_mask_count(const double* __restrict__ partial, int nblk, double* __restrict__ count,
+                                                       double* __restrict__ inv_den) {
+  double s = 0;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += partial[b];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) {
+    if (count) *count = s;
+    if (inv_den) *inv_den = 1.0 / (s > 1.0 ? s : 1.0);
+  }
 }
 
 inline unsigned ew_grid(int64_t n4) {
@@ -689,13 +724,32 @@ extern "C" int mmg_dropout_mask(uint64_t seed, const uint64_t* seed_ptr, uint32_
   return MMG_OK;
 }
 
+extern "C" size_t mmg_sup_mask_ws_bytes(int64_t n) { return n < 0 ? 0 : (size_t)PL_BLOCKS * 8 + 256; }
+
+extern "C" int mmg_sup_mask_draw(const uint64_t* seed_ptr, uint64_t seed, const int64_t* ids, int64_t n, float fraction,
+                                 float* sup, double* count, double* inv_den, void* ws, size_t ws_bytes, void* stream) {
+  MMG_CHECK_ARG(n >= 0 && ws && (n == 0 || sup), "sup_mask_draw: bad args");
+  MMG_CHECK_ARG(fraction >= 0.f && fraction <= 1.f, "sup_mask_draw: fraction outside [0, 1]");
+  if (ws_bytes < mmg_sup_mask_ws_bytes(n)) { mmg_set_error("sup_mask_draw: workspace too small"); return MMG_E_WS; }
+  hipStream_t st = (hipStream_t)stream;
+  double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  int64_t nb = (n + 255) / 256;
+  if (nb > PL_BLOCKS) nb = PL_BLOCKS;
+  if (nb < 1) nb = 1;
+  // mmg_keep keeps with probability 1 - p: an element is supervised with probability `fraction`
+  hipLaunchKernelGGL(k_sup_mask_draw, dim3((unsigned)nb), dim3(256), 0, st, seed_ptr, seed, ids, n, 1.0f - fraction, sup, partial);
+  hipLaunchKernelGGL(k_sup_mask_count, dim3(1), dim3(64), 0, st, partial, (int)nb, count, inv_den);
+  MMG_CHECK_LAUNCH("sup_mask_draw");
+  return MMG_OK;
+}
+
 extern "C" size_t mmg_pair_loss_ws_bytes(int64_t n) { return n < 0 ? 0 : (size_t)PL_BLOCKS * 8 + 256; }
 
 extern "C" int mmg_pair_loss(const float* pred, const float* y, const float* w, const float* sup, int64_t n, double inv_den,
                              const double* inv_den_ptr, int loss_type, float* dpred, double* loss, void* ws,
                              size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(n >= 0 && loss && ws, "pair_loss: bad args");
-  MMG_CHECK_ARG(loss_type == 0 || loss_type == 1, "pair_loss: loss_type must be 0 (mae) or 1 (mse)");
+  MMG_CHECK_ARG(loss_type >= 0 && loss_type <= 2, "pair_loss: loss_type must be 0 (mae), 1 (mse) or 2 (huber)");
   MMG_CHECK_ARG(n == 0 || (pred && y), "pair_loss: null buffer");
   if (ws_bytes < mmg_pair_loss_ws_bytes(n)) { mmg_set_error("pair_loss: workspace too small"); return MMG_E_WS; }
   hipStream_t st = (hipStream_t)stream;

@@ -20,7 +20,10 @@ struct AdamTable {
 
 __global__ __launch_bounds__(256) void k_adam(AdamTable tb, float* __restrict__ p, float* __restrict__ m,
                                               float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
-                                              float* __restrict__ step, unsigned* __restrict__ ticket, int bump) {
+                                              const float* __restrict__ hyper, float* __restrict__ step,
+                                              unsigned* __restrict__ ticket, int bump) {
+  // device-resident hyper-parameters (a captured step keeps its launch arguments; a scheduler changes lr between replays)
+  if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
   const float t = *step + 1.f;
   const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
   const float step_size = lr / bc1;
@@ -95,9 +98,9 @@ __global__ void k_seed_advance(uint64_t* state) {
 
 }  // namespace
 
-extern "C" int mmg_adam_step(float* p, float* m, float* v, const float* const* grads, const int32_t* offsets, int n_tensors,
-                             float lr, float beta1, float beta2, float eps, float weight_decay, float* step,
-                             uint32_t* ticket, void* stream) {
+static int adam_launch(float* p, float* m, float* v, const float* const* grads, const int32_t* offsets, int n_tensors,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, const float* hyper, float* step,
+                       uint32_t* ticket, void* stream) {
   MMG_CHECK_ARG(p && m && v && grads && offsets && step && ticket, "adam_step: null buffer");
   MMG_CHECK_ARG(n_tensors >= 1, "adam_step: no tensors");
   hipStream_t st = (hipStream_t)stream;
@@ -113,10 +116,23 @@ extern "C" int mmg_adam_step(float* p, float* m, float* v, const float* const* g
     if (nb < 1) nb = 1;
     if (nb > 512) nb = 512;
     const int last = t0 + MMG_ADAM_MAX_TENSORS >= n_tensors;
-    hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, st, tb, p, m, v, lr, beta1, beta2, eps, weight_decay, step, ticket, last);
+    hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, st, tb, p, m, v, lr, beta1, beta2, eps, weight_decay, hyper, step, ticket,
+                       last);
   }
   MMG_CHECK_LAUNCH("adam_step");
   return MMG_OK;
+}
+
+extern "C" int mmg_adam_step(float* p, float* m, float* v, const float* const* grads, const int32_t* offsets, int n_tensors,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, float* step,
+                             uint32_t* ticket, void* stream) {
+  return adam_launch(p, m, v, grads, offsets, n_tensors, lr, beta1, beta2, eps, weight_decay, nullptr, step, ticket, stream);
+}
+
+extern "C" int mmg_adam_step_dev(float* p, float* m, float* v, const float* const* grads, const int32_t* offsets,
+                                 int n_tensors, const float* hyper, float* step, uint32_t* ticket, void* stream) {
+  MMG_CHECK_ARG(hyper, "adam_step_dev: null hyper-parameter buffer");
+  return adam_launch(p, m, v, grads, offsets, n_tensors, 0.f, 0.f, 0.f, 0.f, 0.f, hyper, step, ticket, stream);
 }
 
 extern "C" int mmg_vec_sums(const mmg_sum_job_t* jobs, int n_jobs, void* stream) {
@@ -139,6 +155,8 @@ extern "C" int mmg_vec_sums(const mmg_sum_job_t* jobs, int n_jobs, void* stream)
     }
     for (int q = 0; q < jobs[j].n_src; ++q) MMG_CHECK_ARG(jobs[j].src[q], "vec_sums: job %d has a null source", j);
     if (jobs[j].len > maxlen) maxlen = jobs[j].len;
+    // the jobs of a launch run concurrently: two of them writing one destination would lose a contribution
+    for (int i = 0; i < j; ++i) MMG_CHECK_ARG(jobs[i].dst != jobs[j].dst, "vec_sums: jobs %d and %d share a destination", i, j);
   }
   if (maxlen == 0) return MMG_OK;
   int nb = (maxlen + 256 * 4 - 1) / (256 * 4);

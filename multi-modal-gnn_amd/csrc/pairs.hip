@@ -71,13 +71,13 @@ constexpr size_t BWD_LDS_MAX = 160 * 1024;
 
 __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                  const int32_t* __restrict__ li, const int32_t* __restrict__ deg, int thr,
-                                                 int want_low, int64_t n, int n_labs, int lds_db, float drop_p,
-                                                 uint64_t seed, const uint64_t* __restrict__ seed_ptr,
+                                                 int want_low, int64_t n, int64_t n_total, int n_pat, int n_labs, int lds_db,
+                                                 float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_ptr,
                                                  const int64_t* __restrict__ pair_id,
                                                  const float* __restrict__ dpred, const int32_t* __restrict__ sel,
                                                  const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io) {
   if (seed_ptr) seed = *seed_ptr;
-  if (sel) n = *n_sel;
+  if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }     // never beyond the launch bound
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* W2s = sm + OFF_W2; float* b2s = sm + OFF_B2; float* W3s = sm + OFF_W3;
   float* T1t = sm + OFF_T1; float* T2t = sm + OFF_T2;
@@ -100,8 +100,12 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
     int p_i = -1, l_i = 0;
     if (k < n) {
       if (sel) k = sel[k];
-      const int pp = pi[k];
-      if (((int)(deg[pp] < thr)) == want_low) { p_i = pp; l_i = li[k]; }
+      if (k >= 0 && k < n_total) {                   // (an entry outside the pair arrays is not a pair)
+        const int pp = pi[k], ll = li[k];
+        if ((unsigned)pp < (unsigned)n_pat && (unsigned)ll < (unsigned)n_labs && ((int)(deg[pp] < thr)) == want_low) {
+          p_i = pp; l_i = ll;
+        }
+      }
     }
     const bool active = p_i >= 0;
     // inactive lanes run the same code on row 0 with dout = 0: every contribution is then zero
@@ -205,7 +209,36 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
 // barrier anywhere: waves are independent.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 constexpr int TP = 32;                 // pairs per wave tile
+
+// Every INDEXED access of the two matrix-core pair kernels goes through a buffer descriptor whose base and byte length
+// are KERNEL ARGUMENTS (filled on the host from the array sizes; length 0 = the array is absent).  Two properties follow:
+//   * an index that is stale, past the end of its list, or plain garbage can never become an address -- the load returns
+//     0 and the store is dropped by the range check of the descriptor (round 2 built the io_perm / pair_id descriptors
+//     with num_records = -1, i.e. unbounded: see DESIGN.md section 5, "the 12:45 fault");
+//   * all four descriptor words are scalar (SGPR) values by construction, so the compiler never wraps a load in a
+//     waterfall loop (its `base ? -1 : 0` select on the device was lowered to a per-lane v_cndmask, which made the
+//     descriptor "divergent": 12 readfirstlane loops per tile, each behind a vmcnt(0)).
+struct PairBufs {
+  const void* pid; const void* io;          // pair_id / io_perm (int64 each) or any valid pointer when absent
+  uint32_t pid_bytes, io_bytes;             // n_total * 8, or 0 when absent
+  uint32_t pair_bytes;                      // n_total * 4: pi, li, pred / dpred
+  uint32_t pat_bytes;                       // n_patients * 4: deg
+  uint32_t a_bytes;                         // n_patients * 256: rows of A
+  uint32_t b_bytes;                         // n_labs * 256: rows of B
+  int32_t n_pat;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pair_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ int pair_ld_i32(__amdgpu_buffer_rsrc_t d, unsigned byte_off) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(d, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ f32x4 pair_ld_f4(__amdgpu_buffer_rsrc_t d, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d, (int)byte_off, 0, 0));
+}
 constexpr int LDH = 68;                // H1 / dH1 tile row stride (floats)
 constexpr int LDD = 36;                // D2 tile row stride
 constexpr int WAVE_LDS = TP * LDH + TP * LDD + 4 * TP + 2 * TP;   // floats per wave
@@ -252,12 +285,13 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
                                                        const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                        int thr, int want_low, int64_t n, int n_labs, float drop_p,
                                                        uint64_t seed, const uint64_t* __restrict__ seed_ptr,
-                                                       const int64_t* __restrict__ pair_id,
+                                                       PairBufs pb,
                                                        const float* __restrict__ dpred, const int32_t* __restrict__ sel,
-                                                       const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io,
+                                                       const int32_t* __restrict__ n_sel,
                                                        float* __restrict__ slab) {
   if (seed_ptr) seed = *seed_ptr;
-  if (sel) n = *n_sel;                   // compacted pair list (device-resident length): see mmg_pair_select
+  // compacted pair list (device-resident length, see mmg_pair_select), never beyond the capacity the launch was sized for
+  if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }
   __shared__ __attribute__((aligned(16))) float sm[4 * WAVE_LDS];
   __shared__ __attribute__((aligned(16))) float W2s[32 * LDH];      // W2[u][k], row stride LDH (shared by the 4 waves)
   __shared__ float tail_red[4][68];                                 // per wave: dW3[32] | db2[32] | db3
@@ -291,36 +325,34 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
   // Three-deep software pipeline over this wave's tiles, one dependent load per stage:  t+3: list position -> pair
   // index;  t+2: pair -> patient, lab, rng id, slot of its upstream gradient;  t+1: gate degree, upstream gradient,
   // the A / B row halves.  A stage only ISSUES loads; they are finalised (selects, clamps) one iteration later by the
-  // next stage.  Every load is unconditional -- list positions past the end and nullable arrays go through buffer
-  // descriptors (zero-sized for a null array, unbounded for io / pair_id whose length the kernel does not know),
-  // indices are clamped to element 0 -- because a branch around a load makes the compiler's vmcnt waits conservative.
+  // next stage.  Every load is unconditional and BOUNDED -- lists, index arrays, node tables and the upstream gradient
+  // go through buffer descriptors sized on the host (PairBufs; zero-sized for an absent array) -- because a branch
+  // around a load makes the compiler's vmcnt waits conservative.
   struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
-  typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
-  const __amdgpu_buffer_rsrc_t sel_d = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int32_t*>(sel ? sel : pi), 0, sel ? (int)(n * 4) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t io_d = __builtin_amdgcn_make_buffer_rsrc(
-      io ? (void*)const_cast<int64_t*>(io) : (void*)const_cast<int32_t*>(pi), 0, io ? -1 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t pid_d = __builtin_amdgcn_make_buffer_rsrc(
-      pair_id ? (void*)const_cast<int64_t*>(pair_id) : (void*)const_cast<int32_t*>(pi), 0, pair_id ? -1 : 0, 0x00020000);
-  const bool has_sel = sel != nullptr, has_io = io != nullptr, has_pid = pair_id != nullptr;
+  const __amdgpu_buffer_rsrc_t sel_d = pair_rsrc(sel ? sel : pi, sel ? (uint32_t)(n * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t io_d = pair_rsrc(pb.io, pb.io_bytes), pid_d = pair_rsrc(pb.pid, pb.pid_bytes);
+  const __amdgpu_buffer_rsrc_t pi_d = pair_rsrc(pi, pb.pair_bytes), li_d = pair_rsrc(li, pb.pair_bytes);
+  const __amdgpu_buffer_rsrc_t dp_d = pair_rsrc(dpred, pb.pair_bytes), deg_d = pair_rsrc(deg, pb.pat_bytes);
+  const __amdgpu_buffer_rsrc_t A_d = pair_rsrc(H.A, pb.a_bytes), B_d = pair_rsrc(H.B, pb.b_bytes);
+  const bool has_sel = sel != nullptr, has_io = pb.io_bytes != 0u, has_pid = pb.pid_bytes != 0u;
   struct RawMeta { int k, p, l; pu32x2 o2, d2; };
   auto issue_k = [&](int64_t t) {                    // raw list entry of tile t (0 past the end / without a list)
     const int64_t idx = t * TP + l31;
-    return (int)__builtin_amdgcn_raw_buffer_load_b32(sel_d, (int)(idx < n ? idx : 0) * 4, 0, 0);
+    return pair_ld_i32(sel_d, (unsigned)(idx < n ? idx : 0) * 4u);
   };
   auto fin_k = [&](int kr, int64_t t) {
     const int64_t idx = t * TP + l31;
     return idx < n ? (has_sel ? kr : (int)idx) : -1;
   };
   auto issue_meta = [&](int k) {
-    const int kc = k >= 0 ? k : 0;
+    const unsigned kc = k >= 0 ? (unsigned)k : 0u;
     RawMeta r;
     r.k = k;
-    r.p = pi[kc];
-    r.l = li[kc];
+    r.p = pair_ld_i32(pi_d, kc * 4u);
+    r.l = pair_ld_i32(li_d, kc * 4u);
     if (AUX) {
-      r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, kc * 8, 0, 0);
-      r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, kc * 8, 0, 0);
+      r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, (int)(kc * 8u), 0, 0);
+      r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, (int)(kc * 8u), 0, 0);
     }
     return r;
   };
@@ -328,22 +360,22 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
     const int kc = r.k >= 0 ? r.k : 0;
     Meta m;
     m.k = r.k;
-    m.p_i = r.k >= 0 ? r.p : -1;
+    // a list entry outside the pair arrays, or a row id outside the table, is not a pair (nothing is read or written for it)
+    m.p_i = ((unsigned)r.k < (pb.pair_bytes >> 2) && (unsigned)r.p < (unsigned)pb.n_pat) ? r.p : -1;
     m.l_i = r.l;
     m.o = (AUX && has_io) ? (int)r.o2[0] : kc;
     m.pid = (AUX && has_pid) ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
     return m;
   };
   auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
-    const int pp = m.p_i >= 0 ? m.p_i : 0;
-    *dg = deg[pp];
-    *dv = dpred[m.o];                          // (slot 0 for a position past the end: masked when it is used)
-    const float* ap = H.A + (size_t)pp * 64 + 32 * h;
-    const float* bp = H.B + (size_t)m.l_i * 64 + 32 * h;
+    const unsigned pp = m.p_i >= 0 ? (unsigned)m.p_i : 0u;
+    *dg = pair_ld_i32(deg_d, pp * 4u);
+    *dv = __builtin_bit_cast(float, pair_ld_i32(dp_d, (unsigned)m.o * 4u));   // (masked when the position is past the end)
+    const unsigned ao = pp * 256u + 128u * h, bo = (unsigned)m.l_i * 256u + 128u * h;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      ra[q] = *reinterpret_cast<const f32x4*>(ap + q * 4);
-      rb[q] = *reinterpret_cast<const f32x4*>(bp + q * 4);
+      ra[q] = pair_ld_f4(A_d, ao + q * 16u);
+      rb[q] = pair_ld_f4(B_d, bo + q * 16u);
     }
   };
   const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
@@ -614,12 +646,12 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
                                                           const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                           int thr, int want_low, int64_t n, float drop_p, uint64_t seed,
                                                           const uint64_t* __restrict__ seed_ptr,
-                                                          const int64_t* __restrict__ pair_id, float* __restrict__ pred,
+                                                          PairBufs pb, float* __restrict__ pred,
                                                           const int32_t* __restrict__ sel,
-                                                          const int32_t* __restrict__ n_sel, const int64_t* __restrict__ io,
+                                                          const int32_t* __restrict__ n_sel,
                                                           int n_labs_lds) {
   if (seed_ptr) seed = *seed_ptr;
-  if (sel) n = *n_sel;
+  if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }     // never beyond the list's capacity
   // the lab-side first-layer table B (a few dozen 256-B rows, read once per PAIR) lives in LDS when it fits:
   // 4.3 M pairs x 256 B would otherwise stream from L2
   extern __shared__ __attribute__((aligned(16))) float Bs[];
@@ -658,60 +690,57 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
   // for in the iteration that issues it:   tile t+3: list position -> pair index k   (sel[.])
   //                                        tile t+2: k -> patient, lab, rng id, output slot
   //                                        tile t+1: patient -> gate degree, A row;  lab -> B row
-  // Every load of the pipeline is unconditional: list positions past the end and nullable arrays go through buffer
-  // descriptors (zero-sized for a null array: the load returns 0 and a select substitutes the default; unbounded for
-  // io / pair_id, whose length the kernel does not know: their indices come from the list), indices are clamped to 0.  A branch around a load makes the compiler's vmcnt waits conservative (minimum over both
-  // paths) and the first version of this loop drained the whole pipeline twice per tile.
+  // Every load of the pipeline is unconditional and BOUNDED: lists, index arrays, node tables and the output all go
+  // through buffer descriptors sized on the host (PairBufs; zero-sized for an absent array: the load returns 0 and a
+  // select substitutes the default).  A branch around a load makes the compiler's vmcnt waits conservative (minimum
+  // over both paths) and the first version of this loop drained the whole pipeline twice per tile.
   struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
-  typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
-  const __amdgpu_buffer_rsrc_t sel_d = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<int32_t*>(sel ? sel : pi), 0, sel ? (int)(n * 4) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t io_d = __builtin_amdgcn_make_buffer_rsrc(
-      io ? (void*)const_cast<int64_t*>(io) : (void*)const_cast<int32_t*>(pi), 0, io ? -1 : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t pid_d = __builtin_amdgcn_make_buffer_rsrc(
-      pair_id ? (void*)const_cast<int64_t*>(pair_id) : (void*)const_cast<int32_t*>(pi), 0,
-      pair_id ? -1 : 0, 0x00020000);
-  const bool has_sel = sel != nullptr, has_io = io != nullptr, has_pid = pair_id != nullptr;
+  const __amdgpu_buffer_rsrc_t sel_d = pair_rsrc(sel ? sel : pi, sel ? (uint32_t)(n * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t io_d = pair_rsrc(pb.io, pb.io_bytes), pid_d = pair_rsrc(pb.pid, pb.pid_bytes);
+  const __amdgpu_buffer_rsrc_t pi_d = pair_rsrc(pi, pb.pair_bytes), li_d = pair_rsrc(li, pb.pair_bytes);
+  const __amdgpu_buffer_rsrc_t pred_d = pair_rsrc(pred, pb.pair_bytes), deg_d = pair_rsrc(deg, pb.pat_bytes);
+  const __amdgpu_buffer_rsrc_t A_d = pair_rsrc(H.A, pb.a_bytes), B_d = pair_rsrc(H.B, pb.b_bytes);
+  const bool has_sel = sel != nullptr, has_io = pb.io_bytes != 0u, has_pid = pb.pid_bytes != 0u;
   // A stage only ISSUES loads; what it loaded is finalised (selects, clamps) one iteration later by the next stage, so
   // nothing is waited for in the iteration that issued it.
   struct RawMeta { int k, p, l; pu32x2 o2, d2; };
   auto issue_k = [&](int64_t t) {                    // raw list entry of tile t (0 past the end / without a list)
     const int64_t idx = t * TP + l31;
-    return (int)__builtin_amdgcn_raw_buffer_load_b32(sel_d, (int)(idx < n ? idx : 0) * 4, 0, 0);
+    return pair_ld_i32(sel_d, (unsigned)(idx < n ? idx : 0) * 4u);
   };
   auto fin_k = [&](int kr, int64_t t) {
     const int64_t idx = t * TP + l31;
     return idx < n ? (has_sel ? kr : (int)idx) : -1;
   };
   auto issue_meta = [&](int k) {
-    const int kc = k >= 0 ? k : 0;
+    const unsigned kc = k >= 0 ? (unsigned)k : 0u;
     RawMeta r;
     r.k = k;
-    r.p = pi[kc];
-    r.l = li[kc];
-    r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, kc * 8, 0, 0);
-    r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, kc * 8, 0, 0);
+    r.p = pair_ld_i32(pi_d, kc * 4u);
+    r.l = pair_ld_i32(li_d, kc * 4u);
+    r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, (int)(kc * 8u), 0, 0);
+    r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, (int)(kc * 8u), 0, 0);
     return r;
   };
   auto fin_meta = [&](const RawMeta& r) {
     const int kc = r.k >= 0 ? r.k : 0;
     Meta m;
     m.k = r.k;
-    m.p_i = r.k >= 0 ? r.p : -1;
+    // a list entry outside the pair arrays, or a row id outside the table, is not a pair (nothing is read or written for it)
+    m.p_i = ((unsigned)r.k < (pb.pair_bytes >> 2) && (unsigned)r.p < (unsigned)pb.n_pat) ? r.p : -1;
     m.l_i = r.l;
     m.o = has_io ? (int)r.o2[0] : kc;
     m.pid = has_pid ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
     return m;
   };
   auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg) {
-    const int pp = m.p_i >= 0 ? m.p_i : 0;
-    *dg = deg[pp];
-    const float* ap = H.A + (size_t)pp * 64 + 8 * h;
-    const float* bp = H.B + (size_t)m.l_i * 64 + 8 * h;
+    const unsigned pp = m.p_i >= 0 ? (unsigned)m.p_i : 0u;
+    *dg = pair_ld_i32(deg_d, pp * 4u);
+    const unsigned ao = pp * 256u + 32u * h, bo = (unsigned)m.l_i * 256u + 32u * h;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {              // q = 2 ks + half-chunk: floats 16 ks + 8 h + 4 (q & 1) ..
-      ra[q] = *reinterpret_cast<const f32x4*>(ap + (q >> 1) * 16 + (q & 1) * 4);
-      if (!B_LDS) rb[q] = *reinterpret_cast<const f32x4*>(bp + (q >> 1) * 16 + (q & 1) * 4);
+      ra[q] = pair_ld_f4(A_d, ao + (q >> 1) * 64u + (q & 1) * 16u);
+      if (!B_LDS) rb[q] = pair_ld_f4(B_d, bo + (q >> 1) * 64u + (q & 1) * 16u);
     }
   };
   const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
@@ -737,7 +766,8 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
     m0 = m1;
     if (__ballot(active) == 0ull) continue;
     if (B_LDS) {
-      const float* bl = Bs + mc.l_i * PF_LDB + 8 * h;
+      const int lc = (unsigned)mc.l_i < (unsigned)n_labs_lds ? mc.l_i : 0;       // (a lab id outside the staged table)
+      const float* bl = Bs + lc * PF_LDB + 8 * h;
 #pragma unroll
       for (int q = 0; q < 8; ++q) cb[q] = *reinterpret_cast<const f32x4*>(bl + (q >> 1) * 16 + (q & 1) * 4);
     }
@@ -784,7 +814,8 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
       for (int e = 0; e < 4; ++e) part = fmaf(w3r[4 * i + e], post[e], part);
     }
     part += __shfl_xor(part, 32, 64);
-    if (h == 0 && active) pred[mc.o] = part + b3;
+    if (h == 0 && active)          // (a slot past the end of pred is dropped by the descriptor's range check)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, part + b3), pred_d, (int)((unsigned)mc.o * 4u), 0, 0);
   }
 }
 
@@ -927,10 +958,30 @@ int check_head(const mmg_head_t* h, const char* what) {
 
 }  // namespace
 
+// host side of PairBufs: sizes are checked against the 32-bit byte offsets of the descriptors
+static int fill_pair_bufs(PairBufs* pb, const int32_t* pi, const int64_t* pair_id, const int64_t* io_perm, int64_t n_total,
+                          int64_t n_patients, int n_labs, const char* what) {
+  MMG_CHECK_ARG(n_total >= 1 && n_total < (1ll << 29), "%s: %lld pairs outside [1, 2^29) (32-bit buffer offsets)", what,
+                (long long)n_total);
+  MMG_CHECK_ARG(n_patients >= 1 && n_patients < (1ll << 24), "%s: %lld patient rows outside [1, 2^24)", what,
+                (long long)n_patients);
+  MMG_CHECK_ARG(n_labs >= 1 && n_labs < (1 << 24), "%s: %d lab rows outside [1, 2^24)", what, n_labs);
+  pb->pid = pair_id ? (const void*)pair_id : (const void*)pi;
+  pb->io = io_perm ? (const void*)io_perm : (const void*)pi;
+  pb->pid_bytes = pair_id ? (uint32_t)(n_total * 8) : 0u;
+  pb->io_bytes = io_perm ? (uint32_t)(n_total * 8) : 0u;
+  pb->pair_bytes = (uint32_t)(n_total * 4);
+  pb->pat_bytes = (uint32_t)(n_patients * 4);
+  pb->a_bytes = (uint32_t)(n_patients * 256);
+  pb->b_bytes = (uint32_t)n_labs * 256u;
+  pb->n_pat = (int32_t)n_patients;
+  return MMG_OK;
+}
+
 extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
-                                 int degree_threshold, int want_low, int64_t n_pairs, int n_labs, float drop_p, uint64_t seed,
-                                 const uint64_t* seed_ptr, const int64_t* pair_id, float* pred, const int32_t* sel,
-                                 const int32_t* n_sel, const int64_t* io_perm, void* stream) {
+                                 int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total, int64_t n_patients,
+                                 int n_labs, float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
+                                 float* pred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0, "pair_head_fwd: n_pairs < 0");
   MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_fwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
@@ -938,23 +989,26 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   if (rc) return rc;
   MMG_CHECK_ARG(pi && li && deg && pred, "pair_head_fwd: null buffer");
   MMG_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pair_head_fwd: drop_p out of range");
+  MMG_CHECK_ARG(n_pairs <= n_total, "pair_head_fwd: %lld listed pairs of %lld", (long long)n_pairs, (long long)n_total);
+  PairBufs pb;
+  rc = fill_pair_bufs(&pb, pi, pair_id, io_perm, n_total, n_patients, n_labs, "pair_head_fwd");
+  if (rc) return rc;
   HeadDev H{head->A, head->B, head->W2, head->b2, head->W3, head->b3};
   int64_t g = ((n_pairs + TP - 1) / TP + 3) / 4;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
-  const int n_labs_lds = (n_labs > 0 && n_labs <= 256) ? n_labs : 0;       // 256 rows x 272 B = 68 KB: two workgroups per CU
+  const int n_labs_lds = n_labs <= 256 ? n_labs : 0;       // 256 rows x 272 B = 68 KB: two workgroups per CU
   const size_t lds = (size_t)n_labs_lds * PF_LDB * sizeof(float);
-  MMG_CHECK_ARG(n_pairs < (1ll << 29), "pair_head_fwd: %lld pairs exceed the 32-bit buffer descriptors", (long long)n_pairs);
   if (n_labs_lds) {
     constexpr int lds_max = 256 * PF_LDB * (int)sizeof(float);
     MMG_CHECK_HIP((MmgMaxLds<&k_pair_fwd_mfma<true>, lds_max>::set()), "pair_head_fwd(attr)");
     MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, want_low ? 2 : 0, k_pair_fwd_mfma<true>, dim3((unsigned)g), dim3(256),
                lds, (hipStream_t)stream, H, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed,
-               seed_ptr, pair_id, pred, sel, n_sel, io_perm, n_labs_lds);
+               seed_ptr, pb, pred, sel, n_sel, n_labs_lds);
   } else {
     MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, want_low ? 2 : 0, k_pair_fwd_mfma<false>, dim3((unsigned)g), dim3(256),
                0, (hipStream_t)stream, H, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed,
-               seed_ptr, pair_id, pred, sel, n_sel, io_perm, 0);
+               seed_ptr, pb, pred, sel, n_sel, 0);
   }
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;
@@ -966,10 +1020,10 @@ extern "C" size_t mmg_pair_head_bwd_ws_bytes(int64_t n_pairs, int n_labs) {
 }
 
 extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi, const int32_t* li,
-                                 const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int n_labs,
-                                 float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
-                                 const float* dpred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
-                                 void* ws, size_t ws_bytes, void* stream) {
+                                 const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total,
+                                 int64_t n_patients, int n_labs, float drop_p, uint64_t seed, const uint64_t* seed_ptr,
+                                 const int64_t* pair_id, const float* dpred, const int32_t* sel, const int32_t* n_sel,
+                                 const int64_t* io_perm, void* ws, size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(n_pairs >= 0 && n_labs >= 0, "pair_head_bwd: negative size");
   MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_bwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
@@ -979,21 +1033,24 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
                 "pair_head_bwd: grad has a null pointer");
   MMG_CHECK_ARG(pi && li && deg && dpred, "pair_head_bwd: null buffer");
   MMG_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "pair_head_bwd: drop_p out of range");
+  MMG_CHECK_ARG(n_pairs <= n_total, "pair_head_bwd: %lld listed pairs of %lld", (long long)n_pairs, (long long)n_total);
+  PairBufs pb;
+  rc = fill_pair_bufs(&pb, pi, pair_id, io_perm, n_total, n_patients, n_labs, "pair_head_bwd");
+  if (rc) return rc;
   HeadDev H{head->A, head->B, head->W2, head->b2, head->W3, head->b3};
   HeadGradDev G{grad->dA, grad->dB, grad->dW2, grad->db2, grad->dW3, grad->db3};
   hipStream_t st = (hipStream_t)stream;
   if (n_labs <= 128) {
     // MFMA path: one wave per 32-pair tile, 4 waves per workgroup, persistent grid
     int64_t g = ((n_pairs + TP - 1) / TP + 3) / 4;
-    if (g > 256) g = 256;                // 509 registers: ONE workgroup is resident per CU; fewer workgroups = fewer
-                                         // global atomics in the final flush (512 -> 256: -0.6 % on the step)
+    if (g > 256) g = 256;                // ONE workgroup is resident per CU; fewer workgroups = fewer partial slabs
     if (g < 1) g = 1;
     MMG_CHECK_ARG(ws && ws_bytes >= mmg_pair_head_bwd_ws_bytes(n_pairs, n_labs), "pair_head_bwd: workspace too small");
     float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
 #define MMG_LAUNCH_PBWD(LT_, AUX_)                                                                                    \
   MMG_LAUNCH(MMG_PROBE_PAIR_BWD, n_pairs, 0, 0, want_low ? 2 : 0, (k_pair_bwd_mfma<LT_, AUX_>), dim3((unsigned)g),      \
              dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed,    \
-             seed_ptr, pair_id, dpred, sel, n_sel, io_perm, slab)
+             seed_ptr, pb, dpred, sel, n_sel, slab)
     const bool aux = pair_id != nullptr || io_perm != nullptr;
     if (n_labs <= 64) { if (aux) MMG_LAUNCH_PBWD(2, true); else MMG_LAUNCH_PBWD(2, false); }
     else { if (aux) MMG_LAUNCH_PBWD(4, true); else MMG_LAUNCH_PBWD(4, false); }
@@ -1010,7 +1067,8 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     int64_t g = (n_pairs + PT - 1) / PT;
     if (g > 512) g = 512;
     hipLaunchKernelGGL(k_pair_bwd, dim3((unsigned)g), dim3(PT), lds, st, H, G, pi, li, deg, degree_threshold,
-                       want_low ? 1 : 0, n_pairs, n_labs, lds_db, drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel, io_perm);
+                       want_low ? 1 : 0, n_pairs, n_total, (int)n_patients, n_labs, lds_db, drop_p, seed, seed_ptr, pair_id,
+                       dpred, sel, n_sel, io_perm);
   }
   MMG_CHECK_LAUNCH("pair_head_bwd");
   return MMG_OK;

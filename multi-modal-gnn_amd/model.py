@@ -322,18 +322,27 @@ class _Run:
             self.partial.add(name)
 
     def flush_grad_sums(self):
-        """The deferred slab sums of the weight gradients (one launch), then grads[name] += every later contribution
-        recorded by acc(), all parameters in ONE mmg_vec_sums launch per 8."""
+        """The deferred slab sums of the weight gradients (one launch), then grads[name] = grads[name] + every later
+        contribution recorded by acc(), all parameters in ONE mmg_vec_sums launch per 8.  The sum goes to a NEW tensor:
+        grads[name] may be shared (dWsum serves three lin_r names) or belong to the caller (an autograd grad_output in
+        encode / forward mode).  More than three further contributions chain: each level reads the previous level's
+        result, so levels are separate launches (jobs of one launch run concurrently)."""
         ops.wgrad_reduce_flush(self.wgrad_jobs)
-        jobs = []
+        levels: List[list] = []
         for name, more in self.pending.items():
-            dst = self.grads[name]
-            while more:                               # (4 sources per job: dst itself + 3)
-                jobs.append((dst, [dst] + [m.reshape(dst.shape) for m in more[:3]]))
-                more = more[3:]
+            cur, lvl = self.grads[name], 0
+            more = [m.reshape(cur.shape) for m in more]
+            while more:                               # (4 sources per job: the running sum + 3)
+                dst = torch.empty_like(cur, memory_format=torch.contiguous_format)
+                if len(levels) <= lvl:
+                    levels.append([])
+                levels[lvl].append((dst, [cur] + more[:3]))
+                cur, more, lvl = dst, more[3:], lvl + 1
+            self.grads[name] = cur
         self.pending = {}
-        for j0 in range(0, len(jobs), 8):
-            ops.vec_sums(jobs[j0:j0 + 8])
+        for jobs in levels:
+            for j0 in range(0, len(jobs), 8):
+                ops.vec_sums(jobs[j0:j0 + 8])
 
     def allreduce(self, t):
         if self.comm is not None:

@@ -706,6 +706,17 @@ def pair_select(pi, deg, thr: int, dpred=None, io_perm=None, dpred_sorted=None, 
     return sel_low, sel_high, counts
 
 
+def _pair_sizes(head: Head, pi, li, deg, pair_id, io_perm, per_pair):
+    """The array lengths the kernels range-check against (mmg_pair_head_*: n_total, n_patients, n_labs) must be the real
+    ones: every per-pair array has pi's length."""
+    n = pi.numel()
+    for name, t in (("li", li), ("pair_id", pair_id), ("io_perm", io_perm), ("pred / dpred", per_pair)):
+        if t is not None and t.numel() != n:
+            raise ValueError(f"pair head: {name} has {t.numel()} entries, pi has {n}")
+    if head.A.dim() != 2 or head.A.shape[1] != 64 or head.B.dim() != 2 or head.B.shape[1] != 64:
+        raise ValueError("pair head: A and B must be [rows, 64]")
+
+
 def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred, seed_dev=None,
                   sel=None, n_sel=None, n_bound: Optional[int] = None, io_perm=None):
     """sel / n_sel: compacted positions (pair_select) and their device-resident count; n_bound >= that count.
@@ -715,9 +726,11 @@ def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, s
     if n == 0:
         return
     h = head.c()
+    _pair_sizes(head, pi, li, deg, pair_id, io_perm, pred)
     _tok = _pb("pair_head_fwd")
     check(lib.mmg_pair_head_fwd(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
-                                int(want_low), n, int(head.B.shape[0]), float(p), seed & 0xFFFFFFFFFFFFFFFF,
+                                int(want_low), n, pi.numel(), min(int(head.A.shape[0]), deg.numel()),
+                                int(head.B.shape[0]), float(p), seed & 0xFFFFFFFFFFFFFFFF,
                                 _p(seed_dev, torch.int64),
                                 _p(pair_id, torch.int64), _p(pred), _p(sel, torch.int32), _p(n_sel, torch.int32),
                                 _p(io_perm, torch.int64), _stream()), "mmg_pair_head_fwd")
@@ -734,9 +747,13 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
     h = head.c()
     g = HeadGradT(_p(grads.A), _p(grads.B), _p(grads.W2), _p(grads.b2), _p(grads.W3), _p(grads.b3))
     ws = workspace(lib.mmg_pair_head_bwd_ws_bytes(n, n_labs), head.A.device)
+    _pair_sizes(head, pi, li, deg, pair_id, io_perm, dpred)
+    if tuple(grads.A.shape) != tuple(head.A.shape) or tuple(grads.B.shape) != tuple(head.B.shape):
+        raise ValueError("pair_head_bwd: gradient tables must have the shapes of A and B")
     _tok = _pb("pair_head_bwd")
     check(lib.mmg_pair_head_bwd(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32),
-                                thr, int(want_low), n, n_labs, float(p), seed & 0xFFFFFFFFFFFFFFFF,
+                                thr, int(want_low), n, pi.numel(), min(int(head.A.shape[0]), deg.numel()), n_labs, float(p),
+                                seed & 0xFFFFFFFFFFFFFFFF,
                                 _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _p(sel, torch.int32),
                                 _p(n_sel, torch.int32), _p(io_perm, torch.int64), _p(ws, torch.uint8), ws.numel(), _stream()),
           "mmg_pair_head_bwd")
@@ -744,15 +761,40 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
 
 
 # ------------------------------------------------------------------------------------------ loss
-def pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae", inv_den_dev=None):
+LOSS_TYPES = {"mae": 0, "mse": 1, "huber": 2}
+
+
+def sup_mask_draw(n: int, fraction: float, device, seed: int = 0, seed_dev=None, ids=None, sup=None, count=None,
+                  inv_den=None):
+    """The per-epoch supervision subset drawn on the device (mmg_sup_mask_draw; train.py:150-176 of the reference)
+    -> (sup float [n], count fp64 [1], inv_den fp64 [1] = 1 / max(count, 1)); the three may be passed in (a captured step
+    overwrites them in place).  seed_dev: int64 device tensor whose first element is the seed at run time."""
+    lib = _lib.load()
+    sup = torch.empty(max(n, 1), dtype=torch.float32, device=device)[:n] if sup is None else sup
+    count = torch.empty(1, dtype=torch.float64, device=device) if count is None else count
+    inv_den = torch.empty(1, dtype=torch.float64, device=device) if inv_den is None else inv_den
+    ws = workspace(lib.mmg_sup_mask_ws_bytes(n), device)
+    check(lib.mmg_sup_mask_draw(_p(seed_dev, torch.int64), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(ids, torch.int64), n,
+                                float(fraction), _p(sup) if n else None, _p(count, torch.float64),
+                                _p(inv_den, torch.float64), _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_sup_mask_draw")
+    return sup, count, inv_den
+
+
+def pair_loss(pred, y, w=None, sup=None, inv_den: float = 1.0, loss_type: str = "mae", inv_den_dev=None, loss_out=None,
+              want_dpred: bool = True):
     """-> (loss fp64 scalar tensor, dpred [n]) in one pass (mmg_pair_loss).  inv_den_dev: fp64 [1] device tensor that
-    overrides inv_den at run time (a captured step whose supervision subset changes size between replays)."""
+    overrides inv_den at run time (a captured step whose supervision subset changes size between replays).
+    loss_out: fp64 device scalar to write the loss to (a slot of the caller's buffer); want_dpred = False: loss only."""
     lib = _lib.load()
     n = pred.numel()
-    dpred = torch.empty_like(pred)
-    loss = torch.empty((), dtype=torch.float64, device=pred.device)
+    dpred = torch.empty_like(pred) if want_dpred else None
+    loss = torch.empty((), dtype=torch.float64, device=pred.device) if loss_out is None else loss_out
+    if loss.numel() != 1:
+        raise ValueError("pair_loss: loss_out must hold one fp64 value")
     ws = workspace(lib.mmg_pair_loss_ws_bytes(n), pred.device)
-    lt = {"mae": 0, "mse": 1}[loss_type]
+    if loss_type not in LOSS_TYPES:
+        raise ValueError(f"Unknown loss type: {loss_type}")            # (model.py:610 of the reference)
+    lt = LOSS_TYPES[loss_type]
     _tok = _pb("pair_loss")
     check(lib.mmg_pair_loss(_p(pred), _p(y), _p(w), _p(sup), n, float(inv_den), _p(inv_den_dev, torch.float64), lt,
                             _p(dpred), _p(loss, torch.float64),

@@ -5,8 +5,13 @@ meaning and error behaviour; the graph and the model live on the GPU.
 Differences that are switches, not silent fixes:
   * ``train_embeddings=False`` (default) reproduces the reference: the optimizer is built from
     ``model.parameters()`` BEFORE the lazy embeddings exist, so they are never updated;
-  * the per-epoch supervision mask draws from ``mask_generator`` when given, else from the wall-clock
-    seed exactly as train.py:156 does (CPU RNG, then moved to the device);
+  * the per-epoch supervision mask draws from ``mask_generator`` when given (a CPU generator reproduces the
+    reference's ``torch.rand(n) < fraction`` bit for bit; a device generator draws on the device); without one the
+    reference seeds from the wall clock (train.py:156) -- the device step then draws the subset inside the captured
+    step from the device RNG stream (``mmg_sup_mask_draw``), the eager path from the wall-clock seed as the reference;
+  * ``Trainer.train()`` runs every epoch as replays of two hipGraphs (training step, validation forward) with ONE host
+    read of the two loss scalars per epoch -- what the scheduler, early stopping and the history need
+    (``device_step=False`` keeps the eager autograd path);
   * ``ReduceLROnPlateau`` is built without the ``verbose`` kwarg torch >= 2.7 removed.
 """
 from __future__ import annotations
@@ -73,35 +78,49 @@ class EdgeMasker:
         self._cache = {}
         return self
 
-    def get_masked_data(self, split: str = "train"):
+    def draw_supervision_mask(self, n: int, device=None) -> torch.Tensor:
+        """The per-epoch supervision subset of the n train edges (train.py:150-166): torch.rand(n) < mask_fraction.
+        mask_generator on the CPU (or none: wall-clock seed, train.py:156) draws on the host exactly like the reference;
+        a device generator draws on its device, nothing crosses PCIe."""
+        if self.mask_fraction <= 0:
+            return torch.ones(n, dtype=torch.bool, device=device)
+        gen = self.mask_generator
+        if gen is None:
+            torch.manual_seed(int(time.time()))                              # train.py:156
+            m = torch.rand(n) < self.mask_fraction
+        elif gen.device.type == "cpu":
+            m = torch.rand(n, generator=gen) < self.mask_fraction
+        else:
+            return torch.rand(n, generator=gen, device=gen.device) < self.mask_fraction
+        return m if device is None else m.to(device)
+
+    def get_masked_data(self, split: str = "train", want_mask: bool = True):
+        """want_mask = False: the fourth value is None (the device step draws / receives its mask separately)."""
         if split == "train":
             mask = self.train_mask
-            n = int(mask.sum())
-            if self.mask_fraction > 0:
-                if self.mask_generator is None:
-                    torch.manual_seed(int(time.time()))                          # train.py:156
-                    supervision_mask = torch.rand(n) < self.mask_fraction
-                else:
-                    supervision_mask = torch.rand(n, generator=self.mask_generator) < self.mask_fraction
-            else:
-                supervision_mask = torch.ones(n, dtype=torch.bool)
         elif split in ("val", "test"):
             mask = self.val_mask if split == "val" else self.test_mask
-            supervision_mask = torch.ones(int(mask.sum()), dtype=torch.bool)
         else:
             raise ValueError(f"Unknown split: {split}")
         # the split is static: keep ONE tensor object per split so the model's pair cache (sorted pairs) hits
         if split not in self._cache:
             self._cache[split] = (self.edge_index[:, mask].contiguous(), self.edge_attr[mask].squeeze(-1).contiguous())
         edge_indices, edge_values = self._cache[split]
-        return edge_indices, edge_values, mask, supervision_mask.to(edge_indices.device)
+        supervision_mask = None
+        if want_mask:
+            n = edge_indices.shape[1]
+            if split == "train":
+                supervision_mask = self.draw_supervision_mask(n, edge_indices.device)
+            else:
+                supervision_mask = torch.ones(n, dtype=torch.bool, device=edge_indices.device)
+        return edge_indices, edge_values, mask, supervision_mask
 
 
 class Trainer:
     """train.py:183-561."""
 
     def __init__(self, model: nn.Module, data, masker: EdgeMasker, config: Dict, device: torch.device,
-                 train_embeddings: bool = False):
+                 train_embeddings: bool = False, device_step: bool = True):
         self.model = model.to(device)
         self.data = data.to(device)
         self.masker = masker
@@ -124,6 +143,11 @@ class Trainer:
         self.train_losses, self.val_losses = [], []
         self.lab_weights = self._compute_lab_weights()
         self._pairs = {}
+        # the captured device step (built at the first epoch) and the captured validation passes
+        self.device_step = bool(device_step)
+        self._dstep = None
+        self._deval = {}
+        self._losses = None          # fp64 [2] on the device: (train loss, validation loss) of the current epoch
 
     def _build_optimizer(self, oc: Dict) -> optim.Optimizer:
         kind = oc.get("type", "adam").lower()
@@ -164,15 +188,71 @@ class Trainer:
         w = w * L / w.sum()
         return w.float()
 
-    def _split_pairs(self, split):
-        edge_indices, edge_values, _, sup = self.masker.get_masked_data(split)
+    def _split_pairs(self, split, want_mask: bool = True):
+        edge_indices, edge_values, _, sup = self.masker.get_masked_data(split, want_mask=want_mask)
         if split not in self._pairs:          # keep the SAME tensor objects across epochs (pair-cache key)
             self._pairs[split] = (edge_indices[0].contiguous(), edge_indices[1].contiguous())
         pi, li = self._pairs[split]
         return pi, li, edge_values, sup
 
+    # ------------------------------------------------------------------ device step (hipGraph replays)
+    def _device_step_ok(self) -> bool:
+        from .optim import Adam
+        return (self.device_step and torch.device(self.device).type == "cuda" and isinstance(self.optimizer, Adam)
+                and self.loss_fn in ("mae", "mse", "huber") and getattr(self.model, "_comm", None) is None)
+
+    def _loss_slots(self):
+        if self._losses is None:
+            self._losses = torch.zeros(2, dtype=torch.float64, device=self.device)
+        return self._losses
+
+    def _build_device_step(self):
+        """The training step of train_epoch as ONE captured hipGraph (PiecewiseGraphedTrainStep, comm = None).  The
+        supervision subset is drawn inside the step when the masker has no generator (the reference's wall-clock seed,
+        train.py:156), injected through set_mask otherwise."""
+        from .data import build_plan
+        pi, li, y, _ = self._split_pairs("train", want_mask=False)
+        m = self.masker
+        frac = float(m.mask_fraction)
+        in_graph = frac > 0 and m.mask_generator is None
+        sup0 = None if in_graph else torch.ones(pi.numel(), dtype=torch.bool, device=pi.device)
+        plan = build_plan(self.data, self.device)
+        if len(self.model.embeddings) == 0:
+            self.model._init_embeddings(self.data)
+        self._dstep = PiecewiseGraphedTrainStep(self.model, plan, pi, li, y, self.lab_weights, self.optimizer, sup0, None,
+                                                loss_fn=self.loss_fn, mask_fraction=frac if in_graph else None,
+                                                loss_out=self._loss_slots()[0])
+        self._dstep_injects = frac > 0 and not in_graph
+
+    def _train_epoch_device(self) -> torch.Tensor:
+        """One epoch = one replay; returns the loss as a device scalar (no host synchronisation)."""
+        self.model.train()
+        if self._dstep is None:
+            self._build_device_step()
+        if self._dstep_injects:
+            self._dstep.set_mask(self.masker.draw_supervision_mask(self._dstep.pi.numel(), self._dstep.pi.device))
+        return self._dstep.step()
+
+    def _validate_device(self, split: str, slot: int = 1) -> torch.Tensor:
+        self.model.eval()
+        ev = self._deval.get(split)
+        if ev is None:
+            from .data import build_plan
+            pi, li, y, _ = self._split_pairs(split, want_mask=False)
+            ev = GraphedEval(self.model, build_plan(self.data, self.device), pi, li, y, self.loss_fn,
+                             loss_out=self._loss_slots()[slot])
+            self._deval[split] = ev
+        return ev.step()
+
+    # ------------------------------------------------------------------ the reference's call surface
     def train_epoch(self) -> float:
-        """train.py:332-392."""
+        """train.py:332-392.  Returns the loss as a Python float (one host read), as the reference does; train() uses
+        the device-resident form and reads both losses of an epoch at once."""
+        if self._device_step_ok():
+            return float(self._train_epoch_device())
+        return self._train_epoch_eager()
+
+    def _train_epoch_eager(self) -> float:
         self.model.train()
         pi, li, y, sup = self._split_pairs("train")
         self.optimizer.zero_grad()
@@ -195,6 +275,14 @@ class Trainer:
     @torch.no_grad()
     def validate(self, split: str = "val") -> float:
         """train.py:394-431."""
+        if split not in ("val", "test"):
+            raise ValueError(f"Unknown split: {split}")
+        if self._device_step_ok():
+            return float(self._validate_device(split))
+        return self._validate_eager(split)
+
+    @torch.no_grad()
+    def _validate_eager(self, split: str = "val") -> float:
         self.model.eval()
         pi, li, y, _ = self._split_pairs(split)
         pred = self.model.predict_lab_values(self.data, pi, li)
@@ -206,14 +294,28 @@ class Trainer:
         output_dir.mkdir(parents=True, exist_ok=True)
         lc = self.config.get("logging", {})
         history = {"train_loss": [], "val_loss": [], "learning_rates": [], "epoch_times": []}
+        on_device = self._device_step_ok()
         for epoch in range(1, self.epochs + 1):
             t0 = time.time()
-            tl = self.train_epoch()
-            vl = self.validate("val")
+            if on_device:
+                # two graph replays, then ONE host read of both losses: the scheduler, early stopping and the history
+                # below are host decisions on these two numbers (train.py:459-495)
+                self._train_epoch_device()
+                self._validate_device("val")
+                tl, vl = self._losses.tolist()
+            else:
+                tl = self._train_epoch_eager()
+                vl = self._validate_eager("val")
             history["train_loss"].append(tl)
             history["val_loss"].append(vl)
             history["learning_rates"].append(self.optimizer.param_groups[0]["lr"])
             history["epoch_times"].append(time.time() - t0)
+            self.train_losses.append(tl)
+            self.val_losses.append(vl)
+            li_ = lc.get("log_interval", 0)
+            if li_ and epoch % li_ == 0:
+                logging.info(f"Epoch {epoch}/{self.epochs} | Train Loss: {tl:.4f} | Val Loss: {vl:.4f} | "
+                             f"Time: {history['epoch_times'][-1]:.2f}s")
             if self.scheduler is not None:
                 if isinstance(self.scheduler, optim.lr_scheduler.ReduceLROnPlateau):
                     self.scheduler.step(vl)
@@ -233,7 +335,6 @@ class Trainer:
                 break
         with open(output_dir / "training_history.json", "w") as f:
             json.dump(history, f, indent=2)
-        self.train_losses, self.val_losses = history["train_loss"], history["val_loss"]
         return history
 
     def _save(self, path, epoch, val_loss):
@@ -281,11 +382,16 @@ class _SupervisionState:
     are updated in place, so a replay with a new per-epoch mask (train.py:150-176 of the reference) divides by the size
     of THAT subset, exactly like the reference's .mean() over pred[mask] (train.py:366-386)."""
 
-    def __init__(self, sup_mask, comm, n_sup_global):
+    def __init__(self, sup_mask, comm, n_sup_global, n=None, device=None):
         self.comm = comm
-        self.sup = sup_mask.to(torch.float32).contiguous()
+        if sup_mask is None:                     # drawn inside the step (draw()): nothing supervised until then
+            self.sup = torch.zeros(int(n), dtype=torch.float32, device=device)
+        else:
+            self.sup = sup_mask.to(torch.float32).contiguous()
         self.inv_den = torch.ones(1, dtype=torch.float64, device=self.sup.device)
-        self._set_den(n_sup_global)
+        self.count = torch.zeros(1, dtype=torch.float64, device=self.sup.device)
+        if sup_mask is not None:
+            self._set_den(n_sup_global)
 
     def _set_den(self, n_sup_global=None):
         if n_sup_global is not None:
@@ -299,6 +405,19 @@ class _SupervisionState:
     def set_mask(self, sup_mask, n_sup_global=None):
         self.sup.copy_(sup_mask)                 # (bool -> float inside the copy)
         self._set_den(n_sup_global)
+
+    def draw(self, fraction, seed_dev, ids=None):
+        """New subset drawn on the device from the step's seed stream (mmg_sup_mask_draw); capturable.  Sharded: the
+        subset size is summed over the ranks (one more small all-reduce) before the normaliser is formed."""
+        from . import ops
+        if self.comm is None:
+            ops.sup_mask_draw(self.sup.numel(), fraction, self.sup.device, seed_dev=seed_dev, ids=ids, sup=self.sup,
+                              count=self.count, inv_den=self.inv_den)
+        else:
+            ops.sup_mask_draw(self.sup.numel(), fraction, self.sup.device, seed_dev=seed_dev, ids=ids, sup=self.sup,
+                              count=self.count, inv_den=None)
+            self.comm.all_reduce(self.count)
+            torch.reciprocal(self.count.clamp(min=1.0), out=self.inv_den)
 
 
 def _new_seed_state(dev) -> torch.Tensor:
@@ -326,12 +445,13 @@ class GraphedTrainStep:
         self.model, self.data, self.opt = model, data, optimizer
         dev = pi.device
         self.pi, self.li, self.y = pi, li, y
-        self.wl = lab_weights[li].contiguous()
+        if loss_fn not in ("mae", "mse", "huber"):
+            raise ValueError(f"Unknown loss type: {loss_fn}")
+        # the reference weights mae / mse by lab (train.py:366-386) and falls back to the unweighted loss otherwise
+        self.wl = lab_weights[li].contiguous() if loss_fn in ("mae", "mse") else None
         self._sv = _SupervisionState(sup_mask, None, n_sup_global)   # mask + 1/n_sup on the device: set_mask()
         self.sup = self._sv.sup
         self.loss_fn = loss_fn
-        if loss_fn not in ("mae", "mse"):
-            raise ValueError(f"GraphedTrainStep supports 'mae'/'mse', got {loss_fn}")
         model._seed_dev = _new_seed_state(dev)
         self.loss = torch.zeros((), device=dev)
         model.train()
@@ -366,6 +486,8 @@ class GraphedTrainStep:
         self._sv.set_mask(sup_mask, n_sup_global)
 
     def step(self) -> torch.Tensor:
+        if hasattr(self.opt, "sync_hyper"):
+            self.opt.sync_hyper()                    # a scheduler may have changed lr since the last replay
         self.graph.replay()
         return self.loss
 
@@ -385,22 +507,31 @@ class PiecewiseGraphedTrainStep:
     """
 
     def __init__(self, model, plan, pi, li, y, lab_weights, optimizer, sup_mask, comm, loss_fn: str = "mae",
-                 n_sup_global: Optional[float] = None, warmup: int = 2):
+                 n_sup_global: Optional[float] = None, warmup: int = 2, mask_fraction: Optional[float] = None,
+                 loss_out: Optional[torch.Tensor] = None):
+        """mask_fraction: draw a NEW supervision subset of that fraction inside every step (device RNG; the reference
+        redraws it every epoch, train.py:150-176) -- `sup_mask` may then be None; otherwise the subset is `sup_mask`
+        until set_mask.  loss_out: fp64 device scalar the step writes its loss to."""
         from . import ops
         from .model import _Run
-        if loss_fn not in ("mae", "mse"):
-            raise ValueError(f"PiecewiseGraphedTrainStep supports 'mae'/'mse', got {loss_fn}")
+        if loss_fn not in ("mae", "mse", "huber"):
+            raise ValueError(f"Unknown loss type: {loss_fn}")
+        if sup_mask is None and mask_fraction is None:
+            raise ValueError("PiecewiseGraphedTrainStep: a supervision mask or a mask_fraction")
         self.model, self.plan, self.opt, self.comm = model, plan, optimizer, comm
         self.pi, self.li, self.y = pi, li, y
-        self.wl = lab_weights[li].contiguous()
-        self._sv = _SupervisionState(sup_mask, comm, n_sup_global)
+        # the reference weights mae / mse by lab (train.py:366-386) and falls back to the unweighted loss otherwise
+        self.wl = lab_weights[li].contiguous() if loss_fn in ("mae", "mse") else None
+        self.mask_fraction = None if mask_fraction is None else float(mask_fraction)
+        dev = pi.device
+        self._sv = _SupervisionState(sup_mask, comm, n_sup_global, n=pi.numel(), device=dev)
         self.sup = self._sv.sup
         self.loss_fn = loss_fn
+        self._loss_out = loss_out
         self._ops, self._Run = ops, _Run
         self._sel = None
-        self._select()                 # the pair lists of the backward: fixed until set_mask, not part of the step
-        dev = pi.device
         model._seed_dev = _new_seed_state(dev)
+        self._select()                 # the pair lists of the backward (rebuilt inside the step when it draws its mask)
         self.loss = torch.zeros((), device=dev)
         self.params = [p for p in model.parameters()]
         model.train()
@@ -449,6 +580,10 @@ class PiecewiseGraphedTrainStep:
         with torch.no_grad():
             for p in self.params:
                 p.grad = None
+            if self.mask_fraction is not None:       # this step's supervision subset, its size and its pair lists
+                self._sv.draw(self.mask_fraction, model._seed_dev,
+                              getattr(self.comm, "pair_ids", None) if self.comm else None)
+                self._select()
             run = self._Run(model, self.plan)
             run.pairs = model._pairs(self.pi, self.li, self.plan.n_rows,
                                      getattr(self.comm, "pair_ids", None) if self.comm else None,
@@ -457,7 +592,8 @@ class PiecewiseGraphedTrainStep:
             run.need_grad = True
             run.static_select = self._sel
             (pred,) = run.run_forward("predict")
-            loss, dpred = ops.pair_loss(pred, self.y, self.wl, self.sup, 1.0, self.loss_fn, self._sv.inv_den)
+            loss, dpred = ops.pair_loss(pred, self.y, self.wl, self.sup, 1.0, self.loss_fn, self._sv.inv_den,
+                                        loss_out=self._loss_out)
             grads = run.run_backward((dpred,))
             for p, g in zip(self.params, grads):
                 if g is not None:
@@ -480,13 +616,66 @@ class PiecewiseGraphedTrainStep:
 
     def set_mask(self, sup_mask, n_sup_global=None):
         """New supervision subset; 1 / n_sup (summed over the shards) and the backward's pair lists follow it on the device."""
+        if self.mask_fraction is not None:
+            raise ValueError("this step draws its supervision subset itself (mask_fraction)")
         self._sv.set_mask(sup_mask, n_sup_global)
         self._select()
 
     def step(self) -> torch.Tensor:
+        if hasattr(self.opt, "sync_hyper"):
+            self.opt.sync_hyper()                    # a scheduler may have changed lr since the last replay
         for kind, x in self.items:
             if kind == "graph":
                 x.replay()
             else:
                 self.comm.raw_all_reduce(x)
+        return self.loss
+
+
+class GraphedEval:
+    """``Trainer.validate`` (train.py:394-431 of the reference) as ONE captured hipGraph: the eval-mode
+    ``predict_lab_values`` on the split's pairs and the unweighted ``compute_regression_loss`` over all of them.  The
+    loss stays on the device (``loss_out``, or a scalar of the graph's pool); the predictions are ``self.pred``."""
+
+    def __init__(self, model, plan, pi, li, y, loss_fn: str = "mae", loss_out: Optional[torch.Tensor] = None,
+                 warmup: int = 1):
+        from . import ops
+        from .model import _Run
+        if loss_fn not in ops.LOSS_TYPES:
+            raise ValueError(f"Unknown loss type: {loss_fn}")
+        self.model, self.plan = model, plan
+        self.pi, self.li, self.y = pi, li, y
+        self.loss_fn, self._loss_out = loss_fn, loss_out
+        self._ops, self._Run = ops, _Run
+        self.loss = self.pred = None
+        was_training = model.training
+        model.eval()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        torch.cuda.synchronize()
+        model.train(was_training)
+
+    def _body(self):
+        ops, model = self._ops, self.model
+        with torch.no_grad():
+            run = self._Run(model, self.plan)
+            run.pairs = model._pairs(self.pi, self.li, self.plan.n_rows, None, self.plan.lab_deg,
+                                     int(model.degree_threshold))
+            run.n_pairs = self.pi.numel()
+            run.need_grad = False
+            (pred,) = run.run_forward("predict")
+            n = max(int(self.pi.numel()), 1)
+            self.loss, _ = ops.pair_loss(pred, self.y, None, None, 1.0 / n, self.loss_fn, loss_out=self._loss_out,
+                                         want_dpred=False)
+            self.pred = pred
+
+    def step(self) -> torch.Tensor:
+        self.graph.replay()
         return self.loss

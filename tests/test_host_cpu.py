@@ -191,3 +191,50 @@ def test_deferred_weight_gradient_jobs_keep_their_order(monkeypatch):
     many = [job(1000 + i, 0) for i in range(20)]
     ops.wgrad_reduce_flush(many)
     assert [len(c) for c in calls] == [16, 4]
+
+
+def test_vec_sums_refuses_two_jobs_with_one_destination():
+    """The jobs of one mmg_vec_sums launch run concurrently: a shared destination would lose a contribution.  Checked on
+    the host before any launch (as mmg_wgrad_reduce_group does for its gradients)."""
+    import ctypes as C
+    import mmgnn  # noqa: F401
+    from mmgnn import _lib
+    from mmgnn._lib import SumJobT
+    lib = _lib.load()
+    arr = (SumJobT * 2)()
+    for j in range(2):
+        src = (C.c_void_p * 4)(0x2000 + 0x100 * j, None, None, None)
+        arr[j] = SumJobT(0x1000, src, 1, 8, 0, 0, (C.c_int * 4)(0, 0, 0, 0))
+    assert lib.mmg_vec_sums(arr, 2, None) == -1 and b"share a destination" in lib.mmg_last_error()
+
+
+def test_flush_grad_sums_chains_more_than_three_contributions(monkeypatch):
+    """_Run.flush_grad_sums with 5 contributions to one parameter: sums go to NEW tensors (the first contribution may be
+    shared by other names or belong to the caller), 3 further sources per job, and the second job -- which reads the
+    first one's result -- is a later launch."""
+    import mmgnn  # noqa: F401
+    from mmgnn import model as mm, ops
+    launches = []
+    monkeypatch.setattr(ops, "wgrad_reduce_flush", lambda jobs: None)
+
+    def fake_vec_sums(jobs):
+        launches.append(len(jobs))
+        for dst, srcs in jobs:
+            acc = srcs[0].clone()
+            for s_ in srcs[1:]:
+                acc = acc + s_
+            dst.copy_(acc)
+
+    monkeypatch.setattr(ops, "vec_sums", fake_vec_sums)
+    run = object.__new__(mm._Run)
+    run.grads, run.pending, run.partial, run.wgrad_jobs = {}, {}, set(), []
+    parts = [torch.full((4, 3), float(i + 1)) for i in range(5)]
+    shared = torch.full((2,), 10.0)
+    for p_ in parts:
+        run.acc("w", p_)
+    run.acc("a", shared); run.acc("b", shared); run.acc("b", torch.ones(2))
+    run.flush_grad_sums()
+    assert torch.equal(run.grads["w"], torch.full((4, 3), 15.0))
+    assert torch.equal(parts[0], torch.full((4, 3), 1.0))                   # the first contribution is not overwritten
+    assert torch.equal(run.grads["b"], torch.full((2,), 11.0)) and torch.equal(run.grads["a"], torch.full((2,), 10.0))
+    assert run.grads["a"] is shared and launches == [2, 1] and run.pending == {}

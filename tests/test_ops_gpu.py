@@ -632,7 +632,78 @@ def test_pair_head_selected_lists_match_full_sweep(ops, dev, p):
             assert rel(getattr(g1, name), getattr(g0, name).double().cpu()) <= 2e-5, (name, want_low)
 
 
-@pytest.mark.parametrize("loss_type", ["mae", "mse"])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_pair_heads_never_turn_a_bad_list_entry_into_an_address(ops, dev, p):
+    """Every indexed access of the pair kernels is range-checked (buffer descriptors sized on the host from n_total,
+    n_patients, n_labs).  A list with entries outside the pair arrays (negative, past the end), a stale count that is
+    larger than the list, patient / lab ids outside their tables and io_perm slots outside pred: nothing of it is read as
+    an address -- the bad entries contribute nothing and the good ones give what the clean call gives, bit for bit."""
+    gen = torch.Generator().manual_seed(15)
+    P, L, n = 300, 40, 4000
+    A, B = torch.randn(P, 64, generator=gen), torch.randn(L, 64, generator=gen)
+    W2, b2 = torch.randn(32, 64, generator=gen) / 8, torch.randn(32, generator=gen) * 0.1
+    W3, b3 = torch.randn(32, generator=gen) / 5, torch.randn(1, generator=gen)
+    pi = torch.randint(0, P, (n,), generator=gen).sort().values
+    li = torch.randint(0, L, (n,), generator=gen)
+    deg = torch.full((P,), 9, dtype=torch.int64)                     # one head serves every pair
+    perm = torch.randperm(n, generator=gen)
+    dpred = torch.randn(n, generator=gen).to(dev)
+    head = ops.Head(*[t.to(dev) for t in (A, B, W2, b2, W3, b3)])
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    pi_d, li_d, deg_d, io = i32(pi), i32(li), i32(deg), perm.to(dev)
+    good = torch.arange(0, n, 3, dtype=torch.int32)                  # the clean list
+    n_good = good.numel()
+    zeros = lambda: ops.Head(*[torch.zeros_like(t, device=dev) for t in (A, B, W2, b2, W3, b3)])
+
+    def run(sel, count, pi_=pi_d, li_=li_d, io_=io):
+        pred = torch.full((n,), -3.0, device=dev)
+        cnt = torch.tensor([count], dtype=torch.int32, device=dev)
+        ops.pair_head_fwd(head, pi_, li_, deg_d, 6, False, p, 21, io_, pred, sel=sel.to(dev), n_sel=cnt, n_bound=sel.numel(),
+                          io_perm=io_)
+        g = zeros()
+        ops.pair_head_bwd(head, g, pi_, li_, deg_d, 6, False, L, p, 21, io_, dpred, sel=sel.to(dev), n_sel=cnt,
+                          n_bound=sel.numel(), io_perm=io_)
+        torch.cuda.synchronize()
+        return pred, g
+
+    ref_pred, ref_g = run(good, n_good)
+    assert float((ref_pred != -3.0).sum()) == n_good
+    # (1) garbage entries inside the list and a stale count that runs past it into more garbage
+    bad = torch.cat([good, torch.tensor([-1, -2 ** 31, n, n + 5, 2 ** 30, 2 ** 31 - 1], dtype=torch.int32),
+                     torch.full((58,), 2 ** 29, dtype=torch.int32)])
+    pred, g = run(bad, bad.numel())
+    assert torch.equal(pred, ref_pred)
+    for name in "A B W2 b2 W3 b3".split():
+        assert torch.equal(getattr(g, name), getattr(ref_g, name)), name
+    # (2) a count larger than the launch bound cannot reach beyond the list either
+    pred, g = run(good, n_good + 10 ** 6)
+    assert torch.equal(pred, ref_pred) and torch.equal(g.A, ref_g.A) and torch.equal(g.B, ref_g.B)
+    # (3) patient ids outside A / deg are not pairs; lab ids outside B never index past the table and add nothing to dB
+    pi_bad = pi_d.clone()
+    hit = good[::7].long().to(dev)
+    pi_bad[hit[::2]] = P + 17
+    pi_bad[hit[1::2]] = -5
+    pred, g = run(good, n_good, pi_=pi_bad)
+    keep = torch.ones(n, dtype=torch.bool, device=dev)
+    keep[perm.to(dev)[hit]] = False                                  # their output slots stay untouched
+    assert torch.equal(pred[keep], ref_pred[keep]) and bool((pred[~keep] == -3.0).all())
+    assert bool(torch.isfinite(g.A).all()) and bool(torch.isfinite(g.B).all())
+    li_bad = li_d.clone()
+    li_bad[hit] = L + 3
+    pred, g = run(good, n_good, li_=li_bad)
+    assert bool(torch.isfinite(pred).all()) and torch.equal(pred[keep], ref_pred[keep])
+    assert bool(torch.isfinite(g.B).all())
+    # (4) an output slot outside pred is dropped, not written
+    io_bad = io.clone()
+    io_bad[hit] = n + 1000
+    pred, g = run(good, n_good, io_=io_bad)
+    assert torch.equal(pred[keep], ref_pred[keep]) and bool((pred[~keep] == -3.0).all())
+    # the wrapper refuses per-pair arrays of different lengths (the kernels range-check against pi's length)
+    with pytest.raises(ValueError, match="entries"):
+        ops.pair_head_fwd(head, pi_d, li_d[:-1], deg_d, 6, False, p, 21, io, ref_pred)
+
+
+@pytest.mark.parametrize("loss_type", ["mae", "mse", "huber"])
 def test_weighted_pair_loss(ops, dev, loss_type):
     gen = torch.Generator().manual_seed(41)
     n = 100003
@@ -645,12 +716,13 @@ def test_weighted_pair_loss(ops, dev, loss_type):
     loss.backward()
     pd = pred.double().requires_grad_(True)
     d = pd - y.double()
-    ref = ((d.abs() if loss_type == "mae" else d * d) * w.double() * sup.double()).sum() * inv
+    per = {"mae": d.abs(), "mse": d * d, "huber": torch.where(d.abs() <= 1, 0.5 * d * d, d.abs() - 0.5)}[loss_type]
+    ref = (per * w.double() * sup.double()).sum() * inv
     ref.backward()
     assert abs(float(loss) - float(ref)) <= 1e-6 * abs(float(ref))
     assert rel(p.grad, pd.grad) <= 1e-6
     l2 = ops.weighted_pair_loss(p, y.to(dev), None, None, 1.0 / n, loss_type)
-    r2 = (d.abs() if loss_type == "mae" else d * d).mean()
+    r2 = per.mean()
     assert abs(float(l2) - float(r2)) <= 1e-6 * abs(float(r2))
 
 

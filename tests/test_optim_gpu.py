@@ -192,3 +192,122 @@ def test_graphed_step_draws_new_masks_on_the_device(dev):
     nbt = int(m.patient_transform[1].num_batches_tracked)
     step.step()
     assert int(m.patient_transform[1].num_batches_tracked) > nbt      # BatchNorm counters advance inside the graph
+
+
+def test_scheduler_survives_hipgraph_replay(dev, monkeypatch):
+    """The hyper-parameters live on the device (mmg_adam_step_dev): a StepLR / ReduceLROnPlateau that changes
+    param_groups['lr'] between replays (src/train.py:271-291 of the reference) changes the captured step."""
+    import mmgnn  # noqa: F401
+    from mmgnn.optim import Adam
+    gen = torch.Generator().manual_seed(4)
+    ps = _params(dev, gen)
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    grads = [torch.randn(*p.shape, generator=gen).to(dev) for p in ps]
+    for p, g in zip(ps, grads):
+        p.grad = g
+    opt = Adam(ps, lr=1e-2, weight_decay=1e-3)
+    ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-3)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=2, gamma=0.1)
+    rsched = torch.optim.lr_scheduler.StepLR(ropt, step_size=2, gamma=0.1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph):
+            opt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    lrs = []
+    for _ in range(5):
+        opt.sync_hyper()
+        graph.replay()
+        sched.step()
+        lrs.append(opt.param_groups[0]["lr"])
+        for r, g in zip(ref, grads):
+            r.grad = g.cpu()
+        ropt.step()
+        rsched.step()
+    torch.cuda.synchronize()
+    assert lrs[0] == pytest.approx(1e-2) and lrs[-1] == pytest.approx(1e-4)          # the schedule did change lr
+    for p, r in zip(ps, ref):
+        assert float((p.detach().cpu() - r.detach()).abs().max()) <= 2e-6 * float(r.detach().abs().max()) + 1e-7
+    # a change made INSIDE a capture cannot reach the device: refused, not ignored
+    opt.param_groups[0]["lr"] = 0.5
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    with pytest.raises(Exception, match="sync_hyper"):
+        opt.step()
+
+
+def test_add_param_group_gets_its_own_bucket(dev):
+    import mmgnn  # noqa: F401
+    from mmgnn.optim import Adam
+    gen = torch.Generator().manual_seed(5)
+    ps = _params(dev, gen)
+    ref = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    opt = Adam(ps[:4], lr=1e-2)
+    ropt = torch.optim.Adam(ref[:4], lr=1e-2)
+    opt.add_param_group({"params": ps[4:], "lr": 3e-2})
+    ropt.add_param_group({"params": ref[4:], "lr": 3e-2})
+    for _ in range(3):
+        for p, r in zip(ps, ref):
+            g = torch.randn(*p.shape, generator=gen)
+            p.grad, r.grad = g.to(dev), g.clone()
+        opt.step()
+        ropt.step()
+    for p, r in zip(ps, ref):
+        assert float((p.detach().cpu() - r.detach()).abs().max()) <= 2e-6 * float(r.detach().abs().max()) + 1e-7
+
+
+def test_supervision_mask_drawn_on_the_device(dev):
+    """mmg_sup_mask_draw: the per-epoch 20 % subset (train.py:150-176) from the counter RNG -- fraction, subset size and
+    normaliser, determinism per seed, a new subset per seed, id-keyed (partition-invariant) draws."""
+    import mmgnn  # noqa: F401
+    from mmgnn import ops
+    n = 300_001
+    st = torch.tensor([1234567, 0], dtype=torch.int64, device=dev)
+    sup, cnt, inv = ops.sup_mask_draw(n, 0.2, dev, seed_dev=st)
+    assert set(sup.unique().tolist()) == {0.0, 1.0}
+    k = float(sup.sum(dtype=torch.float64))
+    assert float(cnt) == k and float(inv) == 1.0 / k
+    assert abs(k / n - 0.2) < 4 * (0.2 * 0.8 / n) ** 0.5 + 1e-4
+    sup2, _, _ = ops.sup_mask_draw(n, 0.2, dev, seed=1234567)
+    assert torch.equal(sup, sup2)                                   # the device seed and the host seed are the same key
+    st[0] = 7654321
+    sup3, cnt3, _ = ops.sup_mask_draw(n, 0.2, dev, seed_dev=st)
+    assert not torch.equal(sup, sup3) and abs(float(cnt3) / n - 0.2) < 0.01
+    agree = float((sup == sup3).float().mean())
+    assert abs(agree - (0.04 + 0.64)) < 0.01                        # independent draws
+    # keyed on the pair id: a shard that holds pairs [a, b) of the global list draws their part of the global mask
+    ids = torch.arange(1000, 5000, dtype=torch.int64, device=dev)
+    part, _, _ = ops.sup_mask_draw(ids.numel(), 0.2, dev, seed=1234567, ids=ids)
+    assert torch.equal(part, sup[1000:5000])
+    full, c1, i1 = ops.sup_mask_draw(1000, 1.0, dev, seed=3)
+    none, c0, i0 = ops.sup_mask_draw(1000, 0.0, dev, seed=3)
+    assert float(full.sum()) == 1000 and float(none.sum()) == 0 and float(c0) == 0 and float(i0) == 1.0
+    empty, ce, _ = ops.sup_mask_draw(0, 0.2, dev, seed=3)
+    assert empty.numel() == 0 and float(ce) == 0.0
+
+
+@pytest.mark.parametrize("loss_type", ["mae", "mse", "huber"])
+def test_pair_loss_types_match_torch(dev, loss_type):
+    """mmg_pair_loss against compute_regression_loss's torch functions (model.py:579-612), value and gradient; huber
+    crosses its delta = 1 knee."""
+    import mmgnn  # noqa: F401
+    from mmgnn import ops
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(6)
+    n = 50_000
+    pred = (torch.randn(n, generator=gen) * 2).to(dev)
+    y = torch.randn(n, generator=gen).to(dev)
+    pred[:3] = y[:3] + torch.tensor([1.0, -1.0, 0.0], device=dev)    # on the knee and at zero
+    loss, dpred = ops.pair_loss(pred, y, None, None, 1.0 / n, loss_type)
+    p64 = pred.double().cpu().requires_grad_(True)
+    fn = {"mae": F.l1_loss, "mse": F.mse_loss, "huber": F.huber_loss}[loss_type]
+    want = fn(p64, y.double().cpu())
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 1e-6 * abs(float(want))
+    assert float((dpred.double().cpu() - p64.grad).abs().max()) <= 1e-6 * float(p64.grad.abs().max())
+    slot = torch.zeros(2, dtype=torch.float64, device=dev)
+    l2, d2 = ops.pair_loss(pred, y, None, None, 1.0 / n, loss_type, loss_out=slot[1], want_dpred=False)
+    assert d2 is None and float(slot[1]) == float(loss) and float(slot[0]) == 0.0
+    with pytest.raises(ValueError, match="Unknown loss type"):
+        ops.pair_loss(pred, y, None, None, 1.0, "logcosh")

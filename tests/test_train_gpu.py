@@ -177,3 +177,90 @@ def test_mask_and_recover_metrics_follow_the_oracle(dev):
     assert abs(got["mae"] - want["mae"]) <= 1e-3 * want["mae"]
     assert abs(got["r2"] - want["r2"]) <= 2e-3
     assert abs(got["rmse"] - want["rmse"]) <= 1e-3 * want["rmse"]
+
+
+def _history_pair(dev, tmp_path, cfg, n=(300, 12, 15, 10), mask_seed=11):
+    """The same training run twice from one state: eager autograd steps (device_step=False) and the captured device step."""
+    g0 = fx.graph_from_frames(fx.det_frames(*n))
+    gv = om.GraphView(g0)
+    sd = fx.det_state(gv.num_nodes, cfg["model"]["hidden_dim"])
+    out = []
+    for device_step in (False, True):
+        import mmgnn  # noqa: F401
+        from mmgnn.model import build_model
+        from mmgnn.train import EdgeMasker, Trainer
+        g = fx.graph_from_frames(fx.det_frames(*n))
+        tc = cfg["train"]
+        masker = EdgeMasker(g, tc["train_split"], tc["val_split"], tc["test_split"], tc["mask_fraction"], tc["seed"],
+                            mask_generator=torch.Generator().manual_seed(mask_seed))
+        model = build_model(cfg, (g.node_types, g.edge_types), None)
+        model._init_embeddings(g)
+        model.load_state_dict(sd)
+        trainer = Trainer(model, g, masker, cfg, dev, device_step=device_step)
+        d = tmp_path / ("graph" if device_step else "eager")
+        hist = trainer.train(d)
+        out.append((hist, trainer, model))
+    return out
+
+
+@pytest.mark.parametrize("sched", ["step", "reduce_on_plateau"])
+@pytest.mark.parametrize("loss_fn", ["mae", "huber"])
+def test_trainer_train_runs_the_captured_step_and_reproduces_the_eager_history(dev, tmp_path, sched, loss_fn):
+    """Trainer.train() -- the reference's entry point (train.py:433-544) -- replays the captured device step and a captured
+    validation pass with one host read per epoch; its history (losses, learning rates under a scheduler that really
+    changes lr, early-stopping bookkeeping, checkpoints) is the eager autograd path's on the same injected masks."""
+    cfg = _config(hidden=64, dropout=0.0, epochs=5, opt="adam", lr=5e-3)
+    cfg["train"]["loss"] = loss_fn
+    if sched == "step":
+        cfg["train"]["lr_scheduler"] = {"enabled": True, "type": "step", "step_size": 2, "gamma": 0.5}
+    else:
+        cfg["train"]["lr_scheduler"] = {"enabled": True, "type": "reduce_on_plateau", "factor": 0.5, "patience": 0}
+    (he, te, me), (hg, tg, mg) = _history_pair(dev, tmp_path, cfg)
+    assert tg._dstep is not None and te._dstep is None               # the graph path ran / the eager path did not build one
+    assert "val" in tg._deval
+    assert len(hg["train_loss"]) == len(he["train_loss"]) == 5
+    assert hg["learning_rates"] == he["learning_rates"]
+    if sched == "step":
+        assert hg["learning_rates"] == pytest.approx([5e-3, 5e-3, 2.5e-3, 2.5e-3, 1.25e-3])
+    for k in ("train_loss", "val_loss"):
+        for a, b in zip(hg[k], he[k]):
+            assert abs(a - b) <= 2e-4 * abs(b), (k, hg[k], he[k])
+    assert tg.best_val_loss == pytest.approx(te.best_val_loss, rel=2e-4) and tg.patience_counter == te.patience_counter
+    for (k, a), (_, b) in zip(mg.state_dict().items(), me.state_dict().items()):
+        if a.is_floating_point():
+            assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6, k      # five chained Adam steps
+        else:
+            assert torch.equal(a, b), k                                                     # BatchNorm step counters
+    assert (tmp_path / "graph" / "best_model.pt").exists() and (tmp_path / "graph" / "checkpoint_epoch_2.pt").exists()
+    ck = torch.load(tmp_path / "graph" / "best_model.pt", map_location="cpu", weights_only=False)
+    assert ck["val_loss"] == min(hg["val_loss"])
+    # the public single-epoch calls are the same captured steps (one host read each)
+    assert isinstance(tg.train_epoch(), float) and isinstance(tg.validate("val"), float)
+    assert isinstance(tg.validate("test"), float) and "test" in tg._deval
+
+
+def test_trainer_without_a_mask_generator_draws_its_masks_inside_the_step(dev, tmp_path):
+    """No mask_generator = the reference's wall-clock seeded redraw every epoch (train.py:156): the captured step draws the
+    subset itself (mmg_sup_mask_draw), a different one every epoch, and normalises by its size."""
+    import mmgnn  # noqa: F401
+    from mmgnn.model import build_model
+    from mmgnn.train import EdgeMasker, Trainer
+    cfg = _config(hidden=64, dropout=0.2, epochs=4, opt="adam", lr=1e-3)
+    g = fx.graph_from_frames(fx.det_frames(300, 12, 15, 10))
+    masker = EdgeMasker(g, 0.7, 0.15, 0.15, 0.2, 42)
+    model = build_model(cfg, (g.node_types, g.edge_types), None)
+    trainer = Trainer(model, g, masker, cfg, dev)
+    masks, losses = [], []
+    for _ in range(3):
+        losses.append(trainer.train_epoch())
+        st = trainer._dstep
+        masks.append(st.sup.clone())
+        n_sup = float(st.sup.sum())
+        assert float(st._sv.count) == n_sup and float(st._sv.inv_den) == pytest.approx(1.0 / n_sup)
+        assert 0.1 < n_sup / st.sup.numel() < 0.3
+    assert st.mask_fraction == pytest.approx(0.2) and all(np.isfinite(losses))
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+    with pytest.raises(ValueError, match="draws its supervision subset"):
+        st.set_mask(masks[0])
+    hist = trainer.train(tmp_path)
+    assert len(hist["train_loss"]) == 4 and all(np.isfinite(hist["train_loss"] + hist["val_loss"]))
