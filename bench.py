@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: has_lab edges/s for one full training step
-(fwd + weighted-MAE loss + bwd + Adam) of ``predict_lab_values`` on a synthetic eICU-shape hetero-graph.
+(new 20 % supervision mask + fwd + weighted-MAE loss + bwd + Adam) of ``predict_lab_values`` on a synthetic eICU-shape
+hetero-graph.
 
     python bench.py --gpus N --steps K --warmup W [--scale S] [--dim D] [--strong] [--no-strong-x1000]
 
@@ -9,21 +10,28 @@ One process per GPU (N>1: launched by torch.distributed.run, RCCL).  Workload at
                     has_lab edges, 128-d) of ONE global graph of N shards; vocab nodes shared.
                     N=1, scale=100 is BASELINE.json configs[2].
   --strong        : ONE global x<scale> graph, patient-sharded over the N GPUs (headline becomes the strong run).
-  strong_x1000    : in the same invocation, unless --no-strong-x1000: BASELINE.json's north-star split -- ONE x1000
-                    graph (1.83 M patients, 61.5 M has_lab edges), patient-sharded over the N GPUs, RCCL all-reduces
-                    on the shared vocab-side sums / gradients.  Reported as the "strong_x1000" object of the same JSON
-                    line, so the per-N lines of a 1/2/4/8 sweep give BOTH curves.
+  strong_x1000    : in the same invocation, unless --no-strong-x1000: BASELINE.json config 4 -- ONE x1000 graph (1.83 M
+                    patients, 61.5 M has_lab edges) at 256-d, patient-sharded over the N GPUs, RCCL all-reduces on the
+                    shared vocab-side sums / gradients -- and the same graph at 128-d (north_star's 1 -> 8 curve).
+                    Reported as objects of the same JSON line, so the per-N lines of a 1/2/4/8 sweep give the curves.
+A step is what one epoch of the full-batch reference is (src/train.py:332-392): the supervision subset is redrawn
+(train.py:150-176) INSIDE the timed step (device RNG, mmg_sup_mask_draw), then forward, loss, backward, optimizer.
 Prints ONE JSON line (rank 0):
   value / ms_per_step : the timed region (K steps, barrier + synchronize on both sides, max over ranks);
-  roofline            : the kernel family with the most kernel time per step.  Kernel durations are the HIP start /
-                        stop events that hipExtLaunchKernelGGL attaches to each launch (mmg_probe_*: the kernel's own
-                        begin / end timestamps on its stream -- never a pair of events bracketing a launch, which on a
-                        forked stream also measures the wait behind other kernels), taken in eager steps of the same
-                        kernels right after the timed region (graph replays cannot carry per-kernel events);
+  fixed_supervision_mask : the same replays without the per-step redraw (last round's headline), for comparison;
+  trainer_epoch       : N=1: the SAME step reached through the reference's call surface -- mmgnn.train.Trainer
+                        (train_epoch / validate / the loop body of Trainer.train with its one host read per epoch);
+  chain_overhead_ms   : N=1: the step replayed as the CHAIN of hipGraph segments + RCCL all-reduces a sharded run uses
+                        (world_size-1 `nccl` group) minus the single-graph step: the fixed cost of the multi-GPU launch
+                        scheme, measurable on one GPU;
+  roofline            : the kernel (instantiated symbol) of the family with the most kernel time per step.  Kernel
+                        durations are the HIP start / stop events that hipExtLaunchKernelGGL attaches to each launch
+                        (mmg_probe_*: the kernel's own begin / end timestamps on its stream), taken in eager steps of the
+                        same kernels right after the timed region (graph replays cannot carry per-kernel events);
   kernels             : the same figures for the kernels north_star grades -- the per-relation gather and scatter
                         (scatter = matrix kernel + its fixed-order slab sum) -- and the other big kernel families;
   cpu_baseline        : the oracle (CPU restatement of the reference) timed on this host's cores, N=1 only, on bounded
-                        samples of the same workload.
+                        samples of the same workload; the full x100 step (run once, profiles/) is quoted beside it.
 """
 import argparse
 import gc
@@ -38,6 +46,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 import mmgnn  # noqa: E402,F401
 from mmgnn import dist as mdist  # noqa: E402
+from mmgnn import model as mmodel  # noqa: E402
 from mmgnn import ops  # noqa: E402
 from mmgnn.data import build_plan  # noqa: E402
 from mmgnn.model import build_model  # noqa: E402
@@ -47,12 +56,14 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 # the dense layers and the aggregates compute fp32 products as exact bf16 pieces on the bf16 matrix cores: 6 matrix
-# FLOP per algorithmic fp32 FLOP (linear layers), 3 (0/1-indicator aggregates)
+# FLOP per algorithmic fp32 FLOP (linear layers, the pair forward's 64 x 32 layer), 3 (0/1-indicator aggregates)
 MFMA_PEAK_BY_OP = {"linear_fwd": MFMA_BF16_PEAK_TF / 6, "linear_wgrad": MFMA_BF16_PEAK_TF / 6,
-                   "gather_rows": MFMA_BF16_PEAK_TF / 3, "scatter_rows": MFMA_BF16_PEAK_TF / 3}
+                   "gather_rows": MFMA_BF16_PEAK_TF / 3, "scatter_rows": MFMA_BF16_PEAK_TF / 3,
+                   "pair_head_fwd": MFMA_BF16_PEAK_TF / 6, "pair_head_bwd": MFMA_F32_PEAK_TF}
 LAB = ("patient", "has_lab", "lab")
 # kernels that belong to ONE op: the fixed-order slab sums are part of the scatter / weight-gradient they finish
 FOLLOWERS = {"scatter_reduce": "scatter_rows", "linear_wgrad_reduce": "linear_wgrad"}
+MASK_FRACTION = 0.2          # conf/config.yaml train.mask_fraction
 
 
 def parse():
@@ -67,13 +78,17 @@ def parse():
                     help="vocabulary of the synthetic graph: eicu = 50 / 114 / 100 (BASELINE configs 1-4), mimic = 50 / 200 / "
                          "100 (config 5: conf/config.yaml's MIMIC vocabulary caps)")
     ap.add_argument("--strong", action="store_true")
-    ap.add_argument("--no-strong-x1000", action="store_true", help="skip the x1000 patient-sharded sub-record")
+    ap.add_argument("--no-strong-x1000", action="store_true", help="skip the x1000 patient-sharded sub-records")
     ap.add_argument("--strong-scale", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=int, default=10, help="largest CPU sample (x1 is always timed as well)")
     ap.add_argument("--profile-ops", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replays")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel probe pass (profiler runs)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the fixed-mask, Trainer and segment-chain sub-records (profiler runs)")
+    ap.add_argument("--overlap", choices=["auto", "off", "on"], default="auto",
+                    help="vocab-side work of a layer on a side stream (mmgnn.model.set_overlap)")
     return ap.parse_args()
 
 
@@ -101,10 +116,14 @@ def setup_dist(args):
     return world, rank, torch.device("cuda", local)
 
 
-def build_workload(args, world, rank, dev, scale, strong):
-    cfg = {"model": {"architecture": "RGCN", "hidden_dim": args.dim, "num_layers": 2, "dropout": args.dropout,
-                     "use_batch_norm": True, "activation": "relu"}}
-    comm = mdist.ShardComm() if world > 1 else None
+def model_config(args, dim):
+    return {"model": {"architecture": "RGCN", "hidden_dim": dim, "num_layers": 2, "dropout": args.dropout,
+                      "use_batch_norm": True, "activation": "relu"}}
+
+
+def build_workload(args, world, rank, dev, scale, strong, dim, force_comm=False):
+    cfg = model_config(args, dim)
+    comm = mdist.ShardComm() if (world > 1 or force_comm) else None
     from mmgnn.synth import EICU, MIMIC_LIKE
     shape = MIMIC_LIKE if args.shape == "mimic" else EICU
     if strong and world > 1:
@@ -138,10 +157,10 @@ def build_workload(args, world, rank, dev, scale, strong):
     del perm
     pi, li = ei[0][tr].contiguous(), ei[1][tr].contiguous()
     y = g[LAB].edge_attr[tr].squeeze(-1).contiguous()
-    sup = torch.rand(tr.numel(), generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev) < 0.2
+    sup = torch.rand(tr.numel(), generator=torch.Generator(device=dev).manual_seed(1234 + rank), device=dev) < MASK_FRACTION
     wlab = torch.ones(int(g["lab"].num_nodes), device=dev)
     # F5: embeddings are not in the optimizer.  mmgnn.optim.Adam = torch.optim.Adam's arithmetic as ONE launch of
-    # mmg_adam_step over the flat parameter bucket
+    # mmg_adam_step_dev over the flat parameter bucket
     from mmgnn.optim import Adam
     opt = Adam([p for n, p in model.named_parameters() if not n.startswith("embeddings.")], lr=1e-3, weight_decay=1e-5)
     n_sup_global = torch.tensor([float(sup.sum())], device=dev)
@@ -195,7 +214,7 @@ def cpu_sample(args, s, n_warm, n_timed, cores):
     E = ei.shape[1]
     tr = torch.randperm(E, generator=torch.Generator().manual_seed(42))[: int(0.7 * E)].sort().values
     pi, li, y = ei[0][tr], ei[1][tr], ea[tr].squeeze(-1)
-    sup = torch.rand(tr.numel(), generator=torch.Generator().manual_seed(1234)) < 0.2
+    sup = torch.rand(tr.numel(), generator=torch.Generator().manual_seed(1234)) < MASK_FRACTION
     wl = torch.ones(gv.num_nodes["lab"])
     torch.set_num_threads(cores)
     times = []
@@ -209,21 +228,31 @@ def cpu_sample(args, s, n_warm, n_timed, cores):
 
 def cpu_baseline(args):
     """the CPU restatement beside the GPU figure -- x1 (the reference's own CPU-runnable case,
-    2 warm-up + 5 timed steps) and a bounded sample of the x100 workload (x<cpu-scale>; the full x100 step takes ~1 min
-    and ~40 GB on 16 cores, so it is run explicitly with --cpu-scale 100 and recorded in profiles/)."""
+    2 warm-up + 5 timed steps) and a bounded sample of the x100 workload (x<cpu-scale>).  The full x100 step (~1 min and
+    tens of GB on 16 cores) is not part of the default run: it was timed once with `--cpu-only --cpu-scale 100` and its
+    record (profiles/r3_cpu_x100.json) is quoted as `x100`."""
     cores = host_cores()
     s_big = max(1, min(args.cpu_scale, args.scale))
     x1 = cpu_sample(args, 1, 2, 5, cores)
     big = cpu_sample(args, s_big, 1 if s_big > 1 else 2, 3 if s_big > 1 else 5, cores) if s_big > 1 else x1
-    return {"value": big["edges_per_s"], "unit": "has_lab edges/s", "cores": cores, "kind": "port",
-            "cpu_model": cpu_model_name(),
-            "sample": f"oracle (pure PyTorch CPU restatement of the reference) fwd + weighted-MAE loss + bwd, no optimizer "
-                      f"step (the GPU step includes Adam), on the x{big['scale']} eICU-shape graph "
-                      f"({big['has_lab_edges']} has_lab edges, {args.dim}-d, dropout {args.dropout}): median of "
-                      f"{big['timed']} steps after {big['warmup']} warm-up, {cores} threads",
-            "x1": {"value": x1["edges_per_s"], "s_per_step": x1["s_per_step"], "has_lab_edges": x1["has_lab_edges"],
-                   "warmup": 2, "timed": 5},
-            "s_per_step": big["s_per_step"]}
+    out = {"value": big["edges_per_s"], "unit": "has_lab edges/s", "cores": cores, "kind": "port",
+           "cpu_model": cpu_model_name(),
+           "sample": f"oracle (pure PyTorch CPU restatement of the reference) fwd + weighted-MAE loss + bwd, no optimizer "
+                     f"step (the GPU step includes Adam), on the x{big['scale']} eICU-shape graph "
+                     f"({big['has_lab_edges']} has_lab edges, {args.dim}-d, dropout {args.dropout}): median of "
+                     f"{big['timed']} steps after {big['warmup']} warm-up, {cores} threads",
+           "x1": {"value": x1["edges_per_s"], "s_per_step": x1["s_per_step"], "has_lab_edges": x1["has_lab_edges"],
+                  "warmup": 2, "timed": 5},
+           "s_per_step": big["s_per_step"]}
+    path = os.path.join(REPO, "profiles", "r3_cpu_x100.json")
+    if os.path.exists(path):
+        try:
+            rec = json.load(open(path))
+            rec["source"] = "profiles/r3_cpu_x100.json (one untimed-warm-up-free step, run once on a GPU box's host cores)"
+            out["x100"] = rec
+        except Exception:
+            pass
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ kernel table
@@ -231,9 +260,10 @@ def alg_of(tag, M, N, K, fl, extra):
     """Algorithmic (compulsory) bytes and flops of one launch of a probed kernel family."""
     if tag == "linear_fwd":
         if fl & (16 | 64):
-            # BatchNorm / L2-norm backward inside the data-gradient GEMM: reads G and Y (and a second G: flag 128), writes
-            # dZ and dX
-            return 4 * ((4 if fl & 128 else 3) * M * K + N * K + M * N), 2 * M * N * K
+            # BatchNorm / L2-norm backward inside the data-gradient GEMM: reads G and Y (and a second G: flag 128; no G at
+            # all but a row list: flag 256), writes dZ and dX
+            n_in = 4 if fl & 128 else (2 if fl & 256 else 3)
+            return 4 * (n_in * M * K + N * K + M * N), 2 * M * N * K
         return 4 * (M * K + N * K + M * N * (2 if fl & 1 else 1)), 2 * M * N * K
     if tag == "linear_wgrad":
         return 4 * (M * N + M * K + N * K), 2 * M * N * K
@@ -242,20 +272,29 @@ def alg_of(tag, M, N, K, fl, extra):
         # tensor (read and written when the gather accumulates); E comes from the workload (extra)
         e = extra.get((tag, K, fl & (1 if tag == "gather_rows" else 8)), None)
         return (e if e is not None else 0), 0
+    if tag == "pair_head_fwd":
+        # per pair: 12 B of indices / output + its two 256-B first-layer rows are table reads (A: one row per patient,
+        # B: per lab) -> 12 n + 256 (P + L) compulsory; 2 * (64 * 32 + 32) FLOP per pair
+        return 12 * M + 256 * extra.get("pair_rows", 0), 4160 * M
+    if tag == "pair_head_bwd":
+        # M = the launch bound (all pairs of the head); the kernel visits the supervised ones only: 4 chained products
+        # of 2 * 64 * 32 FLOP per visited pair
+        n_vis = extra.get("pair_visited", M)
+        return 12 * n_vis + 2 * 256 * extra.get("pair_rows", 0), 16384 * n_vis
     return 0, 0
 
 
 def kernel_table(rows, n_steps, extra):
-    """probe rows -> {family: {shape key: stats}}; followers (slab sums) are folded into the op they finish."""
+    """probe rows -> list of per-(family, shape, flags) stats; followers (slab sums) are folded in by op_summary."""
     groups = {}
-    for ms, tag, M, N, K, fl in rows:
-        g = groups.setdefault((tag, M, N, K, fl), [0, 0.0])
+    for ms, tag, M, N, K, fl, sym in rows:
+        g = groups.setdefault((tag, M, N, K, fl), [0, 0.0, sym])
         g[0] += 1
         g[1] += ms
     table = []
-    for (tag, M, N, K, fl), (cnt, tot) in groups.items():
+    for (tag, M, N, K, fl), (cnt, tot, sym) in groups.items():
         b, f = alg_of(tag, M, N, K, fl, extra)
-        table.append(dict(kernel=tag, M=M, N=N, K=K, flags=fl, launches_per_step=cnt / n_steps, avg_ms=tot / cnt,
+        table.append(dict(kernel=tag, symbol=sym, M=M, N=N, K=K, flags=fl, launches_per_step=cnt / n_steps, avg_ms=tot / cnt,
                           ms_per_step=tot / n_steps, alg_bytes=b, alg_flops=f))
     return table
 
@@ -287,7 +326,7 @@ def agg_extra(w, D):
     K = total (gather) / total 32-padded (scatter) vocab rows of the fused relations; flags: 1 accumulate, 8 rowscale."""
     plan = w["plan"]
     P = plan.n_rows
-    extra = {}
+    extra = {"pair_rows": P + int(plan.num_nodes.get("lab", 0)), "pair_visited": int(w["sup"].sum())}
     rin = plan.rels_into_patient()
 
     def rel_bytes(rels, rowscale, colscale):
@@ -309,23 +348,55 @@ def agg_extra(w, D):
     return extra
 
 
-def load_traffic(args, scale, strong):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of THIS workload (never guessed); attached to a
-    kernel only when its algorithmic bytes match the profiled launch shape."""
-    if scale != 100 or args.dim != 128 or strong:
+def load_profile(args, scale, strong, what):
+    """Committed rocprofv3 PMC records of THIS workload -- keyed on (vocabulary, scale, width), never borrowed from another
+    one -- or ({}, None).  what = 'traffic' (FETCH_SIZE / WRITE_SIZE passes -> HBM bytes per launch, by kernel symbol) or
+    'pmc' (matrix-core / VALU / LDS counters, by kernel symbol)."""
+    if strong:
         return {}, None
-    for name in ("r2_traffic_x100.json",):
-        path = os.path.join(REPO, "profiles", name)
-        if os.path.exists(path):
-            try:
-                return json.load(open(path))["per_kernel"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2*FETCH+WRITE)"
-            except Exception:
-                pass
-    return {}, None
+    name = f"r3_{what}_{args.shape}_x{scale}_d{args.dim}.json"
+    path = os.path.join(REPO, "profiles", name)
+    if not os.path.exists(path):
+        return {}, None
+    try:
+        d = json.load(open(path))
+        return (d.get("all_kernels", d) if what == "traffic" else d), f"profiles/{name}"
+    except Exception:
+        return {}, None
 
 
-def measure(args, world, rank, dev, scale, strong, steps, warmup, want_kernels):
-    w = build_workload(args, world, rank, dev, scale, strong)
+def sym_key(sym):
+    return sym.replace(" ", "")
+
+
+def lookup(profile, sym):
+    want = sym_key(sym)
+    for k, v in profile.items():
+        if sym_key(k) == want:
+            return v
+    return None
+
+
+def timed_steps(step_fn, steps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step_fn()
+    barrier()
+    return time.perf_counter() - t0, out
+
+
+def make_graphed_step(w, world, warmup_capture, mask_fraction):
+    from mmgnn.train import PiecewiseGraphedTrainStep
+    return PiecewiseGraphedTrainStep(w["model"], w["plan"], w["pi"], w["li"], w["y"], w["wlab"], w["opt"],
+                                     None if mask_fraction is not None else w["sup"], w["comm"],
+                                     n_sup_global=None if mask_fraction is not None else w["n_sup"],
+                                     warmup=warmup_capture, mask_fraction=mask_fraction)
+
+
+def measure(args, world, rank, dev, scale, strong, dim, steps, warmup, want_kernels, want_fixed=False, force_comm=False):
+    w = build_workload(args, world, rank, dev, scale, strong, dim, force_comm=force_comm)
 
     def barrier():
         if world > 1:
@@ -336,12 +407,11 @@ def measure(args, world, rank, dev, scale, strong, steps, warmup, want_kernels):
     train_step(w)
     gstep = None
     if not args.no_graph:
-        # one hipGraph on a single GPU; sharded: a chain of hipGraph segments with the all-reduces between them
+        # one hipGraph on a single GPU; sharded: a chain of hipGraph segments with the all-reduces between them.  The
+        # step draws its own supervision subset (a new one per replay, as every epoch of the reference does)
         ok = torch.ones(1, device=dev)
         try:
-            from mmgnn.train import PiecewiseGraphedTrainStep
-            gstep = PiecewiseGraphedTrainStep(w["model"], w["plan"], w["pi"], w["li"], w["y"], w["wlab"], w["opt"],
-                                              w["sup"], w["comm"], n_sup_global=w["n_sup"], warmup=2 if world == 1 else 1)
+            gstep = make_graphed_step(w, world, 2 if world == 1 else 1, MASK_FRACTION)
         except Exception as e:   # capture is an optimisation, never a requirement
             print(f"[bench] rank {rank}: hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches",
                   file=sys.stderr)
@@ -352,38 +422,35 @@ def measure(args, world, rank, dev, scale, strong, steps, warmup, want_kernels):
         if float(ok) == 0.0:
             w["model"]._seed_dev = None
             gstep = None
-    step_fn = (lambda: gstep.step()) if gstep is not None else (lambda: train_step(w))
+
+    def eager_step():                  # (eager fallback: the subset is redrawn on the device here as well)
+        w["sup"] = torch.rand(w["pi"].numel(), device=dev) < MASK_FRACTION
+        w["supf"] = w["sup"].float()
+        n = w["supf"].sum(dtype=torch.float64).reshape(1)
+        if w["comm"] is not None:
+            torch.distributed.all_reduce(n)
+        w["n_sup"] = max(float(n), 1.0)
+        return train_step(w)
+
+    step_fn = (lambda: gstep.step()) if gstep is not None else eager_step
     for _ in range(max(warmup, 1)):
         step_fn()
 
     # ---- timed region: exactly K steps
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step_fn()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt, loss = timed_steps(step_fn, steps, barrier)
     loss_value = float(loss.detach())
+    n_items = (sum(1 for k, _ in gstep.items if k == "graph"), sum(1 for k, _ in gstep.items if k == "all_reduce")) \
+        if gstep is not None else (0, 0)
 
-    # ---- the same K steps with a NEW supervision mask before every step (train.py:150-176 redraws the 20 % subset every
-    # epoch, and an epoch of the full-batch reference is one step): set_mask uploads nothing (the masks are resident) but
-    # re-derives 1 / n_sup and the backward's pair lists, which the captured step does not contain.  Reported beside the
-    # headline, never as it.
-    dt_newmask = None
-    if gstep is not None and world == 1 and hasattr(gstep, "set_mask"):
-        gen = torch.Generator(device=dev).manual_seed(77)
-        masks = [torch.rand(w["pi"].numel(), generator=gen, device=dev) < 0.2 for _ in range(4)]
-        counts = [float(m.sum()) for m in masks]
-        gstep.set_mask(masks[0], counts[0])
-        gstep.step()
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(steps):
-            gstep.set_mask(masks[i % 4], counts[i % 4])
+    # ---- the same K steps with ONE fixed supervision mask (what round 2 reported as its headline): the per-step draw,
+    # count and pair-list selection are then outside the step
+    dt_fixed = None
+    if want_fixed and gstep is not None and world == 1:
+        del gstep
+        gstep = make_graphed_step(w, world, 1, None)
+        for _ in range(3):
             gstep.step()
-        barrier()
-        dt_newmask = time.perf_counter() - t1
-        gstep.set_mask(w["sup"], w["n_sup"])
+        dt_fixed, _ = timed_steps(lambda: gstep.step(), steps, barrier)
 
     # ---- per-kernel durations: eager steps of the same kernels, every big launch with its own HIP event pair.  Each
     # step is queued behind a ~10 ms spin on the device, so that the host (~25 us of Python per launch) runs ahead and the
@@ -394,84 +461,180 @@ def measure(args, world, rank, dev, scale, strong, steps, warmup, want_kernels):
         n_probe = max(1, min(steps, 5))
         # one stream for this pass: a kernel that shares the GPU with the vocab-side chain of the side stream (model.py
         # overlaps them in the timed region) would report the time it spent sharing, not its own
-        prev = os.environ.get("MMG_OVERLAP")
-        os.environ["MMG_OVERLAP"] = "0"
+        prev = mmodel.OVERLAP_MODE
+        mmodel.set_overlap("off")
         try:
-            ops.probe_arm(1 << 16)
+            ops.probe_arm(1 << 14)
             for _ in range(n_probe):
                 torch.cuda._sleep(20_000_000)
                 train_step(w)
             torch.cuda.synchronize()
             rows = ops.probe_read()
         finally:
-            if prev is None:
-                os.environ.pop("MMG_OVERLAP", None)
-            else:
-                os.environ["MMG_OVERLAP"] = prev
+            mmodel.set_overlap(prev)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     edges = torch.tensor([float(w["E"])], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(edges)
-    launch = ("eager" if gstep is None else "hipGraph replay" if world == 1 else
-              f"{sum(1 for k, _ in gstep.items if k == 'graph')} hipGraph segments + "
-              f"{sum(1 for k, _ in gstep.items if k == 'all_reduce')} all-reduces per step")
+    launch = ("eager" if step_fn is eager_step else "hipGraph replay" if n_items[1] == 0 else
+              f"{n_items[0]} hipGraph segments + {n_items[1]} all-reduces per step")
     rec = dict(dt=float(tmax), edges=float(edges), loss=loss_value, rows=rows, n_probe=n_probe, launch=launch,
-               dt_newmask=dt_newmask,
-               P_loc=int(w["plan"].n_rows), pairs=int(w["pi"].numel()), extra=agg_extra(w, args.dim))
+               dt_fixed=dt_fixed, P_loc=int(w["plan"].n_rows), pairs=int(w["pi"].numel()), extra=agg_extra(w, dim))
     del w, gstep, step_fn
     gc.collect()
     torch.cuda.empty_cache()
     return rec
 
 
+def measure_trainer(args, dev, scale, dim, steps):
+    """The step through the reference's call surface: mmgnn.train.EdgeMasker + Trainer (src/train.py:37-176, 183-561) on the
+    same synthetic graph -- Trainer.train_epoch's captured device step alone, the captured validation pass, and the loop
+    body of Trainer.train (train epoch + validation + ONE host read of both losses)."""
+    from mmgnn.train import EdgeMasker, Trainer
+    from mmgnn.synth import EICU, MIMIC_LIKE
+    g = make_graph(scale, seed=0, device=dev, shape=MIMIC_LIKE if args.shape == "mimic" else EICU)
+    cfg = dict(model_config(args, dim))
+    cfg["train"] = {"optimizer": {"type": "adam", "lr": 1e-3, "weight_decay": 1e-5},
+                    "lr_scheduler": {"enabled": True, "type": "reduce_on_plateau", "factor": 0.5, "patience": 10},
+                    "loss": "mae", "epochs": steps, "early_stopping_patience": 10 ** 9, "train_split": 0.7, "val_split": 0.15,
+                    "test_split": 0.15, "mask_fraction": MASK_FRACTION, "seed": 42}
+    cfg["logging"] = {"save_checkpoints": False, "log_interval": 0}
+    masker = EdgeMasker(g, 0.7, 0.15, 0.15, MASK_FRACTION, 42)          # no generator: the reference's per-epoch redraw
+    torch.manual_seed(42)
+    model = build_model(cfg, (g.node_types, g.edge_types), None)
+    trainer = Trainer(model, g, masker, cfg, dev)                       # moves model and graph (train.py:605-622)
+    for _ in range(3):
+        trainer._train_epoch_device()
+        trainer._validate_device("val")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer._train_epoch_device()
+    torch.cuda.synchronize()
+    t_train = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer._validate_device("val")
+    torch.cuda.synchronize()
+    t_val = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):                 # the loop body of Trainer.train: two replays, one host read
+        trainer._train_epoch_device()
+        trainer._validate_device("val")
+        tl, vl = trainer._losses.tolist()
+    torch.cuda.synchronize()
+    t_epoch = (time.perf_counter() - t0) / steps
+    rec = {"train_epoch_ms": 1e3 * t_train, "validate_ms": 1e3 * t_val, "epoch_ms": 1e3 * t_epoch, "epochs_timed": steps,
+           "train_loss": tl, "val_loss": vl, "train_pairs": int(trainer._dstep.pi.numel()),
+           "val_pairs": int(trainer._deval["val"].pi.numel()),
+           "path": "mmgnn.train.Trainer._train_epoch_device / _validate_device: what Trainer.train_epoch, Trainer.validate and "
+                   "Trainer.train run; the supervision mask is drawn inside the captured step (masker without a generator)"}
+    del trainer, model, masker, g
+    gc.collect()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def measure_chain(args, dev, scale, dim, steps):
+    """The step as a sharded run launches it -- hipGraph segments cut at every collective, RCCL all-reduces between them --
+    on ONE GPU (world_size-1 `nccl` group): its time minus the single graph's is the fixed cost of the launch scheme."""
+    import socket
+    if not torch.distributed.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                             device_id=dev)
+    try:
+        rec = measure(args, 1, 0, dev, scale, False, dim, steps, 3, False, force_comm=True)
+    finally:
+        torch.distributed.destroy_process_group()
+    return rec
+
+
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: libraries that chat on fd 1 (RCCL prints a version banner when a
+    # communicator is created) are sent to stderr for the whole run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    mmodel.set_overlap(args.overlap)
     world, rank, dev = setup_dist(args)
-    head = measure(args, world, rank, dev, args.scale, args.strong, args.steps, args.warmup, not args.no_kernels)
-    strong_rec = None
+    head = measure(args, world, rank, dev, args.scale, args.strong, args.dim, args.steps, args.warmup, not args.no_kernels,
+                   want_fixed=not args.no_extras)
+    strong_recs = {}
     if not args.no_strong_x1000 and not (args.strong and args.scale == args.strong_scale):
-        s_steps = max(3, min(args.steps, 10))
-        strong_rec = measure(args, world, rank, dev, args.strong_scale, True, s_steps, min(args.warmup, 2), False)
-        strong_rec["steps"] = s_steps
+        s_steps = max(3, min(args.steps, 5))
+        for d in sorted({256, args.dim}, reverse=True):          # config 4 (256-d) and north_star's 128-d curve
+            r = measure(args, world, rank, dev, args.strong_scale, True, d, s_steps, 2, False)
+            r["steps"] = s_steps
+            strong_recs[d] = r
+    trainer_rec = chain_rec = None
+    if world == 1 and not args.no_extras and not args.no_graph:
+        try:
+            trainer_rec = measure_trainer(args, dev, args.scale, args.dim, max(5, min(args.steps, 30)))
+        except Exception as e:
+            trainer_rec = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            chain_rec = measure_chain(args, dev, args.scale, args.dim, max(5, min(args.steps, 30)))
+        except Exception as e:
+            chain_rec = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         dt, total_edges = head["dt"], head["edges"]
         ms_per_step = 1e3 * dt / args.steps
         out = {
-            "metric": "has_lab edges/s, one full training step (fwd + weighted-MAE loss + bwd + Adam) of "
-                      "predict_lab_values on the full hetero-graph",
+            "metric": "has_lab edges/s, one full training step (new 20 % supervision mask + fwd + weighted-MAE loss + bwd + "
+                      "Adam) of predict_lab_values on the full hetero-graph",
             "value": total_edges * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (("eICU-shape" if args.shape == "eicu" else "MIMIC-vocabulary (50 / 200 / 100)")
                                     + f" synthetic hetero-graph x{args.scale}"
                                     + (" total, patient-sharded" if args.strong else " per GPU")
-                                    + f", {args.dim}-d, 2 SAGE layers x 6 relations, dropout {args.dropout}"),
+                                    + f", {args.dim}-d, 2 SAGE layers x 6 relations, dropout {args.dropout}, supervision "
+                                      f"mask ({MASK_FRACTION:.0%}) redrawn inside every step"),
                        "patients_per_gpu": head["P_loc"], "has_lab_edges_total": int(total_edges),
                        "train_pairs_rank0": head["pairs"], "hidden_dim": args.dim,
                        "parallelism": f"patient-shard x{world}" if world > 1 else "single GPU",
                        "launch": head["launch"]},
             "loss": head["loss"],
         }
-        if head.get("dt_newmask") is not None:
-            out["new_supervision_mask_every_step"] = {
-                "ms_per_step": 1e3 * head["dt_newmask"] / args.steps,
-                "note": "the same replays with set_mask(a resident random 20 % mask) before every step: the reference redraws "
-                        "the supervision subset every epoch = every full-batch step (train.py:150-176); the normaliser and "
-                        "the backward's pair lists are re-derived outside the captured step"}
+        if head.get("dt_fixed") is not None:
+            out["fixed_supervision_mask"] = {
+                "ms_per_step": 1e3 * head["dt_fixed"] / args.steps,
+                "note": "the same replays with ONE resident supervision mask (round 2's headline): the draw, its count and "
+                        "the backward's pair-list selection are outside the step"}
+        if trainer_rec is not None:
+            if "train_epoch_ms" in trainer_rec:
+                trainer_rec["train_epoch_vs_headline"] = trainer_rec["train_epoch_ms"] / ms_per_step
+            out["trainer_epoch"] = trainer_rec
+        if chain_rec is not None:
+            if "dt" in chain_rec:
+                cms = 1e3 * chain_rec["dt"] / max(5, min(args.steps, 30))
+                out["chain_overhead_ms"] = cms - ms_per_step
+                out["chain"] = {"ms_per_step": cms, "launch": chain_rec["launch"],
+                                "note": "world_size-1 RCCL group on this GPU: the sharded launch scheme (segment replays + "
+                                        "all-reduces issued from Python) without any shard imbalance or wire time"}
+            else:
+                out["chain"] = chain_rec
         if head["rows"]:
             table = kernel_table(head["rows"], head["n_probe"], head["extra"])
-            traffic, tsrc = load_traffic(args, args.scale, args.strong)
+            traffic, tsrc = load_profile(args, args.scale, args.strong, "traffic")
+            pmc, psrc = load_profile(args, args.scale, args.strong, "pmc")
             fam = {}
             for t in table:
                 fam[FOLLOWERS.get(t["kernel"], t["kernel"])] = fam.get(FOLLOWERS.get(t["kernel"], t["kernel"]), 0.0) + t["ms_per_step"]
             dominant = max(fam.items(), key=lambda kv: kv[1])[0]
             if args.profile_ops:
                 for t in sorted(table, key=lambda t: -t["ms_per_step"]):
-                    print(f"  {t['kernel']:20s} M={t['M']:8d} N={t['N']:4d} K={t['K']:4d} fl={t['flags']:2d} "
-                          f"x{t['launches_per_step']:5.1f}/step  {1e3 * t['avg_ms']:8.1f} us  {t['ms_per_step']:7.3f} ms/step",
-                          file=sys.stderr)
+                    print(f"  {t['kernel']:20s} M={t['M']:8d} N={t['N']:4d} K={t['K']:4d} fl={t['flags']:3d} "
+                          f"x{t['launches_per_step']:5.1f}/step  {1e3 * t['avg_ms']:8.1f} us  {t['ms_per_step']:7.3f} ms/step  "
+                          f"{t['symbol']}", file=sys.stderr)
             d = op_summary(table, dominant)
             t_ms = d.get("avg_ms_with_follower", d["avg_ms"])
             hbm_frac = d["hbm_frac"] or 0.0
@@ -482,19 +645,19 @@ def main():
             else:
                 roof = {"bound": "hbm", "achieved": d["alg_bytes"] / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": hbm_frac, "traffic": None}
-            tr = traffic.get("linear_bnbwd" if dominant == "linear_fwd" and d["flags"] & (16 | 64) else dominant)
-            if tr and d["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / d["alg_bytes"] < 2.0:
+            tr = lookup(traffic, d["symbol"])
+            if tr and d["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / d["alg_bytes"] < 3.0:
                 roof["traffic"] = tr["hbm_bytes_per_launch"]
-                roof["traffic_source"] = tsrc
-            roof.update({"kernel": dominant, "shape": [d["M"], d["N"], d["K"]], "flags": d["flags"],
-                         "op_ms_per_step": fam[dominant], "avg_launch_ms": t_ms,
+                roof["traffic_source"] = tsrc + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, 2*FETCH+WRITE)"
+            roof.update({"kernel": d["symbol"], "family": dominant, "shape": [d["M"], d["N"], d["K"]], "flags": d["flags"],
+                         "family_ms_per_step": fam[dominant], "avg_launch_ms": t_ms,
                          "launches_per_step": d["launches_per_step"],
                          "algorithmic_bytes_per_launch": d["alg_bytes"], "algorithmic_flops_per_launch": d["alg_flops"],
                          "timing": "HIP start/stop events attached to each kernel launch (hipExtLaunchKernelGGL), "
                                    f"{head['n_probe']} eager single-stream steps of the same kernels right after the timed "
                                    "region; slab-sum kernels are added to the op they finish"})
             # self-checks: a kernel cannot take longer than the step that contains it, and a roofline fraction is in (0, 1]
-            assert roof["op_ms_per_step"] <= ms_per_step, (roof, ms_per_step)
+            assert roof["family_ms_per_step"] <= ms_per_step, (roof, ms_per_step)
             assert 0.0 < roof["frac"] <= 1.0, roof
             out["roofline"] = roof
             ks = {}
@@ -506,7 +669,7 @@ def main():
                 s_ = op_summary(table, op, fm, fv)
                 if s_ is None:
                     continue
-                e = {"avg_launch_us": 1e3 * s_.get("avg_ms_with_follower", s_["avg_ms"]),
+                e = {"kernel": s_["symbol"], "avg_launch_us": 1e3 * s_.get("avg_ms_with_follower", s_["avg_ms"]),
                      "launches_per_step": s_["launches_per_step"], "ms_per_step": fam.get(op) if fm is None else s_["ms_per_step"],
                      "shape": [s_["M"], s_["N"], s_["K"]]}
                 if "follower_avg_ms" in s_:
@@ -515,29 +678,61 @@ def main():
                     e["algorithmic_bytes"] = s_["alg_bytes"]
                     e["hbm_frac"] = s_["hbm_frac"]
                     assert 0.0 < e["hbm_frac"] <= 1.0, (name, e)
-                tr = traffic.get({"scatter_rowscale": "scatter_rows_rowscale", "linear_bnbwd": "linear_bnbwd"}.get(name, op))
-                if tr and s_["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / s_["alg_bytes"] < 2.0:
+                if s_["alg_flops"]:
+                    e["algorithmic_flops"] = s_["alg_flops"]
+                    if s_["mfma_frac"] is not None:
+                        e["mfma_frac"] = s_["mfma_frac"]
+                tr = lookup(traffic, s_["symbol"])
+                if tr and s_["alg_bytes"] and 0.5 < tr["hbm_bytes_per_launch"] / s_["alg_bytes"] < 3.0:
                     e["traffic"] = tr["hbm_bytes_per_launch"]
-                    fol = traffic.get({"scatter_rows": "scatter_reduce", "linear_wgrad": "linear_wgrad_reduce"}.get(op))
+                    folk = {"scatter_rows": "mmg_k_reduce_slabs<EpiScatter>", "linear_wgrad": "mmg_k_reduce_slabs<EpiStore>"}.get(op)
+                    fol = lookup(traffic, folk) if folk else None
                     if fol and "slab_sum_us" in e:
                         e["traffic"] += fol["hbm_bytes_per_launch"]       # the slab sum that finishes the op
-                    e["traffic_kernel"] = tr["kernel"]
+                    e["traffic_source"] = tsrc
+                pc = lookup(pmc, s_["symbol"])
+                if pc:          # issue fractions of the kernel's own wave time (PMC pass of this workload)
+                    wc = pc.get("SQ_WAVE_CYCLES") or 0
+                    if wc:
+                        if pc.get("SQ_ACTIVE_INST_VALU") is not None:
+                            e["valu_issue_frac"] = 4.0 * pc["SQ_ACTIVE_INST_VALU"] / wc
+                        if pc.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None and pc.get("SQ_BUSY_CYCLES"):
+                            e["mfma_busy_frac"] = pc["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * pc["SQ_BUSY_CYCLES"])
+                        e["pmc_source"] = psrc
                 ks[name] = e
             out["kernels"] = ks
             out["kernel_ms_per_step_all_probed"] = sum(fam.values())
-        if strong_rec is not None:
-            out["strong_x1000"] = {
-                "value": strong_rec["edges"] * strong_rec["steps"] / strong_rec["dt"], "unit": "edges/s",
-                "ms_per_step": 1e3 * strong_rec["dt"] / strong_rec["steps"], "steps": strong_rec["steps"],
-                "scaling": "strong", "n_gpus": world, "patients_per_gpu": strong_rec["P_loc"],
-                "has_lab_edges_total": int(strong_rec["edges"]), "launch": strong_rec["launch"],
-                "workload": f"ONE eICU-shape x{args.strong_scale} graph, patient-sharded over {world} GPU(s), {args.dim}-d"}
+        for d_, r in strong_recs.items():
+            key = "strong_x1000" if d_ == 256 else f"strong_x1000_d{d_}"
+            out[key] = {
+                "value": r["edges"] * r["steps"] / r["dt"], "unit": "edges/s",
+                "ms_per_step": 1e3 * r["dt"] / r["steps"], "steps": r["steps"],
+                "scaling": "strong", "n_gpus": world, "patients_per_gpu": r["P_loc"], "hidden_dim": d_,
+                "has_lab_edges_total": int(r["edges"]), "launch": r["launch"],
+                "workload": f"ONE eICU-shape x{args.strong_scale} graph, patient-sharded over {world} GPU(s), {d_}-d"
+                            + (" (BASELINE.json config 4)" if d_ == 256 and args.strong_scale == 1000 else "")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
         torch.distributed.destroy_process_group()
 
 
+def cpu_only():
+    """`python bench.py --cpu-only --cpu-scale S`: one oracle step (no warm-up) on the x<S> graph -> one JSON line; the
+    record kept as profiles/r3_cpu_x100.json comes from this (S = 100)."""
+    args = parse()
+    cores = host_cores()
+    r = cpu_sample(args, args.cpu_scale, 0, 1, cores)
+    print(json.dumps({"value": r["edges_per_s"], "unit": "has_lab edges/s", "s_per_step": r["s_per_step"], "cores": cores,
+                      "cpu_model": cpu_model_name(), "scale": r["scale"], "has_lab_edges": r["has_lab_edges"],
+                      "warmup": 0, "timed": 1, "dim": args.dim, "dropout": args.dropout}))
+
+
 if __name__ == "__main__":
-    main()
+    if "--cpu-only" in sys.argv:
+        sys.argv.remove("--cpu-only")
+        cpu_only()
+    else:
+        main()

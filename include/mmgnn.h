@@ -308,7 +308,10 @@ int mmg_bn_bwd_apply_rows(const float* G_rows, const float* Y, const int64_t* ro
 #define MMG_PROBE_BN_BWD_APPLY 10
 #define MMG_PROBE_ELEMENTWISE 11
 int mmg_probe_arm(int n_launches);
-int mmg_probe_read(float* ms, int* tag, int64_t* M, int* N, int* K, int* flags, int cap);
+#define MMG_PROBE_NAME_LEN 128
+/* names (nullable): cap * MMG_PROBE_NAME_LEN bytes; entry i receives the instantiated kernel symbol of launch i, e.g.
+ * "k_linear_bnbwd_x6<128, 4, 0>" -- the name rocprofv3 lists the same launch under. */
+int mmg_probe_read(float* ms, int* tag, int64_t* M, int* N, int* K, int* flags, char* names, int cap);
 
 /* Row L2 normalisation, F.normalize(p=2, dim=1, eps): out = z / max(||z||, eps); rnorm = 1/max(..) */
 int mmg_l2norm_fwd(const float* Z, float* out, float* rnorm, int64_t M, int N, float eps, void* stream);

@@ -117,7 +117,7 @@ SIGNATURES = {
     "mmg_affine_act_drop": (C.c_int, [_vp, _P(PrologueT), _vp, _i64, _i32, _vp]),
     "mmg_affine_act_drop_rows": (C.c_int, [_vp, _P(PrologueT), _vp, _i64, _vp, _i32, _vp]),
     "mmg_probe_arm": (C.c_int, [_i32]),
-    "mmg_probe_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32]),
+    "mmg_probe_read": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "mmg_bn_bwd_stats2": (C.c_int, [_vp, _vp, _vp, _P(PrologueT), _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _vp, C.c_size_t, _vp]),
     "mmg_bn_bwd_apply2": (C.c_int, [_vp, _vp, _vp, _P(PrologueT), _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _i64,
                                     _i32, _vp]),

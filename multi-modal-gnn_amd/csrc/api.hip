@@ -3,6 +3,10 @@
 #include <atomic>
 #include <mutex>
 #include <vector>
+#include <string>
+#include <string.h>
+#include <ctype.h>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -21,7 +25,7 @@ extern "C" const char* mmg_last_error(void) { return g_err; }
 // per-thread hook would miss half of the step); it is mutex-guarded, never armed by the product path, and costs the
 // unarmed launch path one relaxed atomic load.
 namespace {
-struct ProbeEntry { hipEvent_t e0, e1; int tag; int64_t M; int N, K, flags; };
+struct ProbeEntry { hipEvent_t e0, e1; int tag; int64_t M; int N, K, flags; const char* text; const char* launcher; };
 std::mutex g_probe_mu;
 std::vector<ProbeEntry> g_probe;
 std::atomic<int> g_probe_left{0};
@@ -31,11 +35,12 @@ void probe_clear() {
 }
 }  // namespace
 
-bool mmg_probe_take(int tag, int64_t M, int N, int K, int flags, hipEvent_t* e0, hipEvent_t* e1) {
+bool mmg_probe_take(int tag, int64_t M, int N, int K, int flags, const char* kernel_text, const char* launcher,
+                    hipEvent_t* e0, hipEvent_t* e1) {
   if (g_probe_left.load(std::memory_order_relaxed) <= 0) return false;
   std::lock_guard<std::mutex> lk(g_probe_mu);
   if (g_probe_left.load(std::memory_order_relaxed) <= 0) return false;
-  ProbeEntry e{nullptr, nullptr, tag, M, N, K, flags};
+  ProbeEntry e{nullptr, nullptr, tag, M, N, K, flags, kernel_text, launcher};
   if (hipEventCreate(&e.e0) != hipSuccess) return false;
   if (hipEventCreate(&e.e1) != hipSuccess) { (void)hipEventDestroy(e.e0); return false; }
   g_probe.push_back(e);
@@ -51,7 +56,58 @@ extern "C" int mmg_probe_arm(int n_launches) {
   return MMG_OK;
 }
 
-extern "C" int mmg_probe_read(float* ms, int* tag, int64_t* M, int* N, int* K, int* flags, int cap) {
+// Instantiated kernel symbol of a probed launch, as rocprofv3 prints it: the kernel expression of the launch site,
+// e.g. "(k_linear_fwd_x6<K, WN, PRO, ACC, L2>)", with the template parameters bound by the launcher's
+// __PRETTY_FUNCTION__ suffix "[K = 128, WN = 4, PRO = false, ACC = false, L2 = false]" -> "k_linear_fwd_x6<128, 4, false, false, false>".
+static void probe_symbol(const char* text, const char* launcher, char* out, int cap) {
+  out[0] = 0;
+  if (!text || cap <= 1) return;
+  std::vector<std::pair<std::string, std::string>> bind;
+  if (launcher) {
+    const char* lb = strrchr(launcher, '[');
+    const char* rb = lb ? strrchr(lb, ']') : nullptr;
+    if (lb && rb) {
+      std::string body(lb + 1, rb);
+      size_t pos = 0;
+      while (pos < body.size()) {
+        size_t eq = body.find(" = ", pos);
+        if (eq == std::string::npos) break;
+        size_t end = eq + 3;
+        int depth = 0;
+        for (; end < body.size(); ++end) {                 // a value may itself contain commas inside <> or ()
+          const char c = body[end];
+          if (c == '<' || c == '(') ++depth;
+          else if (c == '>' || c == ')') --depth;
+          else if (c == ',' && depth == 0) break;
+        }
+        std::string name = body.substr(pos, eq - pos), val = body.substr(eq + 3, end - eq - 3);
+        while (!name.empty() && name.front() == ' ') name.erase(0, 1);
+        bind.emplace_back(name, val);
+        pos = end + 1;
+      }
+    }
+  }
+  std::string t(text), r;
+  for (size_t i = 0; i < t.size();) {
+    const char c = t[i];
+    if (isalpha((unsigned char)c) || c == '_') {
+      size_t j = i;
+      while (j < t.size() && (isalnum((unsigned char)t[j]) || t[j] == '_')) ++j;
+      std::string id = t.substr(i, j - i);
+      for (auto& b : bind) if (b.first == id) { id = b.second; break; }
+      r += id;
+      i = j;
+    } else {
+      r += c;
+      ++i;
+    }
+  }
+  while (!r.empty() && (r.front() == '(' || r.front() == ' ' || r.front() == '&')) r.erase(0, 1);
+  while (!r.empty() && (r.back() == ')' || r.back() == ' ')) r.pop_back();
+  snprintf(out, (size_t)cap, "%s", r.c_str());
+}
+
+extern "C" int mmg_probe_read(float* ms, int* tag, int64_t* M, int* N, int* K, int* flags, char* names, int cap) {
   std::lock_guard<std::mutex> lk(g_probe_mu);
   g_probe_left.store(0, std::memory_order_relaxed);
   int n = 0;
@@ -59,6 +115,7 @@ extern "C" int mmg_probe_read(float* ms, int* tag, int64_t* M, int* N, int* K, i
     float t = 0.f;
     if (n < cap && hipEventSynchronize(e.e1) == hipSuccess && hipEventElapsedTime(&t, e.e0, e.e1) == hipSuccess) {
       ms[n] = t; tag[n] = e.tag; M[n] = e.M; N[n] = e.N; K[n] = e.K; flags[n] = e.flags;
+      if (names) probe_symbol(e.text, e.launcher, names + (size_t)n * MMG_PROBE_NAME_LEN, MMG_PROBE_NAME_LEN);
       ++n;
     }
   }

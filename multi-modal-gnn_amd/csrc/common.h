@@ -59,11 +59,14 @@ struct MmgMaxLds {
 // Measurement hook (mmg_probe_arm / mmg_probe_read, include/mmgnn.h): while armed, a launch made through MMG_LAUNCH
 // carries a HIP start / stop event pair on the kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end
 // timestamps on its stream).  Process-wide and mutex-guarded (api.hip); unarmed cost: one relaxed atomic load.
-bool mmg_probe_take(int tag, int64_t M, int N, int K, int flags, hipEvent_t* e0, hipEvent_t* e1);
+// (the record also keeps what names the INSTANTIATED kernel: the kernel expression as written at the launch site and the
+// __PRETTY_FUNCTION__ of the launcher, whose "[K = 128, WN = 4, ...]" suffix binds the template parameters it mentions)
+bool mmg_probe_take(int tag, int64_t M, int N, int K, int flags, const char* kernel_text, const char* launcher,
+                    hipEvent_t* e0, hipEvent_t* e1);
 #define MMG_LAUNCH(tag, pM, pN, pK, pflags, kernel, grid, block, lds, st, ...)                         \
   do {                                                                                                \
     hipEvent_t e0__, e1__;                                                                            \
-    if (mmg_probe_take(tag, pM, pN, pK, pflags, &e0__, &e1__))                                        \
+    if (mmg_probe_take(tag, pM, pN, pK, pflags, #kernel, __PRETTY_FUNCTION__, &e0__, &e1__))          \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0__, e1__, 0, __VA_ARGS__);                \
     else                                                                                              \
       hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                  \

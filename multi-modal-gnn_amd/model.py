@@ -16,7 +16,6 @@ Algebra used (exact up to fp32 re-association, inside the 1e-4 parity bar):
 from __future__ import annotations
 
 import logging
-import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -29,6 +28,17 @@ from .ops import Pro
 
 EdgeType = Tuple[str, str, str]
 SITE_CONV = 16
+# Vocab-side work of a layer on a side stream beside the patient-side kernels: "auto" = from 16 k patient rows up (below
+# that every kernel is launch-sized and the fork / join events cost more than they hide), "off" = one stream, "on" = always.
+OVERLAP_MODE = "auto"
+
+
+def set_overlap(mode: str):
+    """'auto' | 'off' | 'on' -- see OVERLAP_MODE (bench.py's single-stream probe pass and the tests switch it)."""
+    global OVERLAP_MODE
+    if mode not in ("auto", "off", "on"):
+        raise ValueError(f"overlap mode must be 'auto', 'off' or 'on', got {mode!r}")
+    OVERLAP_MODE = mode
 
 
 def _mangle(et: EdgeType) -> str:
@@ -207,6 +217,9 @@ class HeteroRGCN(nn.Module):
         n = pi.numel()
         if n and (int(pi.min()) < 0 or int(pi.max()) >= n_rows):
             raise IndexError("patient_indices out of range")
+        n_lab = self.embeddings["lab"].weight.shape[0] if "lab" in self.embeddings else None
+        if n and n_lab is not None and (int(li.min()) < 0 or int(li.max()) >= n_lab):
+            raise IndexError("lab_indices out of range")          # (the reference's final_embeds['lab'][lab_indices])
         ei = torch.stack([pi.to(torch.int64), li.to(torch.int64)]).contiguous()
         _, li_sorted, perm = ops.csr_build(ei, n_rows, 0)
         perm64 = perm.to(torch.int64)
@@ -293,10 +306,8 @@ class _Run:
         self.lazy_final = False      # predict mode: the final patient activations stay folded (see _LazyAct)
         # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
         # dependency chain) runs on a side stream underneath the patient-side kernels of the same layer
-        # (MMG_OVERLAP=0: one stream).  Sharded runs keep every collective on the main stream.
-        # (below ~16 k patient rows every kernel is launch-sized and the fork / join events cost more than they hide)
-        ov = os.environ.get("MMG_OVERLAP", "1")                     # 0 = never, 2 = always (tests), else by size
-        self.overlap = ov != "0" and (ov == "2" or self.plan.n_rows >= 16384)
+        # (OVERLAP_MODE / set_overlap).  Sharded runs keep every collective on the main stream.
+        self.overlap = OVERLAP_MODE == "on" or (OVERLAP_MODE == "auto" and self.plan.n_rows >= 16384)
         if self.overlap:
             if getattr(model, "_side_stream", None) is None:
                 model._side_stream = torch.cuda.Stream(device=self.dev)

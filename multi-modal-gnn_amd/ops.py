@@ -97,15 +97,20 @@ def probe_arm(n: int):
     check(_lib.load().mmg_probe_arm(int(n)), "mmg_probe_arm")
 
 
-def probe_read(cap: int = 1 << 18):
-    """-> list of (ms, family name, M, N, K, flags) of the probed launches (flags: 1 accumulate, 4 prologue, 8 rowscale, 16 BatchNorm backward staged in the GEMM, 32 L2-norm epilogue, 64 L2-norm backward staged, 128 two upstream gradients)."""
+PROBE_NAME_LEN = 128
+
+
+def probe_read(cap: int = 1 << 16):
+    """-> list of (ms, family name, M, N, K, flags, kernel symbol) of the probed launches (flags: 1 accumulate, 4 prologue, 8 rowscale, 16 BatchNorm backward staged in the GEMM, 32 L2-norm epilogue, 64 L2-norm backward staged, 128 two upstream gradients, 256 row-list upstream gradient)."""
     import numpy as np
     ms = np.zeros(cap, np.float32); tag = np.zeros(cap, np.int32); M = np.zeros(cap, np.int64)
     N = np.zeros(cap, np.int32); K = np.zeros(cap, np.int32); fl = np.zeros(cap, np.int32)
+    names = np.zeros(cap * PROBE_NAME_LEN, np.uint8)
     n = _lib.load().mmg_probe_read(ms.ctypes.data, tag.ctypes.data, M.ctypes.data, N.ctypes.data, K.ctypes.data,
-                                   fl.ctypes.data, cap)
-    return [(float(ms[i]), PROBE_TAGS.get(int(tag[i]), str(int(tag[i]))), int(M[i]), int(N[i]), int(K[i]), int(fl[i]))
-            for i in range(n)]
+                                   fl.ctypes.data, names.ctypes.data, cap)
+    nm = names.reshape(cap, PROBE_NAME_LEN)
+    return [(float(ms[i]), PROBE_TAGS.get(int(tag[i]), str(int(tag[i]))), int(M[i]), int(N[i]), int(K[i]), int(fl[i]),
+             bytes(nm[i]).split(b"\0", 1)[0].decode("ascii", "replace")) for i in range(n)]
 
 
 _WS = {}

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_io import checksum, load, rel_close, rel_err, t, unpack_mask
+from golden_io import grad_close, checksum, load, rel_close, rel_err, t, unpack_mask
 from oracle import fixtures as fx
 from oracle import model as om
 from oracle import train as ot
@@ -102,6 +102,8 @@ def test_train_step_matches_reference_golden(dev, tag, n, hidden):
         if f"train/grad/{k}" in gold:
             ref = t(gold[f"train/grad/{k}"])
             assert float((gr - ref).abs().max()) <= 2e-4 * float(ref.abs().max()) + 1e-6 * gmax, k
+            ok, worst, _ = grad_close(gr, ref, floor=1e-6 * gmax)                       # ... and per element at the scale of its own row
+            assert ok, f"{k}: element-wise gradient error {worst:.2f} x the bar"
         cs, cr = checksum(gr), t(gold[f"train/grad_sum/{k}"])
         assert abs(float(cs[1] - cr[1])) <= 2e-4 * float(cr[1]) + 1e-6 * gmax * gr.numel(), k
     for k, b in model.named_buffers():
@@ -191,9 +193,9 @@ def test_degree_gate_extremes_in_training(dev, thr):
 @pytest.mark.parametrize("p", [0.0, 0.2])
 def test_train_step_with_side_stream_overlap(dev, p, monkeypatch):
     """The vocab-side work of every layer on a side stream (on by default only above 16 k patients): same results."""
-    monkeypatch.setenv("MMG_OVERLAP", "2")
-    test_train_step_matches_oracle_with_injected_dropout(dev, p)
     import mmgnn.model as mm
+    monkeypatch.setattr(mm, "OVERLAP_MODE", "on")
+    test_train_step_matches_oracle_with_injected_dropout(dev, p)
     n, hidden = (500, 20, 25, 18), 128
     model, g, gd, *_ = make(dev, n, hidden)
     assert mm._Run(model, gd).overlap
@@ -256,11 +258,22 @@ def _train_step_vs_oracle(dev, n, hidden, p=0.0, sup_seed=11, **model_kw):
         sd64, gv, pi, li, y.double(), w.double(), sup, p=p, masks=masks64, num_layers=L,
         use_batch_norm=model_kw.get("use_batch_norm", True), activation=model_kw.get("activation", "relu"))
     gmax = max(float(v.abs().max()) for v in ograds.values())
+    n_tied, n_el = 0, 0
     for k, pm in model.named_parameters():
         gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
         tie = (ograds[k].double() - ograds64[k]).abs()
+        # a tie only counts where the two oracle runs disagree by more than rounding (>= 1e-5 of the tensor's max): the
+        # slack is for flipped ReLU gradients, not a blanket allowance of the fp32 oracle's own rounding error
+        tie = torch.where(tie > 1e-5 * float(ograds[k].abs().max()), tie, torch.zeros_like(tie))
         tol = 2e-4 * float(ograds[k].abs().max()) + 1e-6 * gmax + 1.5 * tie
         assert bool(((gr - ograds[k]).abs().double() <= tol).all()), k
+        ok, worst, nt = grad_close(gr, ograds[k], tie=1.5 * tie, floor=1e-6 * gmax)     # per element, at the scale of the element's row
+        assert ok, f"{k}: element-wise gradient error {worst:.2f} x the bar"
+        n_tied += nt
+        n_el += gr.numel()
+    # the tie slack is an exception, not a tolerance: it may touch a handful of elements (one flipped unit reaches one
+    # row of a weight gradient and the rows of the patients behind it), never a visible share of the model
+    assert n_tied <= max(64, n_el // 2000), f"ReLU-tie slack raised the bar of {n_tied} of {n_el} gradient elements"
     for k, b in model.named_buffers():
         if k.endswith("num_batches_tracked"):
             assert int(b) == int(obufs[k]), k
@@ -302,6 +315,13 @@ def test_large_vocabulary_without_bit_planes_matches_oracle(dev):
     g = fx.graph_from_frames(fx.det_frames(400, 30, 900, 40)).to(dev)
     plan = build_plan(g, dev, use_cache=False)
     assert all(r.mask_t is None and r.mask_r is None for r in plan.rels.values())
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_mimic_schema_vocabulary_at_128d_with_dropout(dev, p):
+    """BASELINE.json config 5 at its own width: 50 / 200 / 100 vocabulary, 128-d, dropout 0.2 (injected masks) -- the
+    unit-per-wave aggregates (k_gather_units / k_scatter_units) with their dropout and row-scale paths, per element."""
+    _train_step_vs_oracle(dev, (900, 50, 200, 100), 128, p=p, sup_seed=5)
 
 
 def test_mimic_schema_vocabulary_matches_oracle(dev):

@@ -237,6 +237,71 @@ def test_linear_fwd(ops, dev, M, N, K):
     assert rel(y, ref) <= 2e-6                     # the 6-term bf16 split keeps fp32 accuracy
 
 
+@pytest.mark.parametrize("M", [2000, 300])          # the x6 matrix-core kernels / the small-M kernel
+@pytest.mark.parametrize("sx,sw", [(1e15, 1e15), (1e-15, 1e-15), (1e30, 1e-30), (3e18, 3e18)])
+def test_dense_kernels_over_the_fp32_range(ops, dev, M, sx, sw):
+    """The 6-term bf16 split over the whole fp32 exponent range (the reference computes these layers with plain fp32
+    addmm, model.py:93-105): operands at 1e+-15 / 1e+-30, products up to ~1e38.  Forward, weight gradient and the fused
+    BatchNorm-backward GEMM keep fp32 accuracy relative to the tensor's scale -- nothing in the split depends on the
+    magnitude as long as every intermediate stays finite."""
+    gen = torch.Generator().manual_seed(int(M))
+    N = K = 128
+    x, W = torch.randn(M, K, generator=gen) * sx, torch.randn(N, K, generator=gen) * sw / K ** 0.5
+    y = ops.linear_fwd(x.to(dev), W.to(dev))
+    ref = x.double() @ W.double().t()
+    assert bool(torch.isfinite(y).all()) and rel(y, ref) <= 2e-6
+    dy = torch.randn(M, N, generator=gen) * min(sw, 1e15)            # (the sum over M rows has to stay below 3.4e38)
+    dW = ops.linear_wgrad(dy.to(dev), x.to(dev))
+    refw = dy.double().t() @ x.double()
+    assert bool(torch.isfinite(dW).all()) and rel(dW, refw) <= 2e-6
+    if ops.linear_bnbwd_supported(M, N, K):
+        g = torch.randn(M, K, generator=gen) * sx
+        yy = torch.randn(M, K, generator=gen)
+        Wkn = torch.randn(K, N, generator=gen) * sw / K ** 0.5
+        dz, dx = ops.linear_bnbwd(g.to(dev), yy.to(dev), ops.Pro(None, None, True, 0.0), None, Wkn.to(dev))
+        dzr = g.double() * (yy.double() > 0)
+        assert torch.equal(dz.cpu().double(), dzr)                           # relu mask only: exact
+        assert rel(dx, dzr @ Wkn.double()) <= 2e-6
+
+
+def test_dense_kernels_denormals_and_non_finite_inputs(ops, dev):
+    """Edges of the range.  (1) Operands within ~2^8 of the smallest normal fp32 (1.18e-38): the low pieces of the split
+    are bf16 denormals, which the matrix cores may flush, so the result degrades towards the first piece alone -- the
+    error stays below the smallest normal number in absolute terms, but it is NOT fp32-accurate relative to such values
+    (fp32 addmm underflows gradually).  Stated, not hidden: activations of this model are O(1).  (2) Non-finite inputs propagate: every output fp32 addmm makes non-finite is
+    non-finite here, every other output is untouched; NaN in -> NaN out.  An inf input row comes out as NaN rather than
+    +-inf (hi = inf makes the remainder inf - inf): non-finite either way, and stated here so nobody reads it as parity."""
+    gen = torch.Generator().manual_seed(3)
+    M, N, K = 1500, 128, 128
+    # (1) tiny magnitudes
+    x = torch.randn(M, K, generator=gen) * 1e-37
+    W = torch.randn(N, K, generator=gen) / K ** 0.5
+    y = ops.linear_fwd(x.to(dev), W.to(dev))
+    ref = x.double() @ W.double().t()
+    assert float((y.double().cpu() - ref).abs().max()) <= 1.2e-38                  # below the smallest normal
+    xd = torch.full((M, K), 1e-41)                                                  # fp32 denormals in
+    yd = ops.linear_fwd(xd.to(dev), W.to(dev))
+    assert bool(torch.isfinite(yd).all()) and float(yd.abs().max()) <= 1e-38        # (flushed or kept: both below normal)
+    # (2) non-finite inputs
+    x = torch.randn(M, K, generator=gen)
+    x[3, 5], x[700, 9], x[1499, 127] = float("inf"), float("nan"), float("-inf")
+    cpu = x @ W.t()                                                                 # fp32 addmm on the host
+    y = ops.linear_fwd(x.to(dev), W.to(dev)).cpu()
+    bad_rows = torch.tensor([3, 700, 1499])
+    assert not bool(torch.isfinite(cpu[bad_rows]).any()) and not bool(torch.isfinite(y[bad_rows]).any())
+    assert bool(torch.isnan(y[700]).all())
+    ok_rows = torch.ones(M, dtype=torch.bool)
+    ok_rows[bad_rows] = False
+    assert bool(torch.isfinite(y[ok_rows]).all()) and rel(y[ok_rows], cpu[ok_rows].double()) <= 2e-6
+    # the weight gradient sums over rows: a non-finite row poisons exactly the columns fp32 would poison (all of them here)
+    dy = torch.randn(M, N, generator=gen)
+    dW = ops.linear_wgrad(dy.to(dev), x.to(dev)).cpu()
+    cw = dy.t() @ x
+    assert torch.equal(torch.isfinite(dW), torch.isfinite(cw))
+    fin = torch.isfinite(cw)
+    assert rel(dW[fin], cw[fin].double()) <= 1e-5
+
+
 def _host_pro(ops, dev, x, scale, shift, relu, p, seed, site, row_offset=0):
     v = x.double() * scale.double() + shift.double()
     if relu:

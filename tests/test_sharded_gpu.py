@@ -164,7 +164,8 @@ def _virtual_shards_vs_unsharded(n, hidden, dropout, bounds=None, world=2, seed=
 def test_two_virtual_shards_match_unsharded(dropout, overlap, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    monkeypatch.setenv("MMG_OVERLAP", overlap)
+    import mmgnn.model as _mm
+    monkeypatch.setattr(_mm, "OVERLAP_MODE", {"0": "off", "1": "auto", "2": "on"}[overlap])
     # seed chosen so that no ReLU pre-activation of the 64x32 head layer sits within fp32 rounding of 0 for a
     # supervised pair (seed 777 has one at 1e-7: its gradient flips with the summation order -- an inherent
     # kink tie, not a sharding effect; the whole gradient is a sum over only ~1.3k supervised pairs)
@@ -223,7 +224,8 @@ def test_piecewise_graph_chain_matches_eager_steps(overlap, monkeypatch):
     eager autograd steps: same losses, same parameters after three optimizer steps (dropout 0: no RNG in the way)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    monkeypatch.setenv("MMG_OVERLAP", overlap)
+    import mmgnn.model as _mm
+    monkeypatch.setattr(_mm, "OVERLAP_MODE", {"0": "off", "1": "auto", "2": "on"}[overlap])
     import mmgnn  # noqa: F401
     from mmgnn import dist as md, ops
     from mmgnn.data import build_plan
@@ -302,7 +304,8 @@ def test_single_graph_step_matches_eager_steps(overlap, monkeypatch):
     overlap = 2 the vocab-side work of every layer forks onto the side stream inside the captured graph."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    monkeypatch.setenv("MMG_OVERLAP", overlap)
+    import mmgnn.model as _mm
+    monkeypatch.setattr(_mm, "OVERLAP_MODE", {"0": "off", "1": "auto", "2": "on"}[overlap])
     import mmgnn  # noqa: F401
     from mmgnn import ops
     from mmgnn.data import build_plan
