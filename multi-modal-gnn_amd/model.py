@@ -302,6 +302,12 @@ class _Run:
         # (sel_low, sel_high, counts) of the pairs the backward must visit, when the caller knows them in advance (a
         # captured step with a per-epoch supervision mask: train.PiecewiseGraphedTrainStep); None: selected from dpred != 0
         self.static_select = None
+        # the same lists for the FORWARD of the heads: a training step whose loss reads the supervised predictions only
+        # (train.py:366-370: predictions[supervision_mask]) does not need the others -- every prediction it does compute,
+        # the loss and every gradient are bit for bit what the full sweep gives (per-pair arithmetic, counter RNG keyed
+        # on the pair id); predictions outside the lists are 0.  Only the captured training steps set this.
+        self.forward_select = None
+        self.lists_ready = None      # event behind which the lists above (and the supervision mask) are valid, or None
         self.pairs = None
         self.lazy_final = False      # predict mode: the final patient activations stay folded (see _LazyAct)
         # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
@@ -1163,7 +1169,13 @@ class _Run:
             raise KeyError(f"graph has no {LAB_EDGE} relation (model.py:297)")
         pi, li, perm, ids, (sel_low, sel_high, counts, n_low, n_high, low_rows, pi_low, deg_low, _) = self.pairs
         thr = int(self.m.degree_threshold)
-        pred = torch.empty(pi.numel(), device=self.dev)          # every pair belongs to exactly one head list
+        if self.lists_ready is not None:             # drawn / selected on the side stream beside the encoder pass
+            torch.cuda.current_stream().wait_event(self.lists_ready)
+        if self.forward_select is not None:
+            pred = ops.zeros(pi.numel(), device=self.dev)        # pairs outside the lists: 0 (never read by the loss)
+            sel_low, sel_high, counts = self.forward_select      # (subsets of the static lists: n_low / n_high still bound them)
+        else:
+            pred = torch.empty(pi.numel(), device=self.dev)      # every pair belongs to exactly one head list
         rec = dict(init=init, fin=fin)
         halves = self.head_weight_halves()
         for which, src, want_low in (("edge_predictor", fin, False), ("tabular_mlp", init, True)):

@@ -508,10 +508,13 @@ class PiecewiseGraphedTrainStep:
 
     def __init__(self, model, plan, pi, li, y, lab_weights, optimizer, sup_mask, comm, loss_fn: str = "mae",
                  n_sup_global: Optional[float] = None, warmup: int = 2, mask_fraction: Optional[float] = None,
-                 loss_out: Optional[torch.Tensor] = None):
+                 loss_out: Optional[torch.Tensor] = None, supervised_heads_only: bool = True):
         """mask_fraction: draw a NEW supervision subset of that fraction inside every step (device RNG; the reference
         redraws it every epoch, train.py:150-176) -- `sup_mask` may then be None; otherwise the subset is `sup_mask`
-        until set_mask.  loss_out: fp64 device scalar the step writes its loss to."""
+        until set_mask.  loss_out: fp64 device scalar the step writes its loss to.
+        supervised_heads_only: the two edge heads are evaluated on the supervised pairs alone (the loss of train.py:366-386
+        reads predictions[supervision_mask] and nothing else; message passing still covers the whole graph): loss,
+        gradients and parameter updates are bit for bit those of the full sweep, `self.pred` is 0 elsewhere."""
         from . import ops
         from .model import _Run
         if loss_fn not in ("mae", "mse", "huber"):
@@ -523,6 +526,9 @@ class PiecewiseGraphedTrainStep:
         # the reference weights mae / mse by lab (train.py:366-386) and falls back to the unweighted loss otherwise
         self.wl = lab_weights[li].contiguous() if loss_fn in ("mae", "mse") else None
         self.mask_fraction = None if mask_fraction is None else float(mask_fraction)
+        self.supervised_heads_only = bool(supervised_heads_only)
+        self.pred = None
+        self._sel_ready = None
         dev = pi.device
         self._sv = _SupervisionState(sup_mask, comm, n_sup_global, n=pi.numel(), device=dev)
         self.sup = self._sv.sup
@@ -581,9 +587,7 @@ class PiecewiseGraphedTrainStep:
             for p in self.params:
                 p.grad = None
             if self.mask_fraction is not None:       # this step's supervision subset, its size and its pair lists
-                self._sv.draw(self.mask_fraction, model._seed_dev,
-                              getattr(self.comm, "pair_ids", None) if self.comm else None)
-                self._select()
+                self._draw_and_select()
             run = self._Run(model, self.plan)
             run.pairs = model._pairs(self.pi, self.li, self.plan.n_rows,
                                      getattr(self.comm, "pair_ids", None) if self.comm else None,
@@ -591,7 +595,11 @@ class PiecewiseGraphedTrainStep:
             run.n_pairs = self.pi.numel()
             run.need_grad = True
             run.static_select = self._sel
+            run.lists_ready = self._sel_ready
+            if self.supervised_heads_only:
+                run.forward_select = self._sel
             (pred,) = run.run_forward("predict")
+            self.pred = pred
             loss, dpred = ops.pair_loss(pred, self.y, self.wl, self.sup, 1.0, self.loss_fn, self._sv.inv_den,
                                         loss_out=self._loss_out)
             grads = run.run_backward((dpred,))
@@ -601,6 +609,25 @@ class PiecewiseGraphedTrainStep:
             self.opt.step()
             ops.seed_advance(model._seed_dev)        # fresh dropout masks for the next replay, drawn on the device
             self.loss = loss                         # fp64 scalar in the graph's pool: the same address at every replay
+
+    def _draw_and_select(self):
+        """The step's supervision subset, its size and the pair lists derived from it.  Single GPU: on the side stream,
+        beside the encoder pass (nothing reads them before the heads); sharded: on the main stream (the subset size is a
+        collective, and collectives cut the graph segments there)."""
+        model = self.model
+        ids = getattr(self.comm, "pair_ids", None) if self.comm else None
+        side = getattr(model, "_side_stream", None)
+        if self.comm is not None or side is None:
+            self._sv.draw(self.mask_fraction, model._seed_dev, ids)
+            self._select()
+            return
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._sv.draw(self.mask_fraction, model._seed_dev, ids)
+            self._select()
+            self._sel_ready = torch.cuda.Event()
+            self._sel_ready.record(side)      # the heads wait for this (_Run.heads_fwd); the encoder pass does not
 
     # ---- replay
     def _select(self):

@@ -258,7 +258,7 @@ def _train_step_vs_oracle(dev, n, hidden, p=0.0, sup_seed=11, **model_kw):
         sd64, gv, pi, li, y.double(), w.double(), sup, p=p, masks=masks64, num_layers=L,
         use_batch_norm=model_kw.get("use_batch_norm", True), activation=model_kw.get("activation", "relu"))
     gmax = max(float(v.abs().max()) for v in ograds.values())
-    n_tied, n_el = 0, 0
+    n_tied, n_off64, n_el = 0, 0, 0
     for k, pm in model.named_parameters():
         gr = pm.grad.cpu() if pm.grad is not None else torch.zeros_like(pm).cpu()
         tie = (ograds[k].double() - ograds64[k]).abs()
@@ -270,10 +270,14 @@ def _train_step_vs_oracle(dev, n, hidden, p=0.0, sup_seed=11, **model_kw):
         ok, worst, nt = grad_close(gr, ograds[k], tie=1.5 * tie, floor=1e-6 * gmax)     # per element, at the scale of the element's row
         assert ok, f"{k}: element-wise gradient error {worst:.2f} x the bar"
         n_tied += nt
+        n_off64 += grad_close(gr, ograds64[k], tie=torch.zeros_like(tie), floor=1e-6 * gmax)[2]
         n_el += gr.numel()
-    # the tie slack is an exception, not a tolerance: it may touch a handful of elements (one flipped unit reaches one
-    # row of a weight gradient and the rows of the patients behind it), never a visible share of the model
-    assert n_tied <= max(64, n_el // 2000), f"ReLU-tie slack raised the bar of {n_tied} of {n_el} gradient elements"
+    # The tie slack is an exception, not a tolerance.  Elements that pass ONLY because of it are counted; they must be a
+    # handful (0 in every configuration but the 256-d eICU-vocabulary step) -- unless the device took the fp64 oracle's side
+    # of the tie, in which case it has to match THAT run per element with no slack at all (one flipped unit moves a
+    # rank-one slice of every weight gradient upstream and, through the BatchNorm mean, a little of every patient row).
+    assert n_tied <= max(64, n_el // 2000) or n_off64 == 0, \
+        f"{n_tied} of {n_el} gradient elements pass only through the ReLU-tie slack and {n_off64} miss the fp64 oracle's bar"
     for k, b in model.named_buffers():
         if k.endswith("num_batches_tracked"):
             assert int(b) == int(obufs[k]), k

@@ -264,3 +264,43 @@ def test_trainer_without_a_mask_generator_draws_its_masks_inside_the_step(dev, t
         st.set_mask(masks[0])
     hist = trainer.train(tmp_path)
     assert len(hist["train_loss"]) == 4 and all(np.isfinite(hist["train_loss"] + hist["val_loss"]))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2])
+def test_heads_on_the_supervised_pairs_only_change_nothing_a_step_returns(dev, p):
+    """The captured training step evaluates the edge heads on the supervised pairs alone (the loss of train.py:366-386
+    reads predictions[supervision_mask] and nothing else).  Against the full sweep over all train pairs: the predictions of
+    the supervised pairs, the loss, and every parameter / buffer after two Adam steps are BITWISE equal (per-pair
+    arithmetic, counter RNG keyed on the pair id); unsupervised pairs read 0 instead of a prediction nobody uses."""
+    import mmgnn  # noqa: F401
+    from mmgnn.data import build_plan
+    from mmgnn.model import build_model
+    from mmgnn.optim import Adam
+    from mmgnn.train import PiecewiseGraphedTrainStep
+    n = (600, 20, 25, 18)
+    cfg = _config(hidden=128, dropout=p)
+    g0 = fx.graph_from_frames(fx.det_frames(*n))
+    gv = om.GraphView(g0)
+    sd = fx.det_state(gv.num_nodes, 128)
+    ei, ea = g0["patient", "has_lab", "lab"].edge_index, g0["patient", "has_lab", "lab"].edge_attr
+    tr, _, _ = ot.edge_splits(ei.shape[1])
+    pi, li, y = ei[0][tr].to(dev), ei[1][tr].to(dev), ea[tr].squeeze(-1).to(dev)
+    w = ot.lab_weights(ei[1][tr], ea[tr].squeeze(-1), gv.num_nodes["lab"]).to(dev)
+    sup = (torch.rand(int(tr.sum()), generator=torch.Generator().manual_seed(3)) < 0.2).to(dev)
+    res = []
+    for flag in (False, True):
+        torch.manual_seed(99)                                     # the same dropout seed stream for both
+        g = fx.graph_from_frames(fx.det_frames(*n)).to(dev)
+        model = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
+        model._init_embeddings(g)
+        model.load_state_dict(sd)
+        opt = Adam([q for k, q in model.named_parameters() if not k.startswith("embeddings.")], lr=1e-2)
+        step = PiecewiseGraphedTrainStep(model, build_plan(g, dev, use_cache=False), pi, li, y, w, opt, sup, None,
+                                         supervised_heads_only=flag)
+        losses = [float(step.step()) for _ in range(2)]
+        res.append((losses, step.pred.clone(), {k: v.clone() for k, v in model.state_dict().items()}))
+    (l0, p0, s0), (l1, p1, s1) = res
+    assert l0 == l1
+    assert torch.equal(p0[sup], p1[sup]) and float(p1[~sup].abs().max()) == 0.0 and float(p0[~sup].abs().max()) > 0.0
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
