@@ -153,6 +153,24 @@ __global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 xbf16x4 __attribute__((ext_vector_type(4)));
 
+// XCD-aware block -> (tile, row-set) map for 2-D grids whose x index selects an output tile (a column slice of the
+// forward, an [TN, TK] tile of the weight gradient) and whose y index selects the rows.  Every tile of one row-set reads
+// the same rows of the streamed operand(s); workgroups are dealt round-robin over the 8 XCDs (linear id b and b + 8 share
+// an XCD and its 4 MB L2, MI355X_MICROARCH.md), so with the natural map (x fastest) the tiles of a row-set land on
+// DIFFERENT XCDs and every one of them fetches its rows from HBM.  Here ids 8 apart -- same XCD, dispatched together --
+// become the tiles of one row-set: the first reader's lines are in L2 for the others.  Speed only: a bijection of the
+// grid for gridDim.y % 8 == 0, the identity otherwise.
+__device__ __forceinline__ void xcd_tile_map(int* bx, int* by) {
+  const unsigned nx = gridDim.x, ny = gridDim.y;
+  *bx = (int)blockIdx.x; *by = (int)blockIdx.y;
+  if (nx > 1u && (ny & 7u) == 0u) {
+    const unsigned L = blockIdx.x + nx * blockIdx.y, j = L >> 3;
+    *bx = (int)(j % nx);
+    *by = (int)((j / nx) * 8u + (L & 7u));
+  }
+}
+
+
 // Memory pipeline: every global access goes through a per-tile buffer descriptor (rows past M and tiles past the end
 // read 0 / are dropped by the range check), so the tile loop is straight-line code without a branch around a load or a
 // store and the compiler's vmcnt waits are exact: X runs two tiles ahead in registers, the epilogue's stores are never
@@ -187,7 +205,9 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
   extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int col = blockIdx.x * BN + wn * 32 + l31;
+  int bx, by;
+  xcd_tile_map(&bx, &by);                 // (column slice, row-set): the slices of one row-set share an XCD's L2
+  const int col = bx * BN + wn * 32 + l31;
 
   xbf16x8 wb[NK][3];
   {
@@ -232,7 +252,7 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
     drop = pr.p > 0.f;
   }
   const int64_t n_tiles = (M + BM - 1) / BM;
-  const int64_t G = gridDim.y, t0 = blockIdx.y;
+  const int64_t G = gridDim.y, t0 = by;
   if (t0 >= n_tiles) return;
   const int n_my = (int)((n_tiles - t0 + G - 1) / G);      // tiles t0, t0+G, ... of this workgroup
   auto rows_of = [&](int64_t tile) -> int {                // valid rows of a tile (0 past the end)
@@ -249,11 +269,10 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
     for (int p = 0; p < NP; ++p)
       nx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
   };
-  auto stage = [&](int64_t tile, int buf, const f32x4* nx) {  // prologue + split + three plane writes
+  auto stage_pass = [&](int64_t tile, int buf, const f32x4* nx, int p) __attribute__((always_inline)) {   // one 16-B element per thread
     const int64_t row0 = tile * BM;
     __bf16* pb = planes + (size_t)buf * 3 * BM * LDP;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
+    {
       const int r = p * ROWS_PER_PASS + prow;
       f32x4 v = nx[p];
       if (PRO) {
@@ -275,13 +294,22 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
       *reinterpret_cast<xbf16x4*>(pb + (2 * BM + r) * LDP + kc4 * 4) = q2;
     }
   };
+  auto stage = [&](int64_t tile, int buf, const f32x4* nx) __attribute__((always_inline)) {  // prologue + split + three plane writes
+#pragma unroll
+    for (int p = 0; p < NP; ++p) stage_pass(tile, buf, nx, p);
+  };
+  // K = 256 keeps ONE workgroup per CU (192 registers of W pieces per wave, 101 KB of planes): no second workgroup stages
+  // its tile while this one multiplies, so the staging of tile t+1 is dealt out between the k-steps of tile t here (the
+  // matrix pipe runs a 32 x 32 x 16 product for 32 clocks; the vector and LDS instructions of a staging pass issue in
+  // its shadow).  The two tiles use different plane buffers, the barrier at the end of the tile orders both.
+  constexpr bool WEAVE = (K == 256) && !L2 && (NP <= NK);
   fetch(t0, nxa);
   stage(t0, 0, nxa);
   fetch(t0 + G, nxa);
   fetch(t0 + 2 * G, nxb);
   __syncthreads();
   const int yvo = ((4 * h) * N + wn * 32 + l31) * 4;     // C/D map: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
-  const int c0 = blockIdx.x * BN;
+  const int c0 = bx * BN;
   auto tile_body = [&](int64_t tt, int buf, f32x4* nx) {
     // nx holds tile tt+G (fetched two tiles ago); after staging it, the registers take tile tt+3G
     const int rows = rows_of(tt);
@@ -292,22 +320,61 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
     for (int i = 0; i < 16; ++i)
       acc[i] = ACC ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, yvo, ((i & 3) + 8 * (i >> 2)) * N * 4, 0))
                    : 0.f;
-    stage(tt + G, buf ^ 1, nx);                // the other buffer: its readers passed the barrier of the last tile
-    fetch(tt + 3 * G, nx);
-    __builtin_amdgcn_sched_barrier(0);         // keep the fetch ahead of the matrix loop (the scheduler sinks it otherwise)
-    const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + l31 * LDP + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-      const xbf16x8 a1 = *reinterpret_cast<const xbf16x8*>(ap + ks * 16);
-      const xbf16x8 a2 = *reinterpret_cast<const xbf16x8*>(ap + BM * LDP + ks * 16);
-      const xbf16x8 a3 = *reinterpret_cast<const xbf16x8*>(ap + 2 * BM * LDP + ks * 16);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wb[ks][0], acc, 0, 0, 0);   // small terms first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wb[ks][1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wb[ks][0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][0], acc, 0, 0, 0);
+    if constexpr (!WEAVE) {
+      stage(tt + G, buf ^ 1, nx);              // the other buffer: its readers passed the barrier of the last tile
+      fetch(tt + 3 * G, nx);
+      __builtin_amdgcn_sched_barrier(0);       // keep the fetch ahead of the matrix loop (the scheduler sinks it otherwise)
     }
+    const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + l31 * LDP + 8 * h;
+    if constexpr (!WEAVE) {
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const xbf16x8 a1 = *reinterpret_cast<const xbf16x8*>(ap + ks * 16);
+        const xbf16x8 a2 = *reinterpret_cast<const xbf16x8*>(ap + BM * LDP + ks * 16);
+        const xbf16x8 a3 = *reinterpret_cast<const xbf16x8*>(ap + 2 * BM * LDP + ks * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, wb[ks][0], acc, 0, 0, 0);   // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wb[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, wb[ks][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wb[ks][0], acc, 0, 0, 0);
+      }
+    } else {
+      // A wave that is alone on its SIMD hides nothing by itself: the fragments of k-step ks+1 are fetched before the
+      // products of k-step ks (their LDS latency then passes under six matrix instructions), and one staging pass of the
+      // NEXT tile is dealt out between the products of every KS_PER_PASS-th k-step (sched_group_barrier: a dependent
+      // MFMA chain issues one instruction per 32 clocks, the vector / LDS work of the pass issues in between).
+      constexpr int KS_PER_PASS = NK / NP;
+      xbf16x8 fr[2][3];
+      auto ldfrag = [&](int ks, xbf16x8* f) __attribute__((always_inline)) {
+        f[0] = *reinterpret_cast<const xbf16x8*>(ap + ks * 16);
+        f[1] = *reinterpret_cast<const xbf16x8*>(ap + BM * LDP + ks * 16);
+        f[2] = *reinterpret_cast<const xbf16x8*>(ap + 2 * BM * LDP + ks * 16);
+      };
+      ldfrag(0, fr[0]);
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        const bool pass = ks % KS_PER_PASS == KS_PER_PASS - 1 && ks / KS_PER_PASS < NP;
+        if (ks + 1 < NK) ldfrag(ks + 1, fr[(ks + 1) & 1]);
+        const xbf16x8* f = fr[ks & 1];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], wb[ks][0], acc, 0, 0, 0);   // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ks][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][0], acc, 0, 0, 0);
+        if (pass) stage_pass(tt + G, buf ^ 1, nx, ks / KS_PER_PASS);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
+          if (i < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // one fragment read of the next k-step
+          if (pass) __builtin_amdgcn_sched_group_barrier(0x002, PRO ? 12 : 5, 0);  // a slice of the staging pass
+          if (pass && i >= 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // its plane writes at the end
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (WEAVE) fetch(tt + 3 * G, nx);  // (its registers are free only now: two tiles stay in flight all the same)
     if constexpr (L2) {
       // row sums of squares: 32 lanes of a half-wave hold the 32 columns of this wave for 16 rows each; the WN waves'
       // partials meet in LDS, 32 threads turn them into 1 / max(norm, eps), every lane scales its 16 values
@@ -371,16 +438,238 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
     tile_body(t0 + (int64_t)(i + 1) * G, 1, nxb);
   }
   if (stat_partial) {
-    // two partials per column (the lane halves) -> one: partial[blockIdx.y][2][N], fixed order
+    // two partials per column (the lane halves) -> one: partial[row-set][2][N], fixed order
     double* red = reinterpret_cast<double*>(planes);          // the planes are dead: every wave passed the last barrier
     red[(h * 2 + 0) * BN + wn * 32 + l31] = cs1;
     red[(h * 2 + 1) * BN + wn * 32 + l31] = cs2;
     __syncthreads();
     for (int e = tid; e < 2 * BN; e += NTHR) {
       const int which = e / BN, c = e % BN;
-      stat_partial[((size_t)blockIdx.y * 2 + which) * N + blockIdx.x * BN + c] = red[which * BN + c] + red[(2 + which) * BN + c];
+      stat_partial[((size_t)by * 2 + which) * N + bx * BN + c] = red[which * BN + c] + red[(2 + which) * BN + c];
     }
   }
+}
+
+// K = 256 with 256 output columns per workgroup: the [M, 256] x [256, 256] layers of the 256-d model (BASELINE config 4).
+// At this shape the six-term product is MATRIX-bound (384 matrix FLOP per byte against a machine balance of ~310), and
+// k_linear_fwd_x6<256, 4> spent half of its time outside the matrix pipe: two workgroups (one per 128-column slice, on
+// different CUs) each staged -- loaded, split, wrote to LDS -- the same X tile and read every A fragment for ONE 32-column
+// tile.  Here one workgroup owns all 256 columns: a wave holds the W pieces of TWO column tiles (384 registers; one wave
+// per SIMD has 512), so an X tile is staged once per CU, a fragment read feeds two products, and the staging of tile t+1
+// is woven between the products of tile t (one pass per two k-steps; its input register is refilled at once with tile
+// t+2, so ONE tile of X in registers keeps a full tile time of load latency).
+template <bool PRO, bool ACC>
+__global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
+    const float* __restrict__ X, ProDev pr, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Y, int64_t M, int N, int flags, double* __restrict__ stat_partial) {
+  constexpr int K = 256, CT = 2, LDP = K + 8, BN = 256, NK = K / 16, NTHR = 256, BM = 32;
+  if (PRO) pr.resolve();
+  extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  const int c0 = bx * BN;
+  xbf16x8 wb[CT][NK][3];
+  float bv[CT];
+  {
+    const bool wkn = (flags & MMG_LIN_W_KN) != 0;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int col = c0 + (wn * CT + ct) * 32 + l31;
+      bv[ct] = bias ? bias[col] : 0.f;
+      const float* wp = wkn ? W + (size_t)(8 * h) * N + col : W + (size_t)col * K + 8 * h;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) {
+        f32x4 w0, w1;
+        if (wkn) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { w0[j] = wp[(size_t)(ks * 16 + j) * N]; w1[j] = wp[(size_t)(ks * 16 + 4 + j) * N]; }
+        } else {
+          w0 = *reinterpret_cast<const f32x4*>(wp + ks * 16); w1 = *reinterpret_cast<const f32x4*>(wp + ks * 16 + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = j < 4 ? w0[j] : w1[j - 4];
+          const __bf16 a = (__bf16)v;
+          const float r1 = v - (float)a;
+          const __bf16 b = (__bf16)r1;
+          wb[ct][ks][0][j] = a; wb[ct][ks][1][j] = b; wb[ct][ks][2][j] = (__bf16)(r1 - (float)b);
+        }
+      }
+    }
+  }
+  constexpr int K4 = K / 4, ROWS_PER_PASS = NTHR / K4, NP = BM / ROWS_PER_PASS;      // 64 quads, 4 rows per pass, 8 passes
+  static_assert(NK == 2 * NP, "one staging pass per two k-steps");
+  const int kc4 = tid % K4, prow = tid / K4;
+  // (the prologue's scale / shift quads are re-read from L1 in every pass: eight registers the wave does not have)
+  float floor_v = -__builtin_inff();
+  bool drop = false;
+  if (PRO) {
+    if (pr.relu) floor_v = 0.f;
+    drop = pr.p > 0.f;
+  }
+  const int64_t n_tiles = (M + BM - 1) / BM;
+  const int64_t G = gridDim.y, t0 = by;
+  if (t0 >= n_tiles) return;
+  const int n_my = (int)((n_tiles - t0 + G - 1) / G);
+  auto rows_of = [&](int64_t tile) -> int {
+    const int64_t r = M - tile * BM;
+    return r <= 0 ? 0 : (r < BM ? (int)r : BM);
+  };
+  auto x_rsrc = [&](int64_t tile) __attribute__((always_inline)) {
+    const int rows = rows_of(tile);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X) + (size_t)(rows ? tile : 0) * BM * K, 0, rows * K * 4,
+                                             0x00020000);
+  };
+  const int xvo = (prow * K + kc4 * 4) * 4;
+  f32x4 nx[NP];                              // ONE tile of X in registers (see the header)
+  auto fetch_pass = [&](__amdgpu_buffer_rsrc_t rs, int p) __attribute__((always_inline)) {
+    nx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
+  };
+  auto stage_pass = [&](int64_t tile, int buf, int p) __attribute__((always_inline)) {
+    const int64_t row0 = tile * BM;
+    __bf16* pb = planes + (size_t)buf * 3 * BM * LDP;
+    const int r = p * ROWS_PER_PASS + prow;
+    f32x4 v = nx[p];
+    if (PRO) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (pr.scale) {
+        sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
+        sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), floor_v);
+      if (drop)
+        mmg_drop4(v, pr.key, (uint64_t)(pr.row_offset + row0 + r) * (uint64_t)K + (uint64_t)(kc4 * 4), pr.thr, pr.inv_keep);
+    }
+    xbf16x4 q0, q1, q2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const __bf16 a = (__bf16)v[j];
+      const float r1 = v[j] - (float)a;
+      const __bf16 b = (__bf16)r1;
+      q0[j] = a; q1[j] = b; q2[j] = (__bf16)(r1 - (float)b);
+    }
+    *reinterpret_cast<xbf16x4*>(pb + (0 * BM + r) * LDP + kc4 * 4) = q0;
+    *reinterpret_cast<xbf16x4*>(pb + (1 * BM + r) * LDP + kc4 * 4) = q1;
+    *reinterpret_cast<xbf16x4*>(pb + (2 * BM + r) * LDP + kc4 * 4) = q2;
+  };
+  {
+    const __amdgpu_buffer_rsrc_t r0 = x_rsrc(t0), r1 = x_rsrc(t0 + G);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) fetch_pass(r0, p);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { stage_pass(t0, 0, p); fetch_pass(r1, p); }
+  }
+  __syncthreads();
+  double cs1[CT] = {0.0, 0.0}, cs2[CT] = {0.0, 0.0};
+  for (int i = 0; i < n_my; ++i) {
+    const int64_t tt = t0 + (int64_t)i * G;
+    const int buf = i & 1;
+    const int rows = rows_of(tt);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(
+        Y + (size_t)(rows ? tt : 0) * BM * N + c0, 0, rows ? (rows * N - c0) * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xs2 = x_rsrc(tt + 2 * G);     // refills: the tile after next
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int yvo = ((4 * h) * N + (wn * CT + ct) * 32 + l31) * 4;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[ct][r] = ACC ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, yvo, ((r & 3) + 8 * (r >> 2)) * N * 4, 0))
+                         : 0.f;
+    }
+    const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + l31 * LDP + 8 * h;
+    constexpr int NF = PRO ? 1 : 2;          // (with a prologue: no room for the second fragment set)
+    xbf16x8 fr[NF][3];
+    auto ldfrag = [&](int ks, xbf16x8* f) __attribute__((always_inline)) {
+      f[0] = *reinterpret_cast<const xbf16x8*>(ap + ks * 16);
+      f[1] = *reinterpret_cast<const xbf16x8*>(ap + BM * LDP + ks * 16);
+      f[2] = *reinterpret_cast<const xbf16x8*>(ap + 2 * BM * LDP + ks * 16);
+    };
+    if (NF == 2) ldfrag(0, fr[0]);
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+      const bool pass = (ks & 1) == 1;
+      if (NF == 2) { if (ks + 1 < NK) ldfrag(ks + 1, fr[(ks + 1) & (NF - 1)]); } else ldfrag(ks, fr[0]);
+      const xbf16x8* f = fr[ks & (NF - 1)];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], wb[ct][ks][0], acc[ct], 0, 0, 0);   // small terms first
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ct][ks][2], acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ct][ks][1], acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ct][ks][0], acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ct][ks][1], acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ct][ks][0], acc[ct], 0, 0, 0);
+      }
+      if (pass) { stage_pass(tt + G, buf ^ 1, ks >> 1); fetch_pass(xs2, ks >> 1); }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
+        if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // a fragment read of the next k-step
+        if (pass) __builtin_amdgcn_sched_group_barrier(0x002, PRO ? 6 : 3, 0);      // a slice of the staging pass
+        if (pass && q >= 8 && q < 11) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // its three plane writes
+        if (pass && q == 11) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // the refill load
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int yvo = ((4 * h) * N + (wn * CT + ct) * 32 + l31) * 4;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int r16 = 0; r16 < 16; ++r16) {
+        const int r = (r16 & 3) + 8 * (r16 >> 2);
+        const float v = acc[ct][r16] + bv[ct];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, yvo, r * N * 4, MMG_NT_ST);
+        const float vs = r + 4 * h < rows ? v : 0.f;
+        t1 += vs; t2 = fmaf(vs, vs, t2);
+      }
+      if (stat_partial) { cs1[ct] += (double)t1; cs2[ct] += (double)t2; }
+    }
+    __syncthreads();                         // buf fully read, buf^1 fully written
+  }
+  if (stat_partial) {
+    double* red = reinterpret_cast<double*>(planes);          // the planes are dead: every wave passed the last barrier
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      red[(h * 2 + 0) * BN + (wn * CT + ct) * 32 + l31] = cs1[ct];
+      red[(h * 2 + 1) * BN + (wn * CT + ct) * 32 + l31] = cs2[ct];
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * BN; e += NTHR) {
+      const int which = e / BN, c = e % BN;
+      stat_partial[((size_t)by * 2 + which) * N + c0 + c] = red[which * BN + c] + red[(2 + which) * BN + c];
+    }
+  }
+}
+
+template <bool PRO, bool ACC>
+int launch_fwd_x6_k256_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                         int flags, hipStream_t st, double* stat_partial, int64_t gy) {
+  constexpr int lds = 2 * 3 * 32 * (256 + 8) * 2;
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_x6_k256<PRO, ACC>, lds>::set()), "linear_fwd(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, 256, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0), (k_linear_fwd_x6_k256<PRO, ACC>),
+             dim3((unsigned)(N / 256), (unsigned)gy), dim3(256), lds, st, X, pr, W, bias, Y, M, N, flags, stat_partial);
+  return 0;
+}
+
+// rows of partial statistics = grid.y of the K = 256, 256-column kernel
+inline int64_t fwd_k256_rows(int64_t M, int N) {
+  const int64_t n_tiles = (M + 31) / 32;
+  int64_t gy = 256 / (N / 256);
+  if (gy < 1) gy = 1;
+  return gy > n_tiles ? n_tiles : gy;
+}
+
+int launch_fwd_x6_k256(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                       int flags, hipStream_t st, double* stat_partial) {
+  const bool pro = pr.scale || pr.relu || pr.p > 0.f, acc = (flags & MMG_LIN_ACCUMULATE) != 0;
+  const int64_t gy = fwd_k256_rows(M, N);
+  if (pro) return acc ? launch_fwd_x6_k256_v<true, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+                      : launch_fwd_x6_k256_v<true, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
+  return acc ? launch_fwd_x6_k256_v<false, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+             : launch_fwd_x6_k256_v<false, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
 }
 
 inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y of the bf16-split forward (= partial stat rows)
@@ -757,14 +1046,16 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wn = wid / WNK, wk = wid % WNK;
   const int tiles_k = K / TK;
-  const int tn0 = (blockIdx.x / tiles_k) * TN, tk0 = (blockIdx.x % tiles_k) * TK;
+  int bx, by;
+  xcd_tile_map(&bx, &by);                 // (output tile, stage set): the tiles that stream the same rows share an XCD's L2
+  const int tn0 = (bx / tiles_k) * TN, tk0 = (bx % tiles_k) * TK;
   // 32-row stages are dealt round-robin: workgroup y takes stages y, y + G, y + 2G, ...  At any moment the grid reads
   // one contiguous window of dY and X (G x 16 KB each), which spreads over every HBM channel; a contiguous chunk per
   // workgroup makes G streams advance in lockstep a fixed (power-of-two-ish) stride apart and pile onto few channels.
   (void)rows_per_split;
   const int64_t total_st = (M + WG_ROWS - 1) / WG_ROWS;
   const int64_t G = gridDim.y;
-  const int n_st = (int64_t)blockIdx.y < total_st ? (int)((total_st - blockIdx.y + G - 1) / G) : 0;
+  const int n_st = (int64_t)by < total_st ? (int)((total_st - by + G - 1) / G) : 0;
 
   f32x16 acc[MT][KT];
 #pragma unroll
@@ -787,7 +1078,7 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
   const int yvo = (yr * N + yc4 * 4) * 4, xvo = (xr * K + xc4 * 4) * 4;
   f32x4 ny[RING][NY], nxr[RING][NX];
   auto fetch = [&](int st, f32x4* fy, f32x4* fx) {
-    const int64_t r0 = ((int64_t)blockIdx.y + (int64_t)st * G) * WG_ROWS;
+    const int64_t r0 = ((int64_t)by + (int64_t)st * G) * WG_ROWS;
     const int64_t left = M - r0;
     const int rows = st < n_st ? (left < WG_ROWS ? (int)left : WG_ROWS) : 0;
     const int64_t rb = rows ? r0 : 0;
@@ -831,7 +1122,7 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
   auto stage = [&](int st, int buf, const f32x4* fy, const f32x4* fx) {
     __bf16* yb = wplanes + (size_t)buf * (PY + PX);
     __bf16* xb = yb + PY;
-    const int64_t r0 = ((int64_t)blockIdx.y + (int64_t)st * G) * WG_ROWS;
+    const int64_t r0 = ((int64_t)by + (int64_t)st * G) * WG_ROWS;
 #pragma unroll
     for (int u = 0; u < NY; ++u) {
       const f32x4 v = fy[u];                     // rows past the end arrive as zeros
@@ -903,7 +1194,7 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
     for (int j = 0; j < RING; ++j) body(s + j, j);
   }
   // slab[split][N*K (+N bias sums)]; with a single split `slab` is dW itself (direct_accumulate: 1 = overwrite, 2 = add)
-  float* dst = slab + (size_t)blockIdx.y * slab_stride;
+  float* dst = slab + (size_t)by * slab_stride;
 #pragma unroll
   for (int x = 0; x < MT; ++x)
 #pragma unroll
@@ -954,13 +1245,15 @@ __global__ __launch_bounds__(512) void k_linear_wgrad_ws(const float* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_k = K / TK;
-  const int tn0 = (blockIdx.x / tiles_k) * TN, tk0 = (blockIdx.x % tiles_k) * TK;
+  int bx, by;
+  xcd_tile_map(&bx, &by);                 // (output tile, stage set): see k_linear_wgrad_x6
+  const int tn0 = (bx / tiles_k) * TN, tk0 = (bx % tiles_k) * TK;
   const int64_t total_st = (M + WG_ROWS - 1) / WG_ROWS;
   const int64_t G = gridDim.y;                   // stages are dealt round-robin (see k_linear_wgrad_x6)
-  const int n_st = (int64_t)blockIdx.y < total_st ? (int)((total_st - blockIdx.y + G - 1) / G) : 0;
+  const int n_st = (int64_t)by < total_st ? (int)((total_st - by + G - 1) / G) : 0;
   constexpr int RING = 4;
   const int n_pad = (n_st + RING - 1) / RING * RING;
-  float* dst = slab + (size_t)blockIdx.y * slab_stride;
+  float* dst = slab + (size_t)by * slab_stride;
 
   if (wid >= 4) {
     // ------------------------------------------------------------------ stagers: waves 4,5 stage dY, waves 6,7 stage X
@@ -971,7 +1264,7 @@ __global__ __launch_bounds__(512) void k_linear_wgrad_ws(const float* __restrict
     const int vo = (8 * g * ld + c4 * 4) * 4;
     f32x4 ring[RING][8];
     auto fetch = [&](int st, f32x4* f) {
-      const int64_t r0 = ((int64_t)blockIdx.y + (int64_t)st * G) * WG_ROWS;
+      const int64_t r0 = ((int64_t)by + (int64_t)st * G) * WG_ROWS;
       const int64_t left = M - r0;
       const int rows = st < n_st ? (left < WG_ROWS ? (int)left : WG_ROWS) : 0;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1236,12 +1529,15 @@ static int linear_fwd_stats_impl(const float* X, const mmg_prologue_t* pro, cons
     } else if (K == 128) {
       if (N % 128 == 0) rc = launch_fwd_x6<128, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
       else rc = launch_fwd_x6<128, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+    } else if (N % 256 == 0) {
+      rc = launch_fwd_x6_k256(X, pr, W, bias, Y, M, N, accumulate, st, partial);     // one workgroup spans 256 columns
     } else {
       rc = launch_fwd_x6<256, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
     }
     if (rc) return rc;
     if (col_sums) {     // partial[gy][2][N] -> col_sums[2][N]
-      const int rows = (int)fwd_x6_rows(M, N, N % 128 == 0 ? 128 : 64, K);
+      const int rows = (K == 256 && N % 256 == 0) ? (int)fwd_k256_rows(M, N)
+                                                  : (int)fwd_x6_rows(M, N, N % 128 == 0 ? 128 : 64, K);
       int rc2 = mmg_partial_sum_bn(partial, col_sums, N, rows, fin, stream);     // (+ the BatchNorm fold when asked for)
       if (rc2) return rc2;
       stats_done = true;
