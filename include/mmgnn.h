@@ -338,7 +338,9 @@ int mmg_pair_loss(const float* pred, const float* y, const float* w, const float
  * else 0.0f, from the counter RNG keyed on (seed, a site of its own, ids[k] or k) -- partition-invariant when ids holds
  * global pair ids.  seed_ptr (nullable, DEVICE) overrides `seed` at run time (the dropout seed stream a captured step
  * advances).  count / inv_den (nullable, DEVICE doubles) receive the subset size and 1 / max(size, 1) -- the normaliser
- * mmg_pair_loss reads through inv_den_ptr. */
+ * mmg_pair_loss reads through inv_den_ptr.  sup == NULL: count only -- a patient-sharded rank draws the mask of ITS pairs
+ * (ids = their global ids) and counts the subset of ALL n_global pairs (ids NULL) itself: the draw is a pure function of
+ * (seed, id), so every rank gets the global size without a collective. */
 size_t mmg_sup_mask_ws_bytes(int64_t n);
 int mmg_sup_mask_draw(const uint64_t* seed_ptr, uint64_t seed, const int64_t* ids, int64_t n, float fraction, float* sup,
                       double* count, double* inv_den, void* ws, size_t ws_bytes, void* stream);

@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_sup_mask_draw(const uint64_t* __restric
   for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
     const uint64_t e = ids ? (uint64_t)ids[k] : (uint64_t)k;
     const float m = mmg_keep(seed, SUP_SITE, e, keep_p) ? 1.f : 0.f;
-    sup[k] = m;
+    if (sup) sup[k] = m;                           // (sup == NULL: count only)
     s += (double)m;
   }
   s = wave_sum_d(s);
@@ -728,7 +728,7 @@ extern "C" size_t mmg_sup_mask_ws_bytes(int64_t n) { return n < 0 ? 0 : (size_t)
 
 extern "C" int mmg_sup_mask_draw(const uint64_t* seed_ptr, uint64_t seed, const int64_t* ids, int64_t n, float fraction,
                                  float* sup, double* count, double* inv_den, void* ws, size_t ws_bytes, void* stream) {
-  MMG_CHECK_ARG(n >= 0 && ws && (n == 0 || sup), "sup_mask_draw: bad args");
+  MMG_CHECK_ARG(n >= 0 && ws && (sup || count || inv_den), "sup_mask_draw: bad args");
   MMG_CHECK_ARG(fraction >= 0.f && fraction <= 1.f, "sup_mask_draw: fraction outside [0, 1]");
   if (ws_bytes < mmg_sup_mask_ws_bytes(n)) { mmg_set_error("sup_mask_draw: workspace too small"); return MMG_E_WS; }
   hipStream_t st = (hipStream_t)stream;

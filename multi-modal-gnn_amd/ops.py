@@ -770,17 +770,20 @@ LOSS_TYPES = {"mae": 0, "mse": 1, "huber": 2}
 
 
 def sup_mask_draw(n: int, fraction: float, device, seed: int = 0, seed_dev=None, ids=None, sup=None, count=None,
-                  inv_den=None):
+                  inv_den=None, count_only: bool = False):
     """The per-epoch supervision subset drawn on the device (mmg_sup_mask_draw; train.py:150-176 of the reference)
     -> (sup float [n], count fp64 [1], inv_den fp64 [1] = 1 / max(count, 1)); the three may be passed in (a captured step
     overwrites them in place).  seed_dev: int64 device tensor whose first element is the seed at run time."""
     lib = _lib.load()
-    sup = torch.empty(max(n, 1), dtype=torch.float32, device=device)[:n] if sup is None else sup
+    if count_only:                       # the size of the subset of ids 0 .. n-1, nothing written per pair
+        sup = None
+    else:
+        sup = torch.empty(max(n, 1), dtype=torch.float32, device=device)[:n] if sup is None else sup
     count = torch.empty(1, dtype=torch.float64, device=device) if count is None else count
     inv_den = torch.empty(1, dtype=torch.float64, device=device) if inv_den is None else inv_den
     ws = workspace(lib.mmg_sup_mask_ws_bytes(n), device)
     check(lib.mmg_sup_mask_draw(_p(seed_dev, torch.int64), int(seed) & 0xFFFFFFFFFFFFFFFF, _p(ids, torch.int64), n,
-                                float(fraction), _p(sup) if n else None, _p(count, torch.float64),
+                                float(fraction), _p(sup) if (n and sup is not None) else None, _p(count, torch.float64),
                                 _p(inv_den, torch.float64), _p(ws, torch.uint8), ws.numel(), _stream()), "mmg_sup_mask_draw")
     return sup, count, inv_den
 

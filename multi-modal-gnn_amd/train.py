@@ -406,18 +406,22 @@ class _SupervisionState:
         self.sup.copy_(sup_mask)                 # (bool -> float inside the copy)
         self._set_den(n_sup_global)
 
-    def draw(self, fraction, seed_dev, ids=None):
-        """New subset drawn on the device from the step's seed stream (mmg_sup_mask_draw); capturable.  Sharded: the
-        subset size is summed over the ranks (one more small all-reduce) before the normaliser is formed."""
+    def draw(self, fraction, seed_dev, ids=None, n_global=None):
+        """New subset drawn on the device from the step's seed stream (mmg_sup_mask_draw); capturable.  Sharded: the draw
+        is a pure function of (seed, global pair id), so every rank counts the subset of ALL n_global pairs itself (a
+        hash-only pass, no memory traffic) instead of summing the shard sizes with a collective."""
         from . import ops
         if self.comm is None:
             ops.sup_mask_draw(self.sup.numel(), fraction, self.sup.device, seed_dev=seed_dev, ids=ids, sup=self.sup,
                               count=self.count, inv_den=self.inv_den)
-        else:
-            ops.sup_mask_draw(self.sup.numel(), fraction, self.sup.device, seed_dev=seed_dev, ids=ids, sup=self.sup,
-                              count=self.count, inv_den=None)
-            self.comm.all_reduce(self.count)
-            torch.reciprocal(self.count.clamp(min=1.0), out=self.inv_den)
+            return
+        if n_global is None:
+            raise ValueError("a sharded draw needs the global number of pairs")
+        local = torch.empty(1, dtype=torch.float64, device=self.sup.device)
+        ops.sup_mask_draw(self.sup.numel(), fraction, self.sup.device, seed_dev=seed_dev, ids=ids, sup=self.sup,
+                          count=local, inv_den=None)
+        ops.sup_mask_draw(int(n_global), fraction, self.sup.device, seed_dev=seed_dev, count=self.count,
+                          inv_den=self.inv_den, count_only=True)
 
 
 def _new_seed_state(dev) -> torch.Tensor:
@@ -530,6 +534,26 @@ class PiecewiseGraphedTrainStep:
         self.pred = None
         self._sel_ready = None
         dev = pi.device
+        self.n_pairs_global, self._draw_ids = None, None
+        if comm is not None and self.mask_fraction is not None:
+            # the draw is keyed on GLOBAL pair ids 0 .. n_global-1: the positions in the unsharded pair list when the
+            # caller gave them (dist.shard_pairs), the shards' pairs numbered back to back otherwise (one all-reduce of
+            # the shard sizes, here, once)
+            ids = getattr(comm, "pair_ids", None)
+            if ids is not None:
+                hi = torch.tensor([float(int(ids.max()) + 1 if ids.numel() else 0)], dtype=torch.float64, device=dev)
+                sizes = torch.zeros(int(comm.world), dtype=torch.float64, device=dev)
+                sizes[int(comm.rank)] = hi[0]
+                comm.raw_all_reduce(sizes)
+                self.n_pairs_global = int(sizes.max().item())
+                self._draw_ids = ids.to(torch.int64).contiguous()
+            else:
+                sizes = torch.zeros(int(comm.world), dtype=torch.float64, device=dev)
+                sizes[int(comm.rank)] = float(pi.numel())
+                comm.raw_all_reduce(sizes)
+                off = int(sizes[:int(comm.rank)].sum().item())
+                self.n_pairs_global = int(sizes.sum().item())
+                self._draw_ids = torch.arange(off, off + pi.numel(), dtype=torch.int64, device=dev)
         self._sv = _SupervisionState(sup_mask, comm, n_sup_global, n=pi.numel(), device=dev)
         self.sup = self._sv.sup
         self.loss_fn = loss_fn
@@ -615,10 +639,10 @@ class PiecewiseGraphedTrainStep:
         beside the encoder pass (nothing reads them before the heads); sharded: on the main stream (the subset size is a
         collective, and collectives cut the graph segments there)."""
         model = self.model
-        ids = getattr(self.comm, "pair_ids", None) if self.comm else None
+        ids = self._draw_ids
         side = getattr(model, "_side_stream", None)
         if self.comm is not None or side is None:
-            self._sv.draw(self.mask_fraction, model._seed_dev, ids)
+            self._sv.draw(self.mask_fraction, model._seed_dev, ids, self.n_pairs_global)
             self._select()
             return
         main = torch.cuda.current_stream()

@@ -280,6 +280,12 @@ def test_supervision_mask_drawn_on_the_device(dev):
     ids = torch.arange(1000, 5000, dtype=torch.int64, device=dev)
     part, _, _ = ops.sup_mask_draw(ids.numel(), 0.2, dev, seed=1234567, ids=ids)
     assert torch.equal(part, sup[1000:5000])
+    # ...and counts the GLOBAL subset by itself (count_only: no per-pair output), so no collective is needed for 1 / n_sup
+    rest = torch.cat([torch.arange(0, 1000, dtype=torch.int64), torch.arange(5000, n, dtype=torch.int64)]).to(dev)
+    other, c_other, _ = ops.sup_mask_draw(rest.numel(), 0.2, dev, seed=1234567, ids=rest)
+    _, c_part, _ = ops.sup_mask_draw(ids.numel(), 0.2, dev, seed=1234567, ids=ids)
+    none_, c_glob, i_glob = ops.sup_mask_draw(n, 0.2, dev, seed=1234567, count_only=True)
+    assert none_ is None and float(c_glob) == float(c_part) + float(c_other) == k and float(i_glob) == 1.0 / k
     full, c1, i1 = ops.sup_mask_draw(1000, 1.0, dev, seed=3)
     none, c0, i0 = ops.sup_mask_draw(1000, 0.0, dev, seed=3)
     assert float(full.sum()) == 1000 and float(none.sum()) == 0 and float(c0) == 0 and float(i0) == 1.0

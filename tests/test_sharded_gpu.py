@@ -426,5 +426,19 @@ def test_rccl_backend_carries_the_sharded_step():
         step.set_mask(sup2)
         assert abs(float(step._sv.inv_den) - 1.0 / float(sup2.sum())) <= 1e-12
         assert torch.isfinite(step.step())
+        # the supervision subset drawn INSIDE the sharded step: keyed on global pair ids, its global size counted by every
+        # rank itself (no collective added: the chain has as many all-reduces as with an injected mask)
+        m3, plan3, comm3, opt3 = make(True)
+        step3 = PiecewiseGraphedTrainStep(m3, plan3, pi, li, y, wlab, opt3, None, comm3, warmup=1, mask_fraction=0.2)
+        assert sum(1 for k, _ in step3.items if k == "all_reduce") == n_coll
+        assert step3.n_pairs_global == pi.numel() and torch.equal(step3._draw_ids, torch.arange(pi.numel(), device=dev))
+        seen = []
+        for _ in range(3):
+            assert torch.isfinite(step3.step())
+            k = float(step3.sup.sum())
+            assert float(step3._sv.count) == k and abs(float(step3._sv.inv_den) - 1.0 / k) <= 1e-15
+            assert 0.1 < k / pi.numel() < 0.3
+            seen.append(step3.sup.clone())
+        assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
     finally:
         dist.destroy_process_group()
