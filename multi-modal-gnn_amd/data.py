@@ -157,6 +157,18 @@ def _plan_key(data) -> tuple:
 # their data_ptr(), and the caching allocator hands a freed address to the next graph of the same size -- without the
 # reference a stale plan (CSR, masks, degrees of the old graph) would be returned for it.
 _PLAN_CACHE: Dict[tuple, tuple] = {}
+_PLAN_CACHE_MAX_BYTES = 4 << 30       # pinned edge_index tensors + plans kept alive by the cache (an x1000 graph is ~2.7 GB)
+
+
+def _plan_bytes(plan: "GraphPlan", eis) -> int:
+    n = sum(int(t.numel()) * t.element_size() for t in eis)
+    seen = set()
+    for r in plan.rels.values():
+        for t in (r.rowptr, r.col, r.perm, r.inv_row, r.inv_col, r.col_cnt, r.mask_t, r.mask_r):
+            if t is not None and id(t) not in seen:
+                seen.add(id(t))
+                n += int(t.numel()) * t.element_size()
+    return n
 
 
 def drop_cached_plan(plan: "GraphPlan"):
@@ -235,7 +247,12 @@ def build_plan(data, device=None, validate: bool = True, use_cache: bool = True)
         r = plan.rels[LAB_EDGE]
         plan.lab_deg, _ = ops.row_degree(r.rowptr)
     if use_cache:
-        if len(_PLAN_CACHE) > 8:
-            _PLAN_CACHE.clear()
-        _PLAN_CACHE[key] = (plan, [data[et].edge_index for et in data.edge_types])
+        eis = [data[et].edge_index for et in data.edge_types]
+        nbytes = _plan_bytes(plan, eis)
+        # bounded by entries AND by bytes: oldest entries go first; a plan larger than the budget is not cached at all
+        while _PLAN_CACHE and (len(_PLAN_CACHE) >= 8 or
+                               sum(e[2] for e in _PLAN_CACHE.values()) + nbytes > _PLAN_CACHE_MAX_BYTES):
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        if nbytes <= _PLAN_CACHE_MAX_BYTES:
+            _PLAN_CACHE[key] = (plan, eis, nbytes)
     return plan

@@ -170,6 +170,9 @@ def stratify_by_lab_frequency(predictions, targets, lab_indices, graph) -> Dict[
 
 
 # ---------------------------------------------------------------------------------------------- device reducers
+DEVICE_MAX_SEGMENTS = 2048       # EV_MAXSEG of csrc/evalred.hip (mmg_seg_reduce_ws_bytes returns 0 beyond it)
+
+
 def metrics_from_sums(s) -> Dict[str, float]:
     """MAE / RMSE / R^2 / MAPE from one row (or the sum of rows) of ops.seg_sums:
     (n, sum|e|, sum e^2, sum t, sum t^2, sum|e/t| over t != 0, count(t != 0), clipped) -- evaluate.py:36-82."""
@@ -177,7 +180,9 @@ def metrics_from_sums(s) -> Dict[str, float]:
     if n <= 0:
         return {"mae": float("nan"), "rmse": float("nan"), "r2": float("nan"), "mape": float("nan")}
     ss_tot = s_t2 - s_t * s_t / n
-    if s_sq == 0:
+    if n < 2:
+        r2 = float("nan")                          # sklearn's r2_score: not defined for fewer than two samples
+    elif s_sq == 0:
         r2 = 1.0
     elif ss_tot > 1e-12 * max(s_t2, 1e-300):
         r2 = 1.0 - s_sq / ss_tot
@@ -252,7 +257,9 @@ def evaluate_model(model, graph, test_edges, config: Dict, output_dir) -> Dict:
     predictions = model.predict_lab_values(graph, patient_indices, lab_indices)
 
     ev = config["evaluation"]
-    if predictions.is_cuda:
+    # the device reducers keep one [segments, 8] fp64 table in LDS: up to EV_MAXSEG = 2048 lab segments; a larger lab
+    # vocabulary is reduced by the host reducers below (numpy, as the reference does it), not refused
+    if predictions.is_cuda and int(graph["lab"].num_nodes) <= DEVICE_MAX_SEGMENTS:
         # HIP device: every reducer runs there (segment sums); the predictions never travel to the host
         lab_store = graph["lab"]
         meta = getattr(lab_store, "metadata", None) if "metadata" in lab_store else None

@@ -201,6 +201,14 @@ class Trainer:
         return (self.device_step and torch.device(self.device).type == "cuda" and isinstance(self.optimizer, Adam)
                 and self.loss_fn in ("mae", "mse", "huber") and getattr(self.model, "_comm", None) is None)
 
+    def _graph_plan(self):
+        """ONE plan (CSR, bit planes, degrees) of the static graph for the captured training step and every captured
+        validation pass (held here: the module-level plan cache is bounded and may decline a very large graph)."""
+        if getattr(self, "_plan", None) is None:
+            from .data import build_plan
+            self._plan = build_plan(self.data, self.device)
+        return self._plan
+
     def _loss_slots(self):
         if self._losses is None:
             self._losses = torch.zeros(2, dtype=torch.float64, device=self.device)
@@ -216,7 +224,7 @@ class Trainer:
         frac = float(m.mask_fraction)
         in_graph = frac > 0 and m.mask_generator is None
         sup0 = None if in_graph else torch.ones(pi.numel(), dtype=torch.bool, device=pi.device)
-        plan = build_plan(self.data, self.device)
+        plan = self._graph_plan()
         if len(self.model.embeddings) == 0:
             self.model._init_embeddings(self.data)
         self._dstep = PiecewiseGraphedTrainStep(self.model, plan, pi, li, y, self.lab_weights, self.optimizer, sup0, None,
@@ -239,8 +247,7 @@ class Trainer:
         if ev is None:
             from .data import build_plan
             pi, li, y, _ = self._split_pairs(split, want_mask=False)
-            ev = GraphedEval(self.model, build_plan(self.data, self.device), pi, li, y, self.loss_fn,
-                             loss_out=self._loss_slots()[slot])
+            ev = GraphedEval(self.model, self._graph_plan(), pi, li, y, self.loss_fn, loss_out=self._loss_slots()[slot])
             self._deval[split] = ev
         return ev.step()
 

@@ -108,3 +108,17 @@ def test_baselines_golden():
     for name, m in meta["baselines"].items():
         for k, v in m.items():
             assert close(res[name][k], v), (name, k)
+
+
+def test_segment_metrics_for_a_single_sample_group():
+    """A stratification group / lab with ONE sample: sklearn's r2_score is undefined there (nan), MAE / RMSE are that
+    sample's error; an empty group is all nan (evaluate.py:36-82 through sklearn)."""
+    import math
+    import mmgnn  # noqa: F401
+    from mmgnn.evaluate import metrics_from_sums
+    one = metrics_from_sums([1.0, 0.5, 0.25, 2.0, 4.0, 0.25, 1.0, 0.0])
+    assert math.isnan(one["r2"]) and one["mae"] == 0.5 and one["rmse"] == 0.5 and one["mape"] == 25.0
+    none = metrics_from_sums([0.0] * 8)
+    assert all(math.isnan(v) for v in none.values())
+    two = metrics_from_sums([2.0, 1.0, 0.5, 3.0, 5.0, 0.7, 2.0, 0.0])       # t = (1, 2): ss_tot = 0.5, ss_res = 0.5
+    assert two["r2"] == 0.0
