@@ -677,7 +677,9 @@ inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y 
   const int64_t n_tiles = (M + 31) / 32;
   // persistent workgroups: two per CU (52 KB of LDS, <= 256 registers) up to K = 128; K = 256 keeps 192 registers of
   // W pieces per wave and 101 KB of planes: one per CU
-  int64_t gy = (K <= 128 ? 512 : 256) / n_slices;
+  // (a 64-column workgroup is two waves: three of them fit a CU -- 52 KB of planes, <= 256 registers -- and a layer with
+  //  N = 64 has a single slice, so 768 workgroups instead of 512 put six waves on every CU)
+  int64_t gy = (K <= 128 ? (BN == 64 ? 768 : 512) : 256) / n_slices;
   if (gy < 1) gy = 1;
   if (gy > n_tiles) gy = n_tiles;
   return gy;
@@ -938,7 +940,9 @@ template <int K, int WN, int MODE = 0>
 int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const float* W, float* DX, int64_t M, hipStream_t st,
                     const ProDev& pr2 = mmg_pro_dev(nullptr)) {
   constexpr int N = 32 * WN;
-  const int64_t gy = fwd_x6_rows(M, N, N, K);
+  // one workgroup spans all N columns; two workgroups per CU whatever the width (register-bound), one at K = 256
+  const int64_t n_tiles_ = (M + 31) / 32, want_ = K <= 128 ? 512 : 256;
+  const int64_t gy = want_ < n_tiles_ ? want_ : (n_tiles_ > 0 ? n_tiles_ : 1);
   constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
   MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN, MODE>, lds>::set()), "linear_bnbwd(attr)");
   MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 1 ? 64 : (MODE == 2 ? 16 | 128 : (MODE == 3 ? 16 | 256 : 16)), (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
@@ -1482,7 +1486,7 @@ extern "C" int mmg_bn_finalize(const double* sums, int64_t count, const float* g
 
 extern "C" size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N) {
   if (M < 0 || N <= 0) return 0;
-  const size_t a = (size_t)512 * 2 * N * sizeof(double) + 256;       // <= 512 partial rows from the GEMM epilogue
+  const size_t a = (size_t)768 * 2 * N * sizeof(double) + 256;       // <= 768 partial rows from the GEMM epilogue
   const size_t b = mmg_col_reduce2_ws_bytes(M, N);                   // fallback: a separate column reduction
   return a > b ? a : b;
 }

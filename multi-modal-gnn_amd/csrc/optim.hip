@@ -24,8 +24,14 @@ __global__ __launch_bounds__(256) void k_adam(AdamTable tb, float* __restrict__ 
                                               unsigned* __restrict__ ticket, int bump) {
   // device-resident hyper-parameters (a captured step keeps its launch arguments; a scheduler changes lr between replays)
   if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
-  const float t = *step + 1.f;
-  const float bc1 = 1.f - powf(b1, t), bc2s = sqrtf(1.f - powf(b2, t));
+  // the bias corrections are two powf per step: one wave computes them, LDS hands them to the workgroup
+  __shared__ float s_bc[3];
+  if (threadIdx.x == 0) {
+    const float t0 = *step + 1.f;
+    s_bc[0] = t0; s_bc[1] = 1.f - powf(b1, t0); s_bc[2] = sqrtf(1.f - powf(b2, t0));
+  }
+  __syncthreads();
+  const float t = s_bc[0], bc1 = s_bc[1], bc2s = s_bc[2];
   const float step_size = lr / bc1;
   const int total = tb.off[tb.n] - tb.off[0];
   // every workgroup owns one contiguous chunk of the bucket, so a thread's elements (256 apart) cross a tensor boundary
