@@ -114,6 +114,7 @@ def probe_read(cap: int = 1 << 16):
 
 
 _WS = {}
+_WS_RETIRED = []      # outgrown workspaces: a captured hipGraph may hold their addresses, so they are never handed back
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
@@ -126,6 +127,10 @@ def workspace(nbytes: int, device) -> torch.Tensor:
            torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # a step captured earlier on this stream replays kernels that write to the old buffer: if it went back to
+            # the allocator, the next tensor placed there (an index list, say) would be scribbled over by the replay
+            _WS_RETIRED.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf

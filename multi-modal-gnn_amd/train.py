@@ -30,6 +30,11 @@ import torch.optim as optim
 from .model import build_model, compute_regression_loss
 
 LAB_EDGE = ("patient", "has_lab", "lab")
+# Stream capture checks "unsafe" HIP calls of the capturing THREAD only.  With the default ("global") any thread counts:
+# the watchdog thread of a torch.distributed NCCL / RCCL process group polls its work events (hipEventQuery) on its own
+# schedule, and one poll that lands inside a capture window invalidates the capture and aborts the process -- an
+# intermittent SIGABRT while a step is being recorded (seen once, bench.py with a world_size-1 RCCL group alive).
+CAPTURE_ERROR_MODE = "thread_local"
 
 
 class EdgeMasker:
@@ -476,7 +481,7 @@ class GraphedTrainStep:
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
             self._body()
         torch.cuda.synchronize()
         _restore_training_state(model, optimizer, snap)
@@ -598,7 +603,7 @@ class PiecewiseGraphedTrainStep:
     # ---- recording
     def _begin(self):
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self._pool)
+        g.capture_begin(pool=self._pool, capture_error_mode=CAPTURE_ERROR_MODE)
         self._cur = g
 
     def _end(self):
@@ -715,7 +720,7 @@ class GraphedEval:
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
             self._body()
         torch.cuda.synchronize()
         model.train(was_training)
