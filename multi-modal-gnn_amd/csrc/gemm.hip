@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
   // its tile while this one multiplies, so the staging of tile t+1 is dealt out between the k-steps of tile t here (the
   // matrix pipe runs a 32 x 32 x 16 product for 32 clocks; the vector and LDS instructions of a staging pass issue in
   // its shadow).  The two tiles use different plane buffers, the barrier at the end of the tile orders both.
-  constexpr bool WEAVE = (K == 256) && !L2 && (NP <= NK);
+  constexpr bool WEAVE = (K >= 128) && !L2 && (NP <= NK) && (NK % NP == 0);
   fetch(t0, nxa);
   stage(t0, 0, nxa);
   fetch(t0 + G, nxa);
@@ -353,23 +353,29 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
       };
       ldfrag(0, fr[0]);
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) {
-        const bool pass = ks % KS_PER_PASS == KS_PER_PASS - 1 && ks / KS_PER_PASS < NP;
-        if (ks + 1 < NK) ldfrag(ks + 1, fr[(ks + 1) & 1]);
-        const xbf16x8* f = fr[ks & 1];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], wb[ks][0], acc, 0, 0, 0);   // small terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ks][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ks][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][0], acc, 0, 0, 0);
-        if (pass) stage_pass(tt + G, buf ^ 1, nx, ks / KS_PER_PASS);
+      for (int pg = 0; pg < NP; ++pg) {          // one scheduling region = the k-steps that carry one staging pass
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
-          if (i < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // one fragment read of the next k-step
-          if (pass) __builtin_amdgcn_sched_group_barrier(0x002, PRO ? 12 : 5, 0);  // a slice of the staging pass
-          if (pass && i >= 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // its plane writes at the end
+        for (int kk = 0; kk < KS_PER_PASS; ++kk) {
+          const int ks = pg * KS_PER_PASS + kk;
+          if (ks + 1 < NK) ldfrag(ks + 1, fr[(ks + 1) & 1]);
+          const xbf16x8* f = fr[ks & 1];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], wb[ks][0], acc, 0, 0, 0);   // small terms first
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ks][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ks][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ks][0], acc, 0, 0, 0);
+        }
+        stage_pass(tt + G, buf ^ 1, nx, pg);
+        // a lone wave hides 2-3 vector instructions behind a matrix instruction (profiles/probes/mfma_shadow): the pass
+        // (~25 of them, ~45 with a prologue) is dealt out over all 6 * KS_PER_PASS products of its k-steps
+        constexpr int NM = 6 * KS_PER_PASS, VPER = ((PRO ? 48 : 26) + NM - 1) / NM;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // one MFMA
+          if (i % 6 < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // one fragment read of the next k-step
+          __builtin_amdgcn_sched_group_barrier(0x002, VPER, 0);                     // a slice of the staging pass
+          if (i >= NM - 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // its plane writes at the end
         }
         __builtin_amdgcn_sched_barrier(0);
       }
