@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel probe pass (profiler runs)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the fixed-mask, Trainer and segment-chain sub-records (profiler runs)")
+    ap.add_argument("--next-bn", default=None,
+                    help="comma list of BatchNorm-backward statistics taken from producer epilogues (mmgnn.model.set_next_bn; "
+                         "'none' = all of them as separate passes); default: the library's own")
     ap.add_argument("--overlap", choices=["auto", "off", "on"], default="auto",
                     help="vocab-side work of a layer on a side stream (mmgnn.model.set_overlap)")
     return ap.parse_args()
@@ -563,6 +566,8 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     mmodel.set_overlap(args.overlap)
+    if args.next_bn is not None:
+        mmodel.set_next_bn([] if args.next_bn == "none" else [t for t in args.next_bn.split(",") if t])
     world, rank, dev = setup_dist(args)
     head = measure(args, world, rank, dev, args.scale, args.strong, args.dim, args.steps, args.warmup, not args.no_kernels,
                    want_fixed=not args.no_extras)

@@ -288,6 +288,48 @@ int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const int64_t* ro
 int mmg_bn_bwd_apply_rows(const float* G_rows, const float* Y, const int64_t* rows, int64_t n_sel,
                           const mmg_prologue_t* pro, float* dY, int N, void* stream);
 
+/* The statistics pass of a BatchNorm backward taken from the kernel that PRODUCES its upstream gradient.
+ * mmg_bn_bwd_stats (and _stats2) read the [M, N] upstream gradient and the [M, N] pre-BatchNorm activation once more; a
+ * producer that is handed this descriptor sums them from its output tile while it is still in registers and only reads
+ * Y.  `sums` receives exactly what mmg_bn_bwd_stats(G = the producer's output, y, pro, mean, rstd) would, summed in a
+ * fixed order (16 rows in fp32, the rest in fp64); with accumulate != 0 that is ADDED to `sums` -- the two sums are
+ * linear in G, so two producers whose outputs go through the same BatchNorm with their own dropout masks (the two
+ * encode_nodes passes of a training step, mmg_bn_bwd_stats2) each add their share.
+ * Autograd of  nn.Linear -> BatchNorm1d -> ReLU -> Dropout  chains (src/model.py:93-101, 258-269): the gradient a layer
+ * hands down is the upstream gradient of the BatchNorm below it.
+ *   mmg_linear_fwd_next_bn          dX = dY . W  (MMG_LIN_W_KN) of a plain linear, e.g. the heads' first layer; no prologue,
+ *                                   no accumulate;  M > 512, N % 128 == 0, K in {64, 128}
+ *   mmg_linear_l2bwd_next_bn        dX of mmg_linear_l2bwd;  K = N = 128
+ *   mmg_linear_bnbwd_next_bn        dX of mmg_linear_bnbwd;  K = N = 128
+ *   mmg_linear_bnbwd_rows_next_bn   dX of mmg_linear_bnbwd_rows;  K = N = 128
+ *   mmg_gather_rows_next_bn         the final `out` of mmg_gather_rows (accumulate or not);  the bit-plane layouts, D >= 128
+ * next == NULL: the plain entry point.  A shape (or activation) outside the list above runs the producer followed by
+ * the separate statistics pass: the result is defined for everything the plain entry point accepts. */
+typedef struct {
+  const float* y;                 /* [M, N] pre-BatchNorm activation of the layer below */
+  const mmg_prologue_t* pro;      /* its fold (scale / shift), activation (none | relu) and dropout */
+  const float* mean;              /* [N] */
+  const float* rstd;              /* [N] */
+  double* sums;                   /* [2, N] out (in / out with accumulate) */
+  int accumulate;
+  void* ws;                       /* >= mmg_next_bn_ws_bytes(M, N) */
+  size_t ws_bytes;
+} mmg_next_bn_t;
+size_t mmg_next_bn_ws_bytes(int64_t M, int N);
+int mmg_linear_fwd_next_bn(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias, float* Y, int64_t M,
+                           int N, int K, int flags, const mmg_next_bn_t* next, void* stream);
+int mmg_linear_l2bwd_next_bn(const float* G, const float* out, const float* rnorm, const float* W, float* dZ, float* dX,
+                             int64_t M, int N, int K, float eps, const mmg_next_bn_t* next, void* stream);
+int mmg_linear_bnbwd_next_bn(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean, const float* rstd,
+                             const double* sums, double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ,
+                             float* dX, int64_t M, int N, int K, const mmg_next_bn_t* next, void* stream);
+int mmg_linear_bnbwd_rows_next_bn(const float* G_rows, const int32_t* row_pos, int64_t n_sel, const float* Y,
+                                  const mmg_prologue_t* pro, const float* mean, const float* rstd, const double* sums,
+                                  double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ, float* dX,
+                                  int64_t M, int N, int K, const mmg_next_bn_t* next, void* stream);
+int mmg_gather_rows_next_bn(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                            const mmg_next_bn_t* next, void* stream);
+
 /* Measurement hook (bench.py).  After mmg_probe_arm(n) the next n launches of the big kernels (from any host thread: the
  * backward of a step runs on the autograd engine's thread) carry a HIP start / stop event pair on the kernel itself (hipExtLaunchKernelGGL: the kernel's own begin / end
  * timestamps on its stream -- what rocprofv3 reports -- not a pair of extra queue entries around it).  mmg_probe_read

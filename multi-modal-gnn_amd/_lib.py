@@ -70,6 +70,11 @@ class BnFinT(C.Structure):
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p)]
 
 
+class NextBnT(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("pro", C.POINTER(PrologueT)), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("sums", C.c_void_p), ("accumulate", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
+
+
 class WgradReduceT(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("n4", C.c_int64), ("n_split", C.c_int), ("dW", C.c_void_p), ("dbias", C.c_void_p),
                 ("nk4", C.c_int64), ("accumulate", C.c_int)]
@@ -130,6 +135,14 @@ SIGNATURES = {
     "mmg_linear_fwd_l2norm": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
     "mmg_linear_bnbwd_supported": (C.c_int, [_i64, _i32, _i32]),
     "mmg_linear_l2bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "mmg_next_bn_ws_bytes": (_sz, [_i64, _i32]),
+    "mmg_linear_fwd_next_bn": (C.c_int, [_vp, _P(PrologueT), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _P(NextBnT), _vp]),
+    "mmg_linear_l2bwd_next_bn": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _P(NextBnT), _vp]),
+    "mmg_linear_bnbwd_next_bn": (C.c_int, [_vp, _vp, _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp,
+                                           _i64, _i32, _i32, _P(NextBnT), _vp]),
+    "mmg_linear_bnbwd_rows_next_bn": (C.c_int, [_vp, _vp, _i64, _vp, _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp,
+                                                _vp, _vp, _i64, _i32, _i32, _P(NextBnT), _vp]),
+    "mmg_gather_rows_next_bn": (C.c_int, [_P(RelT), _i32, _i64, _i32, _vp, _i32, _P(NextBnT), _vp]),
     "mmg_linear_bnbwd_rows": (C.c_int, [_vp, _vp, _i64, _vp, _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp,
                                         _i64, _i32, _i32, _vp]),
     "mmg_linear_bnbwd2": (C.c_int, [_vp, _vp, _vp, _P(PrologueT), _P(PrologueT), _vp, _vp, _vp, C.c_double, _vp, _vp, _vp,

@@ -850,17 +850,21 @@ __global__ __launch_bounds__(256) void k_mask_build(const int32_t* __restrict__ 
 // tile), which adds, accumulates and stores.  The loop body is LUT reads + MFMAs; the masks / scales / previous
 // output of the next tile are prefetched, and out goes through a buffer descriptor (no exec-masked tails).
 // Relation r owns the k-steps [K(r), K(r+1)), K = {0, K1, K2, NK} at compile time.
-template <int NK, int K1, int K2, bool ACCUM, int KH>
+// NBN: stat_partial receives the statistics of the BatchNorm backward that consumes `out` (NextBnDev, common.h) instead
+// of the forward ones -- the last layer's backward hands its patient gradient to the BatchNorm of the layer below.
+template <int NK, int K1, int K2, bool ACCUM, int KH, bool NBN>
 __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_rows, int n_tile_total, int D,
                                                  float* __restrict__ out, const unsigned (*lut)[4],
                                                  float (*rss)[3][32], float (*xch)[4][16][64],
-                                                 double* __restrict__ stat_partial) {
+                                                 double* __restrict__ stat_partial, NextBnDev nb) {
   double cs1 = 0.0, cs2 = 0.0;       // column sums / sums of squares of the final output (lane = feature column)
   constexpr int KB = KH * (NK / 2), KE = KB + NK / 2;               // this wave's k-steps
   constexpr bool USE0 = KB < K1, USE1 = KB < K2 && KE > K1, USE2 = KE > K2;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31, ft = wid & 3;
   const int dcol = blockIdx.y * 128 + ft * 32 + l31;
+  NextBnCol nbc = {};
+  if constexpr (NBN && KH == 0) nbc = next_bn_col(nb, dcol);
   // ---- table pieces: B[k = item 16 ks + 8 h + j][n = this lane's feature column]
   // (every load is issued before any is used: indices clamped, no branch in between -- a conditional load per element
   //  made this prologue a chain of 2 x 80 dependent round trips, ~25 us of a 67 us launch)
@@ -935,9 +939,22 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
     for (int i = 0; i < 16; ++i)
       dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0));
   };
+  // next-BatchNorm statistics: the pre-BatchNorm activation of the layer below, same shape and addressing as `out`; one
+  // tile ahead where registers allow (few table pieces), else in flight under this tile's products
+  constexpr bool NB_ON = NBN && KH == 0, NB_AHEAD = NB_ON && NK <= 8;
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(NB_ON ? nb.Y : out), 0,
+                                                                        (int)(unsigned)(n_rows * D * 4), 0x00020000);
+  float ynx[NB_ON ? 16 : 1];
+  auto loady = [&](int tile, float* dst) {
+    const unsigned vo = ((unsigned)(tile * 32 + 4 * h) * (unsigned)D + (unsigned)dcol) * 4u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ysrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0));
+  };
   if (t_beg < t_end) {
     loadm(t_beg, mcur); loadrs(t_beg, rsn);
     if (ACCUM && KH == 0) loadprev(t_beg, prev);
+    if constexpr (NB_AHEAD) loady(t_beg, ynx);
   }
 
   // The tile body, called once before the loop (peeled): the loop is then entered with the same loads / stores in flight
@@ -956,6 +973,14 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
 #pragma unroll
       for (int i = 0; i < 16; ++i) pc[i] = prev[i];
       loadprev(tn, prev);                                           // consumed one tile later
+    }
+    float yc[NB_ON ? 16 : 1];
+    if constexpr (NB_AHEAD) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) yc[i] = ynx[i];
+      loady(tn, ynx);
+    } else if constexpr (NB_ON) {
+      loady(tile, yc);
     }
     f32x16 acc[3];
 #pragma unroll
@@ -998,15 +1023,28 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
     __syncthreads();
     if (KH == 0) {
       const unsigned vo = ((unsigned)(tile * 32 + 4 * h) * (unsigned)D + (unsigned)dcol) * 4u;
-      float t1 = 0.f, t2 = 0.f;
+      if constexpr (NBN) {
+        float tv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float t = v[i] + xb[i][lane];
-        if (ACCUM) t += pc[i];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0);
-        if ((int64_t)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < n_rows) { t1 += t; t2 = fmaf(t, t, t2); }
+        for (int i = 0; i < 16; ++i) {
+          float t = v[i] + xb[i][lane];
+          if (ACCUM) t += pc[i];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0);
+          tv[i] = t;
+        }
+        const int64_t left = n_rows - (int64_t)tile * 32;
+        next_bn_tile(nb, nbc, tv, yc, left < 32 ? (int)left : 32, (int64_t)tile * 32, D, dcol, lane, cs1, cs2);
+      } else {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float t = v[i] + xb[i][lane];
+          if (ACCUM) t += pc[i];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0);
+          if ((int64_t)tile * 32 + (i & 3) + 8 * (i >> 2) + 4 * h < n_rows) { t1 += t; t2 = fmaf(t, t, t2); }
+        }
+        if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }
       }
-      if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }
     }
 #pragma unroll
     for (int i = 0; i < NK / 4; ++i) mcur[i] = mnxt[i];
@@ -1031,9 +1069,10 @@ __device__ __forceinline__ void gather_bits_body(const RelPack& rp, int64_t n_ro
   }
 }
 
-template <int NK, int K1, int K2, bool ACCUM>
+template <int NK, int K1, int K2, bool ACCUM, bool NBN = false>
 __global__ __launch_bounds__(512) void k_gather_bits(RelPack rp, int64_t n_rows, int n_tile_total, int D,
-                                                     float* __restrict__ out, double* __restrict__ stat_partial) {
+                                                     float* __restrict__ out, double* __restrict__ stat_partial,
+                                                     NextBnDev nb) {
   __shared__ __attribute__((aligned(16))) unsigned lut[256][4];
   __shared__ __attribute__((aligned(16))) float rss[8][3][32];
   __shared__ __attribute__((aligned(16))) float xch[2][4][16][64];
@@ -1044,8 +1083,8 @@ __global__ __launch_bounds__(512) void k_gather_bits(RelPack rp, int64_t n_rows,
       lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
   }
   __syncthreads();
-  if ((tid >> 8) == 0) gather_bits_body<NK, K1, K2, ACCUM, 0>(rp, n_rows, n_tile_total, D, out, lut, rss, xch, stat_partial);
-  else gather_bits_body<NK, K1, K2, ACCUM, 1>(rp, n_rows, n_tile_total, D, out, lut, rss, xch, stat_partial);
+  if ((tid >> 8) == 0) gather_bits_body<NK, K1, K2, ACCUM, 0, NBN>(rp, n_rows, n_tile_total, D, out, lut, rss, xch, stat_partial, nb);
+  else gather_bits_body<NK, K1, K2, ACCUM, 1, NBN>(rp, n_rows, n_tile_total, D, out, lut, rss, xch, stat_partial, nb);
 }
 
 // ------------------------------------------------------------------------------ gather, unit-per-wave layout
@@ -1359,8 +1398,22 @@ extern "C" int mmg_gather_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows,
   return mmg_gather_rows_stats(rels, n_rel, n_rows, D, out, accumulate, nullptr, nullptr, 0, stream);
 }
 
+extern "C" int mmg_next_bn_dev(const mmg_next_bn_t* next, int64_t M, int N, const char* what, NextBnDev* d, double** partial);
+extern "C" int mmg_next_bn_finish(const mmg_next_bn_t* next, const double* partial, int N, int rows, void* stream);
+extern "C" int mmg_next_bn_fallback(const float* G, int64_t M, int N, const mmg_next_bn_t* next, const char* what, void* stream);
+
+// next (nullable, exclusive with col_sums): the statistics of the BatchNorm backward that consumes `out` (mmg_next_bn_t)
 static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
-                                  double* col_sums, void* ws, size_t ws_bytes, void* stream, const mmg_bn_fin_t* fin) {
+                                  double* col_sums, void* ws, size_t ws_bytes, void* stream, const mmg_bn_fin_t* fin,
+                                  const mmg_next_bn_t* next = nullptr) {
+  MMG_CHECK_ARG(!(next && col_sums), "gather_rows: forward statistics and next-BatchNorm statistics are exclusive");
+  NextBnDev nbd = next_bn_none();
+  double* nb_partial = nullptr;
+  const bool nb_fused = next && next->pro && (next->pro->relu == MMG_ACT_NONE || next->pro->relu == MMG_ACT_RELU);
+  if (next) {
+    int rcn = mmg_next_bn_dev(next, n_rows, D, "gather_rows_next_bn", &nbd, &nb_partial);
+    if (rcn) return rcn;
+  }
   if (col_sums) {
     MMG_CHECK_ARG(n_rows > 0 && ws && ws_bytes >= mmg_gather_rows_stats_ws_bytes(n_rows, D),
                   "gather_rows_stats: workspace too small");
@@ -1369,6 +1422,7 @@ static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_ro
 #define MMG_GATHER_TAIL(what)                                                                                 \
   do {                                                                                                        \
     MMG_CHECK_LAUNCH(what);                                                                                   \
+    if (next) return mmg_next_bn_fallback(out, n_rows, D, next, "gather_rows_next_bn", stream);               \
     if (col_sums) {                                                                                           \
       int rc_ = mmg_col_reduce2(out, nullptr, col_sums, n_rows, D, ws, ws_bytes, stream);                     \
       if (rc_ || !fin) return rc_;                                                                            \
@@ -1401,9 +1455,16 @@ static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_ro
       int g = 256 / n_dchunks;
       if (g > n_tiles) g = n_tiles;
       dim3 grid((unsigned)g, (unsigned)n_dchunks);
-      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
-      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
+      if (nb_fused) {
+        if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1 | 512, (k_gather_bits<4, 4, 4, true, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, nb_partial, nbd);
+        else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 512, (k_gather_bits<4, 4, 4, false, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, nb_partial, nbd);
+        MMG_CHECK_LAUNCH("gather_rows(bits)");
+        return mmg_next_bn_finish(next, nb_partial, D, g, stream);
+      }
+      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
+      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
       MMG_CHECK_LAUNCH("gather_rows(bits)");
+      if (next) return mmg_next_bn_fallback(out, n_rows, D, next, "gather_rows_next_bn", stream);
       if (col_sums) return mmg_partial_sum_bn(partial, col_sums, D, g, fin, stream);
       return MMG_OK;
     }
@@ -1413,9 +1474,16 @@ static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_ro
       int g = 256 / n_dchunks;
       if (g > n_tiles) g = n_tiles;
       dim3 grid((unsigned)g, (unsigned)n_dchunks);
-      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
-      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial);
+      if (nb_fused) {
+        if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1 | 512, (k_gather_bits<20, 4, 12, true, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, nb_partial, nbd);
+        else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 512, (k_gather_bits<20, 4, 12, false, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, nb_partial, nbd);
+        MMG_CHECK_LAUNCH("gather_rows(bits)");
+        return mmg_next_bn_finish(next, nb_partial, D, g, stream);
+      }
+      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
+      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
       MMG_CHECK_LAUNCH("gather_rows(bits)");
+      if (next) return mmg_next_bn_fallback(out, n_rows, D, next, "gather_rows_next_bn", stream);
       if (col_sums) return mmg_partial_sum_bn(partial, col_sums, D, g, fin, stream);
       return MMG_OK;
     }
@@ -1442,6 +1510,7 @@ static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_ro
                    gp.gu, rp, n_rows, n_tiles, D, out, partial);
       }
       MMG_CHECK_LAUNCH("gather_rows(units)");
+      if (next) return mmg_next_bn_fallback(out, n_rows, D, next, "gather_rows_next_bn", stream);
       if (col_sums) return mmg_partial_sum_bn(partial, col_sums, D, g, fin, stream);
       return MMG_OK;
     }
@@ -1474,6 +1543,11 @@ static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_ro
   else hipLaunchKernelGGL(k_gather<4>, dim3(nb), dim3(256), 0, st, rp, n_rows, out, accumulate);
   MMG_GATHER_TAIL("gather_rows");
 #undef MMG_GATHER_TAIL
+}
+
+extern "C" int mmg_gather_rows_next_bn(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,
+                                       const mmg_next_bn_t* next, void* stream) {
+  return gather_rows_stats_impl(rels, n_rel, n_rows, D, out, accumulate, nullptr, nullptr, 0, stream, nullptr, next);
 }
 
 extern "C" int mmg_gather_rows_stats(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D, float* out, int accumulate,

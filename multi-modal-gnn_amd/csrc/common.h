@@ -124,6 +124,26 @@ __host__ __device__ static inline bool mmg_keep(uint64_t seed, uint32_t site, ui
   return mmg_rng_field(w0, w1, (uint32_t)elem & 3u) >= mmg_keep_threshold(p);
 }
 
+// Dropout keep-fields of a 32 x 32 tile held in the MFMA C layout (lane = column col0 + (lane & 31), register r = tile row
+// (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) of a row-major [*, ncols] tensor: element (row, col) belongs to the RNG group
+// (row * ncols + col) >> 2, shared by the four lanes of a quad.  For the four registers 4g .. 4g+3 quad lane j hashes the
+// row of register 4g + j (ONE hash per lane instead of four) and the words travel inside the quad by DPP:
+//   mmg_c_layout_hash(key, first row of the tile, ncols, col, lane, g, &w0, &w1);
+//   field of register 4g + j  =  mmg_rng_field(mmg_quad_bcast(w0, j), mmg_quad_bcast(w1, j), col & 3)
+__device__ __forceinline__ void mmg_c_layout_hash(uint32_t key, uint64_t row_first, uint32_t ncols, int col, int lane, int g,
+                                                  uint32_t* w0, uint32_t* w1) {
+  const uint64_t row = row_first + (uint64_t)((lane & 3) + 8 * g + 4 * (lane >> 5));
+  mmg_rng_group(key, (row * (uint64_t)ncols + (uint64_t)col) >> 2, w0, w1);
+}
+__device__ __forceinline__ uint32_t mmg_quad_bcast(uint32_t v, int j) {     // j must fold to a constant (unrolled loops)
+  switch (j & 3) {
+    case 0: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xF, 0xF, true);   // quad_perm: every lane reads quad lane j
+    case 1: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xF, 0xF, true);
+    case 2: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xF, 0xF, true);
+    default: return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xF, 0xF, true);
+  }
+}
+
 // activation codes of mmg_prologue_t::relu (include/mmgnn.h): the reference's HeteroRGCN accepts relu, elu and leaky_relu
 // (src/model.py:145-152) for its conv layers.  act'(v) is taken at the PRE-activation value v, as autograd does.
 __device__ static inline float mmg_act(int code, float v) {
@@ -190,6 +210,52 @@ __device__ static inline float mmg_pro_apply(const ProDev& pr, float x, float sc
     v = mmg_keep(pr.seed, pr.site, e, pr.p) ? v * pr.inv_keep : 0.f;
   }
   return v;
+}
+
+// ---- mmg_next_bn_t: the column statistics of the BatchNorm backward that CONSUMES a kernel's output (the two sums of
+// mmg_bn_bwd_stats), taken from the 32 x 32 output tile while it sits in the MFMA C layout.  The separate statistics pass
+// read the [M, N] gradient and the [M, N] pre-BatchNorm activation again (k_col_reduce<1>: 34-55 us four times a step at
+// the x100 shape); here the gradient never leaves the registers and only Y is read.  Sixteen rows are summed in fp32,
+// tiles in fp64 (as the forward statistics of k_linear_fwd_x6 are), workgroups in a fixed order by mmg_partial_sum.
+struct NextBnDev { const float* Y; const float* mean; const float* rstd; ProDev pr; };
+struct NextBnCol { float sc, sh, mu, rs; bool relu, drop; };
+static inline NextBnDev next_bn_none() {
+  NextBnDev d;
+  d.Y = nullptr; d.mean = nullptr; d.rstd = nullptr; d.pr = mmg_pro_dev(nullptr);
+  return d;
+}
+__device__ __forceinline__ NextBnCol next_bn_col(NextBnDev& nb, int col) {
+  nb.pr.resolve();
+  NextBnCol c;
+  c.sc = nb.pr.scale ? nb.pr.scale[col] : 1.f;
+  c.sh = nb.pr.scale ? nb.pr.shift[col] : 0.f;
+  c.mu = nb.mean[col]; c.rs = nb.rstd[col];
+  c.relu = nb.pr.relu == MMG_ACT_RELU; c.drop = nb.pr.p > 0.f;
+  return c;
+}
+__device__ __forceinline__ void next_bn_tile(const NextBnDev& nb, const NextBnCol& cc, const float* v, const float* yv, int rows,
+                                             int64_t row0, int N, int col, int lane, double& cs1, double& cs2) {
+  const int h4 = 4 * (lane >> 5);
+  const uint32_t sub = (uint32_t)col & 3u;
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {            // registers 4 g4 .. 4 g4 + 3: tile rows 8 g4 + 4 h + 0..3
+    uint32_t w0 = 0u, w1 = 0u;
+    if (cc.drop) mmg_c_layout_hash(nb.pr.key, (uint64_t)(nb.pr.row_offset + row0), (uint32_t)N, col, lane, g4, &w0, &w1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * g4 + j, r = j + 8 * g4 + h4;
+      const float y = yv[i];
+      float g = v[i];
+      const float act = fmaf(y, cc.sc, cc.sh);
+      if (cc.relu && !(act > 0.f)) g = 0.f;
+      if (cc.drop) g = mmg_rng_field(mmg_quad_bcast(w0, j), mmg_quad_bcast(w1, j), sub) >= nb.pr.thr ? g * nb.pr.inv_keep : 0.f;
+      g = r < rows ? g : 0.f;
+      const float xh = (y - cc.mu) * cc.rs;
+      t1 += g; t2 = fmaf(g, xh, t2);
+    }
+  }
+  cs1 += (double)t1; cs2 += (double)t2;
 }
 
 __device__ static inline float wave_sum(float v) {

@@ -124,14 +124,14 @@ __global__ __launch_bounds__(NT) void k_col_reduce(const float* __restrict__ A, 
 
 // one wave per output element: lanes stride over the block partials, then a fixed-order wave reduction
 __global__ __launch_bounds__(256) void k_partial_sum(const double* __restrict__ partial, double* __restrict__ out, int n,
-                                                     int nblk) {
+                                                     int nblk, const double* add = nullptr) {
   const int lane = threadIdx.x & 63;
   const int i = (blockIdx.x * 256 + threadIdx.x) >> 6;
   if (i >= n) return;
   double s = 0;
   for (int b = lane; b < nblk; b += 64) s += partial[(size_t)b * n + i];
   s = wave_sum_d(s);
-  if (lane == 0) out[i] = s;
+  if (lane == 0) out[i] = add ? add[i] + s : s;     // (add may alias out: one reader-writer per element)
 }
 
 // one column of the BatchNorm fold (shared by k_bn_finalize and k_partial_sum_bn: the same arithmetic, bit for bit)
@@ -531,6 +531,13 @@ int run_col_reduce(const float* A, const float* B, const ProDev& pr, const float
 // internal (gemm.hip): out[i] = sum over n_rows partial rows, one wave per output, fixed order
 extern "C" int mmg_partial_sum(const double* partial, double* out, int n, int n_rows, void* stream) {
   hipLaunchKernelGGL(k_partial_sum, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, out, n, n_rows);
+  MMG_CHECK_LAUNCH("partial_sum");
+  return MMG_OK;
+}
+
+// internal (gemm.hip, aggregate.hip): out[i] = add[i] + the sum (add nullable, may alias out)
+extern "C" int mmg_partial_sum_add(const double* partial, double* out, int n, int n_rows, const double* add, void* stream) {
+  hipLaunchKernelGGL(k_partial_sum, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, out, n, n_rows, add);
   MMG_CHECK_LAUNCH("partial_sum");
   return MMG_OK;
 }

@@ -189,14 +189,26 @@ typedef unsigned xu32x4 __attribute__((ext_vector_type(4)));
 #define MMG_NT_WG 0
 #endif
 
+// (NextBnDev and its epilogue arithmetic: common.h)
+// the Y values of this lane's 16 tile elements; vo = byte offset of (row 4h, this lane's column) in the tile
+__device__ __forceinline__ void next_bn_load(const NextBnDev& nb, int64_t tile, int rows, int N, int c0, int vo, float* yv) {
+  const size_t off = (size_t)(rows ? tile : 0) * 32 * N + c0;
+  const int bytes = rows ? (rows * N - c0) * 4 : 0;
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(nb.Y) + off, 0, bytes, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    yv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ysrc, vo, ((i & 3) + 8 * (i >> 2)) * N * 4, MMG_NT_LD));
+}
 // L2: the row L2 normalisation that follows the layer (F.normalize, src/model.py:232) in the epilogue -- the workgroup
 // holds whole rows (N == 32 * WN), so Y receives  y / max(|y|, eps)  and rn_out[row] = 1 / max(|y|, eps); the separate
 // pass read and wrote the [M, N] tensor once more.
-template <int K, int WN, bool PRO, bool ACC, bool L2 = false>   // WN waves along N (32 columns each) over a 32-row tile: 64 * WN threads
+// NBN: stat_partial receives the statistics of the NEXT BatchNorm backward (nb, see NextBnDev) instead of the forward ones.
+template <int K, int WN, bool PRO, bool ACC, bool L2 = false, bool NBN = false>   // WN waves along N (32 columns each) over a 32-row tile: 64 * WN threads
 __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_linear_fwd_x6(
     const float* __restrict__ X, ProDev pr, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, int64_t M, int N, int flags, double* __restrict__ stat_partial, float* __restrict__ rn_out,
-    float l2_eps) {
+    float l2_eps, NextBnDev nb) {
+  static_assert(!(NBN && L2), "one epilogue at a time");
   __shared__ float l2_part[L2 ? WN * 32 : 1], l2_rn[L2 ? 32 : 1];
   if (PRO) pr.resolve();
   double cs1 = 0.0, cs2 = 0.0;          // column statistics of the output (BatchNorm batch stats) ride along: lane = column
@@ -233,6 +245,8 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
     }
   }
   const float bv = bias ? bias[col] : 0.f;
+  NextBnCol nbc = {};
+  if constexpr (NBN) nbc = next_bn_col(nb, col);
 
   constexpr int K4 = K / 4;
   const int kc4 = tid % K4;                 // float4 column: this thread always touches the same 4 k's
@@ -320,6 +334,8 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
     for (int i = 0; i < 16; ++i)
       acc[i] = ACC ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, yvo, ((i & 3) + 8 * (i >> 2)) * N * 4, 0))
                    : 0.f;
+    float nby[NBN ? 16 : 1];
+    if constexpr (NBN) next_bn_load(nb, tt, rows, N, c0, yvo, nby);   // in flight under the products
     if constexpr (!WEAVE) {
       stage(tt + G, buf ^ 1, nx);              // the other buffer: its readers passed the barrier of the last tile
       fetch(tt + 3 * G, nx);
@@ -422,16 +438,26 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
       }
       return;
     }
-    float t1 = 0.f, t2 = 0.f;
+    if constexpr (NBN) {
+      float vv[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int r = (i & 3) + 8 * (i >> 2);
-      const float v = acc[i] + bv;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, yvo, r * N * 4, MMG_NT_ST);
-      const float vs = r + 4 * h < rows ? v : 0.f;
-      t1 += vs; t2 = fmaf(vs, vs, t2);
+      for (int i = 0; i < 16; ++i) {
+        vv[i] = acc[i] + bv;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[i]), ys, yvo, ((i & 3) + 8 * (i >> 2)) * N * 4, MMG_NT_ST);
+      }
+      next_bn_tile(nb, nbc, vv, nby, rows, tt * BM, N, col, lane, cs1, cs2);
+    } else {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = (i & 3) + 8 * (i >> 2);
+        const float v = acc[i] + bv;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, yvo, r * N * 4, MMG_NT_ST);
+        const float vs = r + 4 * h < rows ? v : 0.f;
+        t1 += vs; t2 = fmaf(vs, vs, t2);
+      }
+      if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }     // 16 rows in fp32, tiles in fp64
     }
-    if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }     // 16 rows in fp32, tiles in fp64
     __syncthreads();                         // buf fully read, buf^1 fully written
   };
   // A tile index past the end is harmless (zero-sized descriptors).  The first pair is peeled: the loop is then entered
@@ -691,17 +717,18 @@ inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y 
   return gy;
 }
 
-template <int K, int WN, bool PRO, bool ACC, bool L2 = false>
+template <int K, int WN, bool PRO, bool ACC, bool L2 = false, bool NBN = false>
 int launch_fwd_x6_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
-                    int flags, hipStream_t st, double* stat_partial, float* rn_out = nullptr, float l2_eps = 0.f) {
+                    int flags, hipStream_t st, double* stat_partial, float* rn_out = nullptr, float l2_eps = 0.f,
+                    const NextBnDev& nb = next_bn_none()) {
   constexpr int BN = 32 * WN;
   const int n_slices = N / BN;
   const int64_t gy = fwd_x6_rows(M, N, BN, K);
   constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
-  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_x6<K, WN, PRO, ACC, L2>, lds>::set()), "linear_fwd(attr)");
-  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0) | (L2 ? 32 : 0),
-             (k_linear_fwd_x6<K, WN, PRO, ACC, L2>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds, st, X,
-             pr, W, bias, Y, M, N, flags, stat_partial, rn_out, l2_eps);
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_x6<K, WN, PRO, ACC, L2, NBN>, lds>::set()), "linear_fwd(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0) | (L2 ? 32 : 0) | (NBN ? 512 : 0),
+             (k_linear_fwd_x6<K, WN, PRO, ACC, L2, NBN>), dim3((unsigned)n_slices, (unsigned)gy), dim3(64 * WN), lds, st, X,
+             pr, W, bias, Y, M, N, flags, stat_partial, rn_out, l2_eps, nb);
   return 0;
 }
 
@@ -735,10 +762,13 @@ struct BnBwdDev {
   float* dZ; float* dbeta; float* dgamma; float l2_eps; const float* G2; const int32_t* row_pos; int64_t n_sel;
 };
 
-template <int K, int WN, int MODE = 0>
+// NBN: the statistics of the NEXT BatchNorm backward -- the one that consumes DX -- from the epilogue (NextBnDev),
+// partial[row-set][2][N] -> mmg_partial_sum.
+template <int K, int WN, int MODE = 0, bool NBN = false>
 __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(const float* __restrict__ G, BnBwdDev bb, ProDev pr,
                                                                 const float* __restrict__ W, float* __restrict__ DX,
-                                                                int64_t M, ProDev pr2) {
+                                                                int64_t M, ProDev pr2, NextBnDev nb,
+                                                                double* __restrict__ stat_partial) {
   if (MODE != 1) pr.resolve();
   if (MODE == 2) pr2.resolve();
   constexpr int LDP = K + 8, N = 32 * WN, NK = K / 16, NTHR = 64 * WN, BM = 32;
@@ -760,6 +790,9 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
         wb[ks][0][j] = a; wb[ks][1][j] = b; wb[ks][2][j] = (__bf16)(r1 - (float)b);
       }
   }
+  NextBnCol nbc = {};
+  double cs1 = 0.0, cs2 = 0.0;
+  if constexpr (NBN) nbc = next_bn_col(nb, col);
   constexpr int K4 = K / 4;
   const int kc4 = tid % K4, c = kc4 * 4;    // this thread always touches the same 4 columns of G / Y / dZ
   constexpr int ROWS_PER_PASS = NTHR / K4;
@@ -778,7 +811,11 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
       }
     }
   }
-  if (MODE != 1 && bb.sums && blockIdx.y == 0 && tid < K4) {          // d beta / d gamma ride along
+  // (the row-set index through readfirstlane: behind the lane-dependent branch below the compiler otherwise carries
+  //  blockIdx.y -- known to be 0 inside it -- in a VECTOR register, every tile index and buffer descriptor derived from it
+  //  becomes "divergent", and each of the ~135 buffer accesses of the kernel is wrapped in a waterfall loop)
+  const int by_u = __builtin_amdgcn_readfirstlane((int)blockIdx.y);
+  if (MODE != 1 && bb.sums && by_u == 0 && tid < K4) {          // d beta / d gamma ride along
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       if (bb.dbeta) bb.dbeta[c + j] = (float)bb.sums[c + j];
@@ -788,7 +825,7 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
   const bool relu = MODE != 1 && pr.relu == MMG_ACT_RELU, drop = MODE != 1 && pr.p > 0.f, has_bn = MODE != 1 && pr.scale != nullptr;
   const bool drop2 = MODE == 2 && pr2.p > 0.f;
   const int64_t n_tiles = (M + BM - 1) / BM;
-  const int64_t GY = gridDim.y, t0 = blockIdx.y;
+  const int64_t GY = gridDim.y, t0 = by_u;
   if (t0 >= n_tiles) return;
   const int n_my = (int)((n_tiles - t0 + GY - 1) / GY);
   auto rows_of = [&](int64_t tile) __attribute__((always_inline)) -> int {
@@ -912,6 +949,8 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     stage(tt + GY, buf ^ 1);                   // the other buffer: its readers passed the barrier of the last tile
     fetch(tt + 2 * GY);
+    float nby[NBN ? 16 : 1];
+    if constexpr (NBN) next_bn_load(nb, tt, rows, N, 0, yvo, nby);   // in flight under the products
     __builtin_amdgcn_sched_barrier(0);         // keep the fetch ahead of the matrix loop
     const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + l31 * LDP + 8 * h;
 #pragma unroll
@@ -926,12 +965,14 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f, wb[ks][1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f, wb[ks][0], acc, 0, 0, 0);
     }
+    float vv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float v = acc[i];                // (a bit_cast straight from the vector element stored element 0 sixteen times)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), xs, yvo, ((i & 3) + 8 * (i >> 2)) * N * 4,
+      vv[i] = acc[i];                        // (a bit_cast straight from the vector element stored element 0 sixteen times)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[i]), xs, yvo, ((i & 3) + 8 * (i >> 2)) * N * 4,
                                             MMG_NT_ST);
     }
+    if constexpr (NBN) next_bn_tile(nb, nbc, vv, nby, rows, tt * BM, N, col, lane, cs1, cs2);
     __syncthreads();                         // buf fully read, buf^1 fully written
   };
   tile_body(t0, 0);
@@ -940,19 +981,36 @@ __global__ __launch_bounds__(64 * WN, WN == 4 ? 2 : 1) void k_linear_bnbwd_x6(co
     tile_body(t0 + (int64_t)i * GY, 0);
     tile_body(t0 + (int64_t)(i + 1) * GY, 1);
   }
+  if constexpr (NBN) {
+    // two partials per column (the lane halves) -> one: partial[row-set][2][N], fixed order
+    double* red = reinterpret_cast<double*>(planes);          // the planes are dead: every wave passed the last barrier
+    red[(h * 2 + 0) * N + col] = cs1;
+    red[(h * 2 + 1) * N + col] = cs2;
+    __syncthreads();
+    for (int e = tid; e < 2 * N; e += NTHR) {
+      const int which = e / N, cc = e % N;
+      stat_partial[((size_t)by_u * 2 + which) * N + cc] = red[which * N + cc] + red[(2 + which) * N + cc];
+    }
+  }
 }
 
-template <int K, int WN, int MODE = 0>
-int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const float* W, float* DX, int64_t M, hipStream_t st,
-                    const ProDev& pr2 = mmg_pro_dev(nullptr)) {
-  constexpr int N = 32 * WN;
+inline int64_t bnbwd_x6_rows(int64_t M, int K) {       // grid.y of k_linear_bnbwd_x6 (= rows of its partial statistics)
   // one workgroup spans all N columns; two workgroups per CU whatever the width (register-bound), one at K = 256
   const int64_t n_tiles_ = (M + 31) / 32, want_ = K <= 128 ? 512 : 256;
-  const int64_t gy = want_ < n_tiles_ ? want_ : (n_tiles_ > 0 ? n_tiles_ : 1);
+  return want_ < n_tiles_ ? want_ : (n_tiles_ > 0 ? n_tiles_ : 1);
+}
+
+template <int K, int WN, int MODE = 0, bool NBN = false>
+int launch_bnbwd_x6(const float* G, const BnBwdDev& bb, const ProDev& pr, const float* W, float* DX, int64_t M, hipStream_t st,
+                    const ProDev& pr2 = mmg_pro_dev(nullptr), const NextBnDev& nb = next_bn_none(),
+                    double* stat_partial = nullptr) {
+  constexpr int N = 32 * WN;
+  const int64_t gy = bnbwd_x6_rows(M, K);
   constexpr int lds = 2 * 3 * 32 * (K + 8) * 2;
-  MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN, MODE>, lds>::set()), "linear_bnbwd(attr)");
-  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, MODE == 1 ? 64 : (MODE == 2 ? 16 | 128 : (MODE == 3 ? 16 | 256 : 16)), (k_linear_bnbwd_x6<K, WN, MODE>), dim3(1u, (unsigned)gy),
-             dim3(64 * WN), lds, st, G, bb, pr, W, DX, M, pr2);
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_bnbwd_x6<K, WN, MODE, NBN>, lds>::set()), "linear_bnbwd(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, K, (MODE == 1 ? 64 : (MODE == 2 ? 16 | 128 : (MODE == 3 ? 16 | 256 : 16))) | (NBN ? 512 : 0),
+             (k_linear_bnbwd_x6<K, WN, MODE, NBN>), dim3(1u, (unsigned)gy),
+             dim3(64 * WN), lds, st, G, bb, pr, W, DX, M, pr2, nb, stat_partial);
   return 0;
 }
 
@@ -1490,6 +1548,51 @@ extern "C" int mmg_bn_finalize(const double* sums, int64_t count, const float* g
                                float* running_var, int training, int n_updates, float momentum, float eps, float* scale,
                                float* shift, float* mean, float* rstd, int N, void* stream);
 
+// ---- mmg_next_bn_t (include/mmgnn.h): host side shared by the producers (this file and aggregate.hip)
+extern "C" int mmg_partial_sum_add(const double* partial, double* out, int n, int n_rows, const double* add, void* stream);
+extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean, const float* rstd,
+                                double* sums, int64_t M, int N, void* ws, size_t ws_bytes, void* stream);
+
+// workspace: <= 768 partial rows of a fused producer, or (fallback) one row of sums + the separate statistics pass
+extern "C" size_t mmg_next_bn_ws_bytes(int64_t M, int N) {
+  if (M < 0 || N <= 0) return 0;
+  const size_t a = (size_t)768 * 2 * N * sizeof(double) + 256;
+  const size_t b = (size_t)2 * N * sizeof(double) + 512 + mmg_col_reduce2_ws_bytes(M, N);
+  return a > b ? a : b;
+}
+
+// internal: validates the descriptor and fills the device view; *partial = the aligned workspace
+extern "C" int mmg_next_bn_dev(const mmg_next_bn_t* next, int64_t M, int N, const char* what, NextBnDev* d, double** partial) {
+  MMG_CHECK_ARG(next->y && next->pro && next->mean && next->rstd && next->sums, "%s: next-BatchNorm descriptor with a null field", what);
+  MMG_CHECK_ARG(!next->pro->scale || next->pro->shift, "%s: next BatchNorm: scale without shift", what);
+  MMG_CHECK_ARG(next->ws && next->ws_bytes >= mmg_next_bn_ws_bytes(M, N), "%s: next BatchNorm: workspace too small", what);
+  d->Y = next->y; d->mean = next->mean; d->rstd = next->rstd;
+  d->pr = mmg_pro_dev(next->pro);
+  *partial = (double*)(((uintptr_t)next->ws + 255) & ~(uintptr_t)255);
+  return MMG_OK;
+}
+// internal: partial[rows][2][N] -> sums (or sums += when the descriptor says so), fixed order
+extern "C" int mmg_next_bn_finish(const mmg_next_bn_t* next, const double* partial, int N, int rows, void* stream) {
+  return mmg_partial_sum_add(partial, next->sums, 2 * N, rows, next->accumulate ? next->sums : nullptr, stream);
+}
+// internal: the producer has no fused form for this shape -- the separate statistics pass over its finished output G
+extern "C" int mmg_next_bn_fallback(const float* G, int64_t M, int N, const mmg_next_bn_t* next, const char* what, void* stream) {
+  NextBnDev d;
+  double* tmp;
+  int rc = mmg_next_bn_dev(next, M, N, what, &d, &tmp);
+  if (rc) return rc;
+  unsigned char* rest = (unsigned char*)(tmp + 2 * N);
+  const size_t used = (size_t)(rest - (unsigned char*)next->ws);
+  rc = mmg_bn_bwd_stats(G, next->y, next->pro, next->mean, next->rstd, next->accumulate ? tmp : next->sums, M, N, rest,
+                        next->ws_bytes - used, stream);
+  if (rc || !next->accumulate) return rc;
+  return mmg_partial_sum_add(tmp, next->sums, 2 * N, 1, next->sums, stream);
+}
+// relu / none only in the fused epilogues (the fallback takes every activation mmg_bn_bwd_stats does)
+static inline bool next_bn_fusable(const mmg_next_bn_t* next) {
+  return next->pro && (next->pro->relu == MMG_ACT_NONE || next->pro->relu == MMG_ACT_RELU);
+}
+
 extern "C" size_t mmg_linear_fwd_stats_ws_bytes(int64_t M, int N) {
   if (M < 0 || N <= 0) return 0;
   const size_t a = (size_t)768 * 2 * N * sizeof(double) + 256;       // <= 768 partial rows from the GEMM epilogue
@@ -1579,6 +1682,29 @@ extern "C" int mmg_linear_fwd_stats_bn(const float* X, const mmg_prologue_t* pro
   return linear_fwd_stats_impl(X, pro, W, bias, Y, M, N, K, flags, col_sums, ws, ws_bytes, stream, fin);
 }
 
+extern "C" int mmg_linear_fwd_next_bn(const float* X, const mmg_prologue_t* pro, const float* W, const float* bias, float* Y,
+                                      int64_t M, int N, int K, int flags, const mmg_next_bn_t* next, void* stream) {
+  if (!next) return mmg_linear_fwd(X, pro, W, bias, Y, M, N, K, flags, stream);
+  const ProDev pr = mmg_pro_dev(pro);
+  const bool fused = M > 512 && N % 128 == 0 && N <= 4096 && (K == 64 || K == 128) && (flags & ~MMG_LIN_W_KN) == 0 &&
+                     !(pr.scale || pr.relu || pr.p > 0.f) && next_bn_fusable(next);
+  if (!fused) {
+    int rc0 = mmg_linear_fwd(X, pro, W, bias, Y, M, N, K, flags, stream);
+    return rc0 ? rc0 : mmg_next_bn_fallback(Y, M, N, next, "linear_fwd_next_bn", stream);
+  }
+  MMG_CHECK_ARG(X && W && Y, "linear_fwd_next_bn: null buffer");
+  NextBnDev nb;
+  double* partial;
+  int rc = mmg_next_bn_dev(next, M, N, "linear_fwd_next_bn", &nb, &partial);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 64) rc = launch_fwd_x6_v<64, 4, false, false, false, true>(X, pr, W, bias, Y, M, N, flags, st, partial, nullptr, 0.f, nb);
+  else rc = launch_fwd_x6_v<128, 4, false, false, false, true>(X, pr, W, bias, Y, M, N, flags, st, partial, nullptr, 0.f, nb);
+  if (rc) return rc;
+  MMG_CHECK_LAUNCH("linear_fwd_next_bn");
+  return mmg_next_bn_finish(next, partial, N, (int)fwd_x6_rows(M, N, 128, K), stream);
+}
+
 extern "C" int mmg_linear_fwd_l2norm_supported(int64_t M, int N, int K) {
   return (M > 512 && ((N == 128 && (K == 64 || K == 128)) || (N == 64 && (K == 64 || K == 128)))) ? 1 : 0;
 }
@@ -1614,9 +1740,21 @@ extern "C" int mmg_linear_bnbwd_supported(int64_t M, int N, int K) {
   return (M > 512 && (K == 64 || K == 128) && (N == 64 || N == 128)) ? 1 : 0;
 }
 
+extern "C" int mmg_linear_bnbwd_next_bn(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
+                                        const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
+                                        const float* W, float* dZ, float* dX, int64_t M, int N, int K,
+                                        const mmg_next_bn_t* next, void* stream);
+
 extern "C" int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
                                 const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
                                 const float* W, float* dZ, float* dX, int64_t M, int N, int K, void* stream) {
+  return mmg_linear_bnbwd_next_bn(G, Y, pro, mean, rstd, sums, inv_count, dbeta, dgamma, W, dZ, dX, M, N, K, nullptr, stream);
+}
+
+extern "C" int mmg_linear_bnbwd_next_bn(const float* G, const float* Y, const mmg_prologue_t* pro, const float* mean,
+                                        const float* rstd, const double* sums, double inv_count, float* dbeta, float* dgamma,
+                                        const float* W, float* dZ, float* dX, int64_t M, int N, int K,
+                                        const mmg_next_bn_t* next, void* stream) {
   MMG_CHECK_ARG(mmg_linear_bnbwd_supported(M, N, K), "linear_bnbwd: M=%lld N=%d K=%d unsupported (M > 512, K and N in {64,128})",
                 (long long)M, N, K);
   MMG_CHECK_ARG(G && Y && W && dZ && dX, "linear_bnbwd: null buffer");
@@ -1627,11 +1765,21 @@ extern "C" int mmg_linear_bnbwd(const float* G, const float* Y, const mmg_prolog
   BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, nullptr, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (next && K == 128 && N == 128 && next_bn_fusable(next)) {
+    NextBnDev nb;
+    double* partial;
+    rc = mmg_next_bn_dev(next, M, N, "linear_bnbwd", &nb, &partial);
+    if (rc) return rc;
+    rc = launch_bnbwd_x6<128, 4, 0, true>(G, bb, pr, W, dX, M, st, mmg_pro_dev(nullptr), nb, partial);
+    if (rc) return rc;
+    MMG_CHECK_LAUNCH("linear_bnbwd");
+    return mmg_next_bn_finish(next, partial, N, (int)bnbwd_x6_rows(M, K), stream);
+  }
   if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2>(G, bb, pr, W, dX, M, st);
   else rc = N == 128 ? launch_bnbwd_x6<64, 4>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<64, 2>(G, bb, pr, W, dX, M, st);
   if (rc) return rc;
   MMG_CHECK_LAUNCH("linear_bnbwd");
-  return MMG_OK;
+  return next ? mmg_next_bn_fallback(dX, M, N, next, "linear_bnbwd", stream) : MMG_OK;
 }
 
 extern "C" int mmg_linear_bnbwd2(const float* G, const float* G2, const float* Y, const mmg_prologue_t* pro,
@@ -1652,10 +1800,25 @@ extern "C" int mmg_linear_bnbwd2(const float* G, const float* G2, const float* Y
   return MMG_OK;
 }
 
+extern "C" int mmg_linear_bnbwd_rows_next_bn(const float* G_rows, const int32_t* row_pos, int64_t n_sel, const float* Y,
+                                             const mmg_prologue_t* pro, const float* mean, const float* rstd,
+                                             const double* sums, double inv_count, float* dbeta, float* dgamma, const float* W,
+                                             float* dZ, float* dX, int64_t M, int N, int K, const mmg_next_bn_t* next,
+                                             void* stream);
+
 extern "C" int mmg_linear_bnbwd_rows(const float* G_rows, const int32_t* row_pos, int64_t n_sel, const float* Y,
                                      const mmg_prologue_t* pro, const float* mean, const float* rstd, const double* sums,
                                      double inv_count, float* dbeta, float* dgamma, const float* W, float* dZ, float* dX,
                                      int64_t M, int N, int K, void* stream) {
+  return mmg_linear_bnbwd_rows_next_bn(G_rows, row_pos, n_sel, Y, pro, mean, rstd, sums, inv_count, dbeta, dgamma, W, dZ, dX, M,
+                                       N, K, nullptr, stream);
+}
+
+extern "C" int mmg_linear_bnbwd_rows_next_bn(const float* G_rows, const int32_t* row_pos, int64_t n_sel, const float* Y,
+                                             const mmg_prologue_t* pro, const float* mean, const float* rstd,
+                                             const double* sums, double inv_count, float* dbeta, float* dgamma, const float* W,
+                                             float* dZ, float* dX, int64_t M, int N, int K, const mmg_next_bn_t* next,
+                                             void* stream) {
   MMG_CHECK_ARG(mmg_linear_bnbwd_supported(M, N, K) && K == 128 && N == 128,
                 "linear_bnbwd_rows: M=%lld N=%d K=%d unsupported (M > 512, K = N = 128)", (long long)M, N, K);
   MMG_CHECK_ARG(Y && W && dZ && dX && pro && row_pos, "linear_bnbwd_rows: null buffer");
@@ -1665,14 +1828,32 @@ extern "C" int mmg_linear_bnbwd_rows(const float* G_rows, const int32_t* row_pos
   MMG_CHECK_ARG(!sums || pro->scale, "linear_bnbwd_rows: sums without a BatchNorm fold");
   const ProDev pr = mmg_pro_dev(pro);
   BnBwdDev bb{Y, mean, rstd, sums, inv_count, dZ, dbeta, dgamma, 0.f, nullptr, row_pos, n_sel};
+  if (next && next_bn_fusable(next)) {
+    NextBnDev nb;
+    double* partial;
+    int rc0 = mmg_next_bn_dev(next, M, N, "linear_bnbwd_rows", &nb, &partial);
+    if (rc0) return rc0;
+    rc0 = launch_bnbwd_x6<128, 4, 3, true>(G_rows ? G_rows : Y, bb, pr, W, dX, M, (hipStream_t)stream, mmg_pro_dev(nullptr), nb, partial);
+    if (rc0) return rc0;
+    MMG_CHECK_LAUNCH("linear_bnbwd_rows");
+    return mmg_next_bn_finish(next, partial, N, (int)bnbwd_x6_rows(M, K), stream);
+  }
   int rc = launch_bnbwd_x6<128, 4, 3>(G_rows ? G_rows : Y, bb, pr, W, dX, M, (hipStream_t)stream);
   if (rc) return rc;
   MMG_CHECK_LAUNCH("linear_bnbwd_rows");
-  return MMG_OK;
+  return next ? mmg_next_bn_fallback(dX, M, N, next, "linear_bnbwd_rows", stream) : MMG_OK;
 }
+
+extern "C" int mmg_linear_l2bwd_next_bn(const float* G, const float* out, const float* rnorm, const float* W, float* dZ,
+                                        float* dX, int64_t M, int N, int K, float eps, const mmg_next_bn_t* next, void* stream);
 
 extern "C" int mmg_linear_l2bwd(const float* G, const float* out, const float* rnorm, const float* W, float* dZ, float* dX,
                                 int64_t M, int N, int K, float eps, void* stream) {
+  return mmg_linear_l2bwd_next_bn(G, out, rnorm, W, dZ, dX, M, N, K, eps, nullptr, stream);
+}
+
+extern "C" int mmg_linear_l2bwd_next_bn(const float* G, const float* out, const float* rnorm, const float* W, float* dZ,
+                                        float* dX, int64_t M, int N, int K, float eps, const mmg_next_bn_t* next, void* stream) {
   MMG_CHECK_ARG(mmg_linear_bnbwd_supported(M, N, K), "linear_l2bwd: M=%lld N=%d K=%d unsupported (M > 512, K and N in {64,128})",
                 (long long)M, N, K);
   MMG_CHECK_ARG(G && out && rnorm && W && dZ && dX, "linear_l2bwd: null buffer");
@@ -1680,11 +1861,21 @@ extern "C" int mmg_linear_l2bwd(const float* G, const float* out, const float* r
   BnBwdDev bb{out, rnorm, nullptr, nullptr, 0.0, dZ, nullptr, nullptr, eps, nullptr, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc;
+  if (next && K == 128 && N == 128 && next_bn_fusable(next)) {
+    NextBnDev nb;
+    double* partial;
+    rc = mmg_next_bn_dev(next, M, N, "linear_l2bwd", &nb, &partial);
+    if (rc) return rc;
+    rc = launch_bnbwd_x6<128, 4, 1, true>(G, bb, pr, W, dX, M, st, mmg_pro_dev(nullptr), nb, partial);
+    if (rc) return rc;
+    MMG_CHECK_LAUNCH("linear_l2bwd");
+    return mmg_next_bn_finish(next, partial, N, (int)bnbwd_x6_rows(M, K), stream);
+  }
   if (K == 128) rc = N == 128 ? launch_bnbwd_x6<128, 4, 1>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<128, 2, 1>(G, bb, pr, W, dX, M, st);
   else rc = N == 128 ? launch_bnbwd_x6<64, 4, 1>(G, bb, pr, W, dX, M, st) : launch_bnbwd_x6<64, 2, 1>(G, bb, pr, W, dX, M, st);
   if (rc) return rc;
   MMG_CHECK_LAUNCH("linear_l2bwd");
-  return MMG_OK;
+  return next ? mmg_next_bn_fallback(dX, M, N, next, "linear_l2bwd", stream) : MMG_OK;
 }
 
 extern "C" size_t mmg_linear_wgrad_ws_bytes(int64_t M, int N, int K) {

@@ -41,6 +41,25 @@ def set_overlap(mode: str):
     OVERLAP_MODE = mode
 
 
+# Which BatchNorm-backward statistics passes ride on the kernel that produces their upstream gradient (ops.NextBN) instead
+# of a separate pass over gradient + activation: "heads" = the last conv layer's patient BatchNorm (from the heads' data-
+# gradient GEMM), "conv" = the patient BatchNorm of a lower conv layer (from the gather that finishes the gradient),
+# "enc2" = the encoder's second BatchNorm (from the L2-backward GEMM), "enc1" = its first, shared by the two passes of a
+# training step (from the two BatchNorm-backward GEMMs above it).  "enc1" is off by default: two epilogues (with the
+# register spills they cause in those two kernels) cost more than the one joint pass they replace -- x100 eICU shape, same
+# box: none 2.468 ms, heads+conv+enc2 2.431 ms, all four 2.465 ms per step.
+NEXT_BN_SITES = frozenset({"heads", "conv", "enc2"})
+
+
+def set_next_bn(sites):
+    """An iterable of site names out of NEXT_BN_SITES' vocabulary (bench.py's A/B runs and the tests switch it)."""
+    global NEXT_BN_SITES
+    sites = frozenset(sites)
+    if not sites <= {"heads", "conv", "enc2", "enc1"}:
+        raise ValueError(f"unknown next-BatchNorm site(s): {sorted(sites - {'heads', 'conv', 'enc2', 'enc1'})}")
+    NEXT_BN_SITES = sites
+
+
 def _mangle(et: EdgeType) -> str:
     return "<" + "___".join(et) + ">"
 
@@ -252,12 +271,32 @@ class _LazyAct:
     prologue).  Used for the last conv layer's patient activations inside predict_lab_values, which only feed the edge
     head's first linear and its weight gradient (one write + two reads of a [P, D] tensor less per step)."""
 
-    def __init__(self, y: torch.Tensor, pro: Pro):
-        self.y, self.pro = y, pro
+    def __init__(self, y: torch.Tensor, pro: Pro, fold=None):
+        self.y, self.pro, self.fold = y, pro, fold
 
     @property
     def shape(self):
         return self.y.shape
+
+
+BN_SUMS = "__patient_bn_sums__"   # key of a gradient dict: local BatchNorm-backward statistics that came with g[ROW_TYPE]
+
+
+class _NextStats:
+    """The statistics pass of a BatchNorm backward, taken from the epilogue(s) of the kernel(s) that produce its upstream
+    gradient (ops.NextBN / mmg_next_bn_t): y, fold = that BatchNorm's pre-activation and fold; every producer passes
+    `self.next(pro)` (its own dropout mask) and reports the sums it got back.  `sums` is complete once `n` producers --
+    one per gradient that flows into the BatchNorm -- have added their share."""
+
+    def __init__(self, y, fold):
+        self.y, self.fold, self.sums, self.n = y, fold, None, 0
+
+    def next(self, pro):
+        return ops.NextBN(self.y, pro, self.fold, self.sums)
+
+    def took(self, sums):
+        self.sums = sums
+        self.n += 1
 
 
 class _StepFn(torch.autograd.Function):
@@ -453,7 +492,7 @@ class _Run:
             g = self.layers_bwd(layers, g)
             self.enc_bwd(enc, g.get(ROW_TYPE))
             for t, gt in g.items():
-                if t != ROW_TYPE and gt is not None:
+                if t not in (ROW_TYPE, BN_SUMS) and gt is not None:
                     self.acc(f"embeddings.{t}.weight", gt)
         else:
             _, enc0, enc1, layers, hrec = mode
@@ -487,9 +526,10 @@ class _Run:
                         a1, a0 = (a1[0], both[0]), (a0[0], both[1])
                     elif live:
                         self.allreduce(live[0][1])
-                self.enc_bwd_shared(enc1, self.enc_bwd_b(enc1, a1), enc0, self.enc_bwd_b(enc0, a0))
+                nstats = _NextStats(enc1["z1"], enc1["f1"])      # the shared first BatchNorm: both passes add their share
+                self.enc_bwd_shared(enc1, self.enc_bwd_b(enc1, a1, nstats), enc0, self.enc_bwd_b(enc0, a0, nstats), nstats)
             for t, gt in g.items():
-                if t != ROW_TYPE and gt is not None:
+                if t not in (ROW_TYPE, BN_SUMS) and gt is not None:
                     self.acc(f"embeddings.{t}.weight", gt)
             if g_init.get("lab") is not None:
                 self.acc("embeddings.lab.weight", g_init["lab"])
@@ -625,25 +665,34 @@ class _Run:
         self.acc(bn_prefix + ".weight", dbg[1])
         return dy
 
-    def bn_lin_bwd(self, g, y, pro: Pro, fold: Optional[ops.BNFold], bn_prefix: Optional[str], sharded: bool, sums, W):
+    def bn_lin_bwd(self, g, y, pro: Pro, fold: Optional[ops.BNFold], bn_prefix: Optional[str], sharded: bool, sums, W,
+                   nxt: Optional[Tuple["_NextStats", Pro]] = None):
         """bn_bwd followed by the data gradient  dz @ W  through the linear in front of that BatchNorm, as ONE kernel
         (mmg_linear_bnbwd: g and y are read once, dz is written once for the weight gradient).  -> (dz, dx), or None where
-        the fused kernel does not apply (the caller then runs bn_bwd and the GEMM)."""
+        the fused kernel does not apply (the caller then runs bn_bwd and the GEMM).
+        nxt = (stats holder, prologue) of the BatchNorm below, whose backward consumes dx: its statistics ride along."""
         if g is None or pro.relu not in (0, 1) or not ops.linear_bnbwd_supported(y.shape[0], W.shape[1], y.shape[1]):
             return None
+        nb = nxt[0].next(nxt[1]) if nxt is not None else None
+
+        def done(out):
+            if nb is not None:
+                nxt[0].took(out[2])
+            return out[0], out[1]
+
         if fold is None:
-            return ops.linear_bnbwd(g, y, pro, None, W)
+            return done(ops.linear_bnbwd(g, y, pro, None, W, next_bn=nb))
         if sums is None:
             sums = self.bn_bwd_sums(g, y, pro, fold, sharded)
         dbg = torch.empty(2, y.shape[1], device=y.device)       # d beta | d gamma, written by the kernel
         if fold.training:
-            out = ops.linear_bnbwd(g, y, pro, fold, W, sums, fold.count, dbg[0], dbg[1])
+            out = ops.linear_bnbwd(g, y, pro, fold, W, sums, fold.count, dbg[0], dbg[1], next_bn=nb)
         else:
             dbg.copy_(sums)
-            out = ops.linear_bnbwd(g, y, pro, fold, W)
+            out = ops.linear_bnbwd(g, y, pro, fold, W, next_bn=nb)
         self.acc(bn_prefix + ".bias", dbg[0])
         self.acc(bn_prefix + ".weight", dbg[1])
-        return out
+        return done(out)
 
     def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False, dx_into=None):
         """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one."""
@@ -678,18 +727,26 @@ class _Run:
             self.lin_bwd(dz3, enc["act"], None, f"{pt}.8.weight", f"{pt}.8.bias", need_dx=False, partial=True)
             sums = ops.bn_bwd_stats_rows(g, enc["z2"], rows, enc["pro2"], enc["f2"])
         else:
-            dz3, g = ops.linear_l2bwd(g_x0.contiguous(), enc["x0"], enc["rn"], self.W(f"{pt}.8.weight"))
+            # the statistics of the second BatchNorm's backward come out of the epilogue of the GEMM that produces its
+            # upstream gradient (the separate pass read g and z2 once more)
+            if "enc2" in NEXT_BN_SITES:
+                dz3, g, sums = ops.linear_l2bwd(g_x0.contiguous(), enc["x0"], enc["rn"], self.W(f"{pt}.8.weight"),
+                                                next_bn=ops.NextBN(enc["z2"], enc["pro2"], enc["f2"]))
+            else:
+                dz3, g = ops.linear_l2bwd(g_x0.contiguous(), enc["x0"], enc["rn"], self.W(f"{pt}.8.weight"))
+                sums = ops.bn_bwd_stats(g, enc["z2"], enc["pro2"], enc["f2"])
             self.lin_bwd(dz3, enc["z2"], enc["pro2"], f"{pt}.8.weight", f"{pt}.8.bias", need_dx=False, partial=True)
-            sums = ops.bn_bwd_stats(g, enc["z2"], enc["pro2"], enc["f2"])
         return g, sums
 
-    def enc_bwd_b(self, enc, state):
-        """...and from the (all-reduced) statistics on to the upstream gradient of the first BatchNorm."""
+    def enc_bwd_b(self, enc, state, nstats: Optional["_NextStats"] = None):
+        """...and from the (all-reduced) statistics on to the upstream gradient of the first BatchNorm.
+        nstats: holder of that BatchNorm's backward statistics; a fused producer adds its share (this pass's mask)."""
         if state is None:
             return None
         pt = "patient_transform"
         g, sums = state
         y, pro, fold = enc["z2"], enc["pro2"], enc["f2"]
+        nxt = (nstats, enc["pro1"]) if nstats is not None and nstats.fold is not None and "enc1" in NEXT_BN_SITES else None
         if enc.get("rows") is not None:
             # an upstream gradient that is zero outside the listed rows (training statistics): the dense apply pass never
             # reads a gradient tensor, the listed rows are patched afterwards
@@ -698,7 +755,12 @@ class _Run:
             if enc.get("row_pos") is not None and pro.relu in (0, 1) and fold.training and \
                     ops.linear_bnbwd2_supported(y.shape[0], W4.shape[1], y.shape[1]):
                 # dense pass, row patch and the data-gradient GEMM of the second linear in ONE kernel
-                dz2, dx = ops.linear_bnbwd_rows(g, enc["row_pos"], y, pro, fold, W4, sums, fold.count, dbg[0], dbg[1])
+                if nxt is not None:
+                    dz2, dx, nsums = ops.linear_bnbwd_rows(g, enc["row_pos"], y, pro, fold, W4, sums, fold.count, dbg[0], dbg[1],
+                                                           next_bn=nstats.next(enc["pro1"]))
+                    nstats.took(nsums)
+                else:
+                    dz2, dx = ops.linear_bnbwd_rows(g, enc["row_pos"], y, pro, fold, W4, sums, fold.count, dbg[0], dbg[1])
                 self.acc(f"{pt}.5.bias", dbg[0])
                 self.acc(f"{pt}.5.weight", dbg[1])
                 self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", need_dx=False, partial=True)
@@ -708,7 +770,7 @@ class _Run:
             self.acc(f"{pt}.5.bias", dbg[0])
             self.acc(f"{pt}.5.weight", dbg[1])
         else:
-            fused = self.bn_lin_bwd(g, y, pro, fold, f"{pt}.5", True, sums, self.W(f"{pt}.4.weight"))
+            fused = self.bn_lin_bwd(g, y, pro, fold, f"{pt}.5", True, sums, self.W(f"{pt}.4.weight"), nxt=nxt)
             if fused is not None:                # BatchNorm backward inside the data-gradient GEMM of the second linear
                 dz2, dx = fused
                 self.lin_bwd(dz2, enc["z1"], enc["pro1"], f"{pt}.4.weight", f"{pt}.4.bias", need_dx=False, partial=True)
@@ -724,26 +786,36 @@ class _Run:
             return None
         if self.comm is not None:
             self.allreduce(state[1])
-        g = self.enc_bwd_b(enc, state)
+        nstats = _NextStats(enc["z1"], enc["f1"]) if not upto_bn1 else None
+        g = self.enc_bwd_b(enc, state, nstats)
         if upto_bn1:
             return g
         pt = "patient_transform"
-        dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True)
+        sums = nstats.sums if nstats.n == 1 else None        # from the epilogue of the kernel that produced g
+        if sums is not None and self.comm is not None:
+            self.allreduce(sums)
+        dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True, sums=sums)
         self.enc_bwd_first(enc, dz1)
         return None
 
-    def enc_bwd_shared(self, enc_a, g_a, enc_b, g_b):
+    def enc_bwd_shared(self, enc_a, g_a, enc_b, g_b, nstats: Optional["_NextStats"] = None):
         """First BatchNorm + first linear of two passes that share them (same z1, same statistics, own dropout masks):
-        g_out = g_out(g_a; pro1_a) + g_out(g_b; pro1_b) -- one statistics pass, one apply pass, one weight / data gradient."""
+        g_out = g_out(g_a; pro1_a) + g_out(g_b; pro1_b) -- one statistics pass, one apply pass, one weight / data gradient.
+        nstats: the statistics the producers of g_a / g_b summed in their epilogues (complete when every gradient that is
+        present added its share; the separate pass over g_a, g_b and z1 runs otherwise)."""
         pt = "patient_transform"
         if g_a is None and g_b is None:
             return
+        n_live = (g_a is not None) + (g_b is not None)
+        pre = nstats.sums if nstats is not None and nstats.n == n_live else None
         if g_a is None or g_b is None:
             enc, g = (enc_a, g_a) if g_b is None else (enc_b, g_b)
-            dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True)
+            if pre is not None and self.comm is not None:
+                self.allreduce(pre)
+            dz1 = self.bn_bwd(g, enc["z1"], enc["pro1"], enc["f1"], f"{pt}.1", sharded=True, sums=pre)
         else:
             y, fold = enc_a["z1"], enc_a["f1"]
-            sums = ops.bn_bwd_stats2(g_a, g_b, y, enc_a["pro1"], enc_b["pro1"], fold)
+            sums = pre if pre is not None else ops.bn_bwd_stats2(g_a, g_b, y, enc_a["pro1"], enc_b["pro1"], fold)
             if self.comm is not None:
                 self.allreduce(sums)
             dbg = torch.empty(2, y.shape[1], device=y.device)
@@ -803,7 +875,7 @@ class _Run:
             pro = Pro(fold.scale if fold else None, fold.shift if fold else None, self.m._act_code, p, self.seed,
                       SITE_CONV + 8 * l + ti, plan.row_offset if sharded else 0, self.seed_dev)
             if last and t == ROW_TYPE and self.lazy_final and self.m._act_code == 1:
-                out[t] = _LazyAct(y[t], pro)                     # consumed through the heads' GEMM prologues
+                out[t] = _LazyAct(y[t], pro, fold)               # consumed through the heads' GEMM prologues
             else:
                 out[t] = ops.affine_act_drop(y[t], pro)
             folds[t], pros[t] = fold, pro
@@ -948,11 +1020,14 @@ class _Run:
         return out, rec
 
     def layers_bwd(self, recs, g):
-        for rec in reversed(recs):
-            g = self.layer_bwd(rec, g)
+        for i in range(len(recs) - 1, -1, -1):
+            g = self.layer_bwd(recs[i], g, below=recs[i - 1] if i > 0 else None)
         return g
 
-    def layer_bwd(self, rec, g_out):
+    def layer_bwd(self, rec, g_out, below=None):
+        """g_out[BN_SUMS] (optional): the LOCAL statistics of this layer's patient BatchNorm backward, summed by the kernel
+        that produced g_out[ROW_TYPE]; below: the record of the layer underneath, whose patient BatchNorm consumes the
+        patient gradient this layer hands down (its statistics then ride on the last kernel that writes that gradient)."""
         plan, D, P, l = self.plan, self.D, self.plan.n_rows, rec["l"]
         x, y = rec["x"], rec["y"]
         dy = {}
@@ -969,6 +1044,11 @@ class _Run:
             gt = g_out.get(ROW_TYPE)
             if gt is None or ROW_TYPE not in y:
                 return None
+            pre = g_out.get(BN_SUMS)
+            if pre is not None and rec["folds"][ROW_TYPE] is not None:
+                if self.comm is not None:
+                    self.allreduce(pre)
+                return pre
             return self.bn_bwd_sums(gt.contiguous(), y[ROW_TYPE], rec["pros"][ROW_TYPE], rec["folds"][ROW_TYPE], True)
 
         g_in: Dict[str, Optional[torch.Tensor]] = {t: None for t in x}
@@ -1094,11 +1174,17 @@ class _Run:
 
         def patient_2(rels):
             if rels:
-                if g_in[ROW_TYPE] is None:
+                nb = None
+                if below is not None and ROW_TYPE in below["y"] and below["folds"].get(ROW_TYPE) is not None and \
+                        "conv" in NEXT_BN_SITES:
+                    nb = ops.NextBN(below["y"][ROW_TYPE], below["pros"][ROW_TYPE], below["folds"][ROW_TYPE])
+                acc_ = g_in[ROW_TYPE] is not None
+                if not acc_:
                     g_in[ROW_TYPE] = torch.empty(P, D, device=self.dev)
-                    ops.gather_rows(rels, P, D, g_in[ROW_TYPE], accumulate=False)
+                if nb is not None:           # the gather is the last writer of the gradient the BatchNorm below consumes
+                    _, g_in[BN_SUMS] = ops.gather_rows(rels, P, D, g_in[ROW_TYPE], accumulate=acc_, next_bn=nb)
                 else:
-                    ops.gather_rows(rels, P, D, g_in[ROW_TYPE], accumulate=True)
+                    ops.gather_rows(rels, P, D, g_in[ROW_TYPE], accumulate=acc_)
 
         if self.overlap and self.comm is None:
             main, side = torch.cuda.current_stream(), self.side
@@ -1107,7 +1193,7 @@ class _Run:
             with torch.cuda.stream(side):
                 rels = vocab_1()
                 ev_tables.record(side)
-            res = patient_1()
+            res = patient_1(patient_sums() if g_out.get(BN_SUMS) is not None else None)
             ev_scatter.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ev_scatter)
@@ -1134,7 +1220,7 @@ class _Run:
             main.wait_stream(side)
         else:
             rels = vocab_1()
-            res = patient_1()
+            res = patient_1(patient_sums() if g_out.get(BN_SUMS) is not None else None)
             vocab_2(res)
             patient_2(rels)
         return g_in
@@ -1273,9 +1359,14 @@ class _Run:
                     gP = (low_rows, torch.zeros(0, D, device=self.dev))
                 else:
                     gP = None                    # single GPU, no such row anywhere: the whole pass contributes exactly 0
+                gsets[which] = {ROW_TYPE: gP, "lab": glab}
+            elif isinstance(xP, _LazyAct) and xP.fold is not None and "heads" in NEXT_BN_SITES:
+                # the final patient activations are BatchNorm outputs: the statistics of that BatchNorm's backward are
+                # summed in the epilogue of the GEMM that produces its upstream gradient
+                gP, bsums = ops.linear_fwd(g.A, w1a, w_kn=True, next_bn=ops.NextBN(xP.y, xP.pro, xP.fold))
+                gsets[which] = {ROW_TYPE: gP, "lab": glab, BN_SUMS: bsums}
             else:
-                gP = ops.linear_fwd(g.A, w1a, w_kn=True)
-            gsets[which] = {ROW_TYPE: gP, "lab": glab}
+                gsets[which] = {ROW_TYPE: ops.linear_fwd(g.A, w1a, w_kn=True), "lab": glab}
         return gsets["tabular_mlp"], gsets["edge_predictor"]
 
 

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (BnFinT, HeadGradT, HeadT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, WgradReduceT,
+from ._lib import (BnFinT, HeadGradT, HeadT, NextBnT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, WgradReduceT,
                    check)
 
 BN_MOMENTUM = 0.1
@@ -265,7 +265,7 @@ def _bn_fin(count: int, N: int, device, bn):
 
 
 def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, accumulate: bool, with_stats: bool = False,
-                bn=None):
+                bn=None, next_bn: Optional["NextBN"] = None):
     """with_stats: also return fp64 [2,D] = (column sums, column sums of squares) of the final `out`.
     bn = (gamma, beta, running_mean, running_var, n_updates): also fold the training-mode BatchNorm of `out` in the launch
     that sums the statistics (mmg_gather_rows_stats_bn) -> (out, sums, BNFold)."""
@@ -278,6 +278,14 @@ def gather_rows(rels: Sequence[Rel], n_rows: int, D: int, out: torch.Tensor, acc
     arr = _rels(rels, D, need_table=True)
     _tok = _pb("gather_rows")
     fold = None
+    if next_bn is not None:       # -> (out, the statistics of the BatchNorm backward that consumes out), see NextBN
+        if bn is not None or with_stats:
+            raise ValueError("gather_rows: next_bn excludes the forward statistics")
+        nbt, sums = _next_bn(next_bn, n_rows, D)
+        check(lib.mmg_gather_rows_next_bn(arr, len(rels), n_rows, D, _p(out), int(accumulate), C.byref(nbt), _stream()),
+              "mmg_gather_rows_next_bn")
+        _pe(_tok, "gather_rows", _agg_bytes(rels, n_rows, D, accumulate) + 4 * D * n_rows, 0)
+        return out, sums
     if bn is not None:
         sums = torch.empty(2, D, dtype=torch.float64, device=out.device)
         ws = workspace(lib.mmg_gather_rows_stats_ws_bytes(n_rows, D), out.device)
@@ -317,8 +325,9 @@ def scatter_rows(rels: Sequence[Rel], n_rows: int, D: int, x: torch.Tensor):
 # ------------------------------------------------------------------------------------------ dense
 def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None, pro: Optional[Pro] = None,
                out: Optional[torch.Tensor] = None, accumulate: bool = False, w_kn: bool = False,
-               with_stats: bool = False, bn=None):
+               with_stats: bool = False, bn=None, next_bn: Optional["NextBN"] = None):
     """out[M,N] (+)= pro(x)[M,K] @ W[N,K]^T + bias;  w_kn: W is stored [K,N] (out = x @ W), read in place.
+    next_bn: -> (out, the statistics of the BatchNorm backward that consumes out), see NextBN.
     with_stats: also return fp64 [2,N] = (column sums, column sums of squares) of out, from the GEMM epilogue.
     bn = (gamma, beta, running_mean, running_var, n_updates): also fold the training-mode BatchNorm of `out` in the launch
     that sums the statistics (mmg_linear_fwd_stats_bn) -> (out, sums, BNFold)."""
@@ -336,6 +345,14 @@ def linear_fwd(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = 
     _tok = _pb("linear_fwd")
     flags = int(accumulate) | (2 if w_kn else 0)
     fold = None
+    if next_bn is not None:
+        if bn is not None or with_stats:
+            raise ValueError("linear_fwd: next_bn excludes the forward statistics")
+        nbt, sums = _next_bn(next_bn, M, N)
+        check(lib.mmg_linear_fwd_next_bn(_p(x, name="x"), _pro(pro), _p(W, name="W"), _p(bias, name="bias"),
+                                         _p(out, name="out"), M, N, K, flags, C.byref(nbt), _stream()), "mmg_linear_fwd_next_bn")
+        _pe(_tok, "linear_fwd", 4 * (M * K + N * K + M * N * (3 if accumulate else 2)), 2 * M * N * K)
+        return out, sums
     if bn is not None:
         sums = torch.empty(2, N, dtype=torch.float64, device=x.device)
         ws = workspace(lib.mmg_linear_fwd_stats_ws_bytes(M, N), x.device)
@@ -437,6 +454,35 @@ class BNFold:
     rstd: torch.Tensor
     count: int
     training: bool
+
+
+@dataclass
+class NextBN:
+    """The BatchNorm backward that CONSUMES an op's output (mmg_next_bn_t): y = its pre-BatchNorm activation, pro = its
+    fold / activation / dropout, fold = its BNFold (mean, rstd).  An op that is handed one also returns the fp64 [2,N]
+    statistics bn_bwd_stats(out, y, pro, fold) would compute -- from its epilogue where the shape has a fused form, from
+    the separate pass elsewhere.  sums: ADD to these sums instead (two producers through one BatchNorm)."""
+    y: torch.Tensor
+    pro: "Pro"
+    fold: "BNFold"
+    sums: Optional[torch.Tensor] = None
+
+
+def _next_bn(nb: NextBN, M: int, N: int):
+    """-> (NextBnT for the C call (keeps its prologue alive), the sums tensor the call fills)."""
+    lib = _lib.load()
+    if tuple(nb.y.shape) != (M, N):
+        raise ValueError(f"next_bn: y is {tuple(nb.y.shape)}, the producer writes [{M},{N}]")
+    acc = nb.sums is not None
+    sums = nb.sums if acc else torch.empty(2, N, dtype=torch.float64, device=nb.y.device)
+    if tuple(sums.shape) != (2, N) or sums.dtype != torch.float64:
+        raise ValueError("next_bn: sums must be fp64 [2,N]")
+    ws = workspace(lib.mmg_next_bn_ws_bytes(M, N), nb.y.device)
+    pc = nb.pro.c()
+    t = NextBnT(_p(nb.y).value, C.pointer(pc), _p(nb.fold.mean).value, _p(nb.fold.rstd).value,
+                _p(sums, torch.float64).value, int(acc), _p(ws, torch.uint8).value, ws.numel())
+    t._keep = (pc, ws)
+    return t, sums
 
 
 def bn_finalize(sums: Optional[torch.Tensor], count: int, gamma, beta, running_mean, running_var, training: bool,
@@ -573,7 +619,7 @@ def linear_bnbwd_supported(M: int, N: int, K: int) -> bool:
 
 
 def linear_bnbwd(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFold], W: torch.Tensor, sums=None,
-                 count: float = 1.0, dbeta=None, dgamma=None):
+                 count: float = 1.0, dbeta=None, dgamma=None, next_bn: Optional["NextBN"] = None):
     """bn_bwd_apply(g, y, ...) and the data gradient dz @ W of the linear in front of that BatchNorm in ONE pass over g and
     y (mmg_linear_bnbwd): -> (dz [M,K], dx [M,N]).  W [K, N] is the forward weight of the linear, read in place."""
     lib = _lib.load()
@@ -584,6 +630,14 @@ def linear_bnbwd(g: torch.Tensor, y: torch.Tensor, pro: Pro, fold: Optional[BNFo
     dz = torch.empty_like(y)
     dx = torch.empty(M, N, device=y.device)
     _tok = _pb("linear_bnbwd")
+    if next_bn is not None:       # -> (dz, dx, the statistics of the BatchNorm backward that consumes dx), see NextBN
+        nbt, nsums = _next_bn(next_bn, M, N)
+        check(lib.mmg_linear_bnbwd_next_bn(_p(g), _p(y), _pro(pro), _p(fold.mean) if fold else None,
+                                           _p(fold.rstd) if fold else None, _p(sums, torch.float64), 1.0 / float(count),
+                                           _p(dbeta), _p(dgamma), _p(W), _p(dz), _p(dx), M, N, K, C.byref(nbt), _stream()),
+              "mmg_linear_bnbwd_next_bn")
+        _pe(_tok, "linear_bnbwd", 4 * (3 * M * K + 2 * M * N), 2 * M * N * K)
+        return dz, dx, nsums
     check(lib.mmg_linear_bnbwd(_p(g), _p(y), _pro(pro), _p(fold.mean) if fold else None, _p(fold.rstd) if fold else None,
                                _p(sums, torch.float64), 1.0 / float(count), _p(dbeta), _p(dgamma), _p(W), _p(dz), _p(dx),
                                M, N, K, _stream()), "mmg_linear_bnbwd")
@@ -612,7 +666,7 @@ def linear_bnbwd2(g: torch.Tensor, g2: torch.Tensor, y: torch.Tensor, pro: Pro, 
 
 
 def linear_bnbwd_rows(g_rows: torch.Tensor, row_pos: torch.Tensor, y: torch.Tensor, pro: Pro, fold: BNFold, W: torch.Tensor,
-                      sums, count, dbeta=None, dgamma=None):
+                      sums, count, dbeta=None, dgamma=None, next_bn: Optional["NextBN"] = None):
     """bn_bwd_apply(None, ...) + bn_bwd_apply_rows(g_rows, ...) + the data gradient dz @ W in one pass -> (dz, dx): the
     upstream gradient is zero outside the listed rows; row_pos [M] int32 = position of a row in the list or -1."""
     lib = _lib.load()
@@ -621,6 +675,15 @@ def linear_bnbwd_rows(g_rows: torch.Tensor, row_pos: torch.Tensor, y: torch.Tens
     dz = torch.empty_like(y)
     dx = torch.empty(M, N, device=y.device)
     _tok = _pb("linear_bnbwd")
+    if next_bn is not None:       # -> (dz, dx, the statistics of the BatchNorm backward that consumes dx), see NextBN
+        nbt, nsums = _next_bn(next_bn, M, N)
+        check(lib.mmg_linear_bnbwd_rows_next_bn(_p(g_rows) if g_rows.numel() else None, _p(row_pos, torch.int32),
+                                                g_rows.shape[0], _p(y), _pro(pro), _p(fold.mean), _p(fold.rstd),
+                                                _p(sums, torch.float64), 1.0 / float(count), _p(dbeta), _p(dgamma), _p(W),
+                                                _p(dz), _p(dx), M, N, K, C.byref(nbt), _stream()),
+              "mmg_linear_bnbwd_rows_next_bn")
+        _pe(_tok, "linear_bnbwd", 4 * (2 * M * K + 2 * M * N), 2 * M * N * K)
+        return dz, dx, nsums
     check(lib.mmg_linear_bnbwd_rows(_p(g_rows) if g_rows.numel() else None, _p(row_pos, torch.int32), g_rows.shape[0], _p(y),
                                     _pro(pro), _p(fold.mean), _p(fold.rstd), _p(sums, torch.float64), 1.0 / float(count),
                                     _p(dbeta), _p(dgamma), _p(W), _p(dz), _p(dx), M, N, K, _stream()),
@@ -629,7 +692,7 @@ def linear_bnbwd_rows(g_rows: torch.Tensor, row_pos: torch.Tensor, y: torch.Tens
     return dz, dx
 
 
-def linear_l2bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor, W: torch.Tensor):
+def linear_l2bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor, W: torch.Tensor, next_bn: Optional["NextBN"] = None):
     """l2norm_bwd(g, out, rn) and the data gradient dz @ W of the linear in front of the normalisation -> (dz, dx): ONE
     kernel where mmg_linear_bnbwd_supported (W [K, N] = the forward weight in place), the two launches elsewhere."""
     lib = _lib.load()
@@ -639,10 +702,18 @@ def linear_l2bwd(g: torch.Tensor, out: torch.Tensor, rn: torch.Tensor, W: torch.
         raise ValueError(f"linear_l2bwd: W has {W.shape[0]} rows, out has {K} columns")
     if not lib.mmg_linear_bnbwd_supported(M, N, K):
         dz = l2norm_bwd(g, out, rn)
+        if next_bn is not None:
+            return (dz,) + tuple(linear_fwd(dz, W, w_kn=True, next_bn=next_bn))
         return dz, linear_fwd(dz, W, w_kn=True)
     dz = torch.empty_like(out)
     dx = torch.empty(M, N, device=out.device)
     _tok = _pb("linear_l2bwd")
+    if next_bn is not None:       # -> (dz, dx, the statistics of the BatchNorm backward that consumes dx), see NextBN
+        nbt, nsums = _next_bn(next_bn, M, N)
+        check(lib.mmg_linear_l2bwd_next_bn(_p(g), _p(out), _p(rn), _p(W), _p(dz), _p(dx), M, N, K, L2_EPS, C.byref(nbt),
+                                           _stream()), "mmg_linear_l2bwd_next_bn")
+        _pe(_tok, "linear_l2bwd", 4 * (3 * M * K + 2 * M * N), 2 * M * N * K)
+        return dz, dx, nsums
     check(lib.mmg_linear_l2bwd(_p(g), _p(out), _p(rn), _p(W), _p(dz), _p(dx), M, N, K, L2_EPS, _stream()), "mmg_linear_l2bwd")
     _pe(_tok, "linear_l2bwd", 4 * (3 * M * K + M * N), 2 * M * N * K)
     return dz, dx

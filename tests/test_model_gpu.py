@@ -293,6 +293,17 @@ def test_config4_eicu_vocabulary_at_256d(dev, p):
     _train_step_vs_oracle(dev, (1834, 50, 114, 100), 256, p=p, sup_seed=3)
 
 
+@pytest.mark.parametrize("sites,num_layers", [((), 2), (("heads", "conv", "enc2", "enc1"), 2), (("heads", "conv", "enc2", "enc1"), 3)])
+def test_batchnorm_backward_statistics_from_producer_epilogues(dev, sites, num_layers, monkeypatch):
+    """mmgnn.model.NEXT_BN_SITES: every BatchNorm-backward statistics pass taken from the epilogue of the kernel that
+    produces its upstream gradient (all four sites, the default leaves one out) and none of them -- the same step against
+    the oracle at the eICU vocabulary / 128-d (the fused kernels need more than 512 patients); three layers put the
+    three-relation gather in front of a BatchNorm as well."""
+    import mmgnn.model as mm
+    monkeypatch.setattr(mm, "NEXT_BN_SITES", frozenset(sites))
+    _train_step_vs_oracle(dev, (1834, 50, 114, 100), 128, p=0.2, sup_seed=3, num_layers=num_layers)
+
+
 @pytest.mark.parametrize("activation", ["elu", "leaky_relu"])
 def test_activation_variants_match_oracle(dev, activation):
     """model.py:145-152 accepts relu / elu / leaky_relu for the conv layers."""

@@ -990,3 +990,105 @@ def test_batchnorm_fold_in_the_statistics_launch(ops, dev, M):
     for a, c in ((f0.scale, f1.scale), (f0.shift, f1.shift), (f0.mean, f1.mean), (f0.rstd, f1.rstd), (rm0, rm1), (rv0, rv1)):
         assert torch.equal(a, c)
     assert f1.count == M and f1.training
+
+
+# ------------------------------------------------------------------------------------------ next-BatchNorm statistics
+def _bn_below(ops, dev, gen, M, N, p, relu=True, row_offset=10, site=23):
+    """A BatchNorm + activation + dropout 'below' a producer: (y, pro, fold)."""
+    y = (torch.randn(M, N, generator=gen) * 1.5 + 0.2).to(dev)
+    gamma, beta = (torch.rand(N, generator=gen) + 0.5).to(dev), (torch.randn(N, generator=gen) * 0.2).to(dev)
+    fold = ops.bn_finalize(ops.col_reduce2(y), M, gamma, beta, None, None, True)
+    return y, ops.Pro(fold.scale, fold.shift, relu, p, seed=11, site=site, row_offset=row_offset), fold
+
+
+def _stats_close(ops, got, out, y, pro, fold, bar=1e-6):
+    want = ops.bn_bwd_stats(out, y, pro, fold)          # the separate pass (fp64 per element) over the finished output
+    assert rel(got[0], want[0]) <= bar and rel(got[1], want[1]) <= bar, (rel(got[0], want[0]), rel(got[1], want[1]))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("M,N,K,relu", [(5003, 128, 64, 1), (5003, 128, 128, 1), (700, 256, 64, 1), (2049, 128, 64, 0),
+                                         (3000, 64, 64, 1), (300, 128, 64, 1), (3000, 128, 64, 2)])
+def test_next_bn_statistics_from_the_linear_epilogue(ops, dev, M, N, K, relu, p):
+    """mmg_linear_fwd_next_bn: the data-gradient GEMM also returns mmg_bn_bwd_stats of its own output (tail tile, two column
+    slices, no activation; N = 64, M <= 512 and leaky_relu take the separate pass inside the call)."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, K, generator=gen).to(dev)
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    y, pro, fold = _bn_below(ops, dev, gen, M, N, p, relu)
+    ref = ops.linear_fwd(dy, W, w_kn=True)
+    out, sums = ops.linear_fwd(dy, W, w_kn=True, next_bn=ops.NextBN(y, pro, fold))
+    assert torch.equal(out, ref)
+    _stats_close(ops, sums, out, y, pro, fold)
+    again = ops.linear_fwd(dy, W, w_kn=True, next_bn=ops.NextBN(y, pro, fold))[1]
+    assert torch.equal(again, sums)                                      # fixed summation order
+    acc = sums.clone()                                                   # sums given: the statistics are ADDED
+    ops.linear_fwd(dy, W, w_kn=True, next_bn=ops.NextBN(y, pro, fold, sums=acc))
+    assert rel(acc, 2 * sums) <= 1e-12
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("M,K,N", [(5003, 128, 128), (3000, 64, 128)])
+def test_next_bn_statistics_from_the_l2_and_bn_backward_gemms(ops, dev, M, K, N, p):
+    """mmg_linear_l2bwd_next_bn / mmg_linear_bnbwd_next_bn / mmg_linear_bnbwd_rows_next_bn: dz and dx unchanged, the statistics
+    of the BatchNorm that consumes dx from the epilogue; two producers ADD into one set of sums (== mmg_bn_bwd_stats2)."""
+    gen = torch.Generator().manual_seed(5 * M + K)
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).to(dev)
+    yb, pro_b, fold_b = _bn_below(ops, dev, gen, M, N, p)
+    # L2 backward
+    z = torch.randn(M, K, generator=gen).to(dev)
+    outn, rn = ops.l2norm_fwd(z)
+    g = torch.randn(M, K, generator=gen).to(dev)
+    dz0, dx0 = ops.linear_l2bwd(g, outn, rn, W)
+    dz1, dx1, s1 = ops.linear_l2bwd(g, outn, rn, W, next_bn=ops.NextBN(yb, pro_b, fold_b))
+    assert torch.equal(dz0, dz1) and torch.equal(dx0, dx1)
+    _stats_close(ops, s1, dx1, yb, pro_b, fold_b)
+    # BatchNorm backward GEMM, dense, then the row-list form adding its share with its own dropout mask
+    y, pro, fold = _bn_below(ops, dev, gen, M, K, p, site=31)
+    sums = ops.bn_bwd_stats(g, y, pro, fold)
+    d0, d1 = torch.zeros(2, K, device=dev), torch.zeros(2, K, device=dev)
+    dz0, dx0 = ops.linear_bnbwd(g, y, pro, fold, W, sums, M, d0[0], d0[1])
+    dz1, dx1, sa = ops.linear_bnbwd(g, y, pro, fold, W, sums, M, d1[0], d1[1], next_bn=ops.NextBN(yb, pro_b, fold_b))
+    assert torch.equal(dz0, dz1) and torch.equal(dx0, dx1) and torch.equal(d0, d1)
+    _stats_close(ops, sa, dx1, yb, pro_b, fold_b)
+    if K == 128:
+        rows = torch.randperm(M, generator=gen)[:157].sort().values.to(dev)
+        g_rows = torch.randn(rows.numel(), K, generator=gen).to(dev)
+        row_pos = torch.full((M,), -1, dtype=torch.int32, device=dev)
+        row_pos[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=dev)
+        sr = ops.bn_bwd_stats_rows(g_rows, y, rows, pro, fold)
+        dzr0, dxr0 = ops.linear_bnbwd_rows(g_rows, row_pos, y, pro, fold, W, sr, M, d0[0], d0[1])
+        pro_b2 = ops.Pro(pro_b.scale, pro_b.shift, True, p, seed=11, site=pro_b.site + 1, row_offset=10)   # the other pass's mask
+        both = sa.clone()
+        dzr1, dxr1, got = ops.linear_bnbwd_rows(g_rows, row_pos, y, pro, fold, W, sr, M, d1[0], d1[1],
+                                                next_bn=ops.NextBN(yb, pro_b2, fold_b, sums=both))
+        assert got is both and torch.equal(dzr0, dzr1) and torch.equal(dxr0, dxr1)
+        want = ops.bn_bwd_stats2(dx1, dxr1, yb, pro_b, pro_b2, fold_b)
+        assert rel(both[0], want[0]) <= 1e-6 and rel(both[1], want[1]) <= 1e-6
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("D,n_rows", [(128, 5000), (256, 1834), (64, 1834)])
+def test_next_bn_statistics_from_the_gather_epilogue(ops, dev, D, n_rows, p):
+    """mmg_gather_rows_next_bn: one relation (the last layer's backward) and three, accumulate or not; D = 64 takes the
+    separate pass inside the call."""
+    gen = torch.Generator().manual_seed(3 * D + n_rows)
+    grels = []
+    for nc, md in zip([50, 114, 100], [50, 9, 25]):
+        ei = simple_edges(gen, n_rows, nc, md)
+        rp, col = _csr(ops, dev, ei, n_rows)
+        _, inv = ops.row_degree(rp)
+        _, cinv = ops.col_degree(col, nc)
+        _, mask_r = ops.rel_mask_build(rp, col, nc)
+        grels.append(ops.Rel(rp, col, nc, rowscale=inv, colscale=cinv, table=(torch.randn(nc, D, generator=gen) * 2).to(dev),
+                             simple=True, mask_r=mask_r))
+    y, pro, fold = _bn_below(ops, dev, gen, n_rows, D, p)
+    base = torch.randn(n_rows, D, generator=gen).to(dev)
+    for rels in (grels[:1], grels):
+        for acc in (True, False):
+            ref = base.clone()
+            ops.gather_rows(rels, n_rows, D, ref, accumulate=acc)
+            o = base.clone()
+            _, sums = ops.gather_rows(rels, n_rows, D, o, accumulate=acc, next_bn=ops.NextBN(y, pro, fold))
+            assert torch.equal(o, ref)
+            _stats_close(ops, sums, o, y, pro, fold)
