@@ -610,6 +610,380 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
   }
 }
 
+// ---------------------------------------------------------------------------- backward on MFMA, two waves per tile
+// k_pair_bwd_mfma above needs ~500 registers per wave: ONE wave per SIMD, so nothing issues while its fp32 matrix
+// instructions run and its matrix pipe idles through every vector phase (measured: 35 % matrix-busy, the rest gather-add,
+// RNG, masks, splits, LDS round trips, the run-length flush).  Here a tile is worked on by TWO waves of the same SIMD in
+// turn, each under 256 registers:
+//   front wave w (0..3): the load pipeline, h1 (gather-add, relu, dropout), (1) H2pre, the layer-2 epilogue -> D2, (2) dW2
+//   back  wave w + 4   : (3) dH1, (4) dB on the bf16 matrix cores, the run-length flush of dA[pi]
+// (64 fp32 matrix instructions + the RNG-heavy vector work in front, 32 fp32 + 24 bf16 matrix instructions + splits and
+// the flush behind: about even.)  The front hands H1, D2 and the tile's patient / lab ids to its back wave through
+// double-buffered LDS tiles; ONE workgroup barrier per tile orders both buffers: the front of tile t + 1 runs beside the
+// back of tile t, one wave's vector instructions issue under the other's matrix instructions.  Same arithmetic, same
+// summation order per wave and the same slab layout as k_pair_bwd_mfma (dW2 and the three bias-like sums accumulate in
+// the front waves, dB in the back waves).
+constexpr int HAND_LDS = TP * LDH + TP * LDD;      // floats per hand-off buffer: H1 [32][LDH] | D2 [32][LDD]
+constexpr int FRONT_LDS = 3 * TP;                  // floats private to a front wave: dout | pair id lo | hi
+
+template <int LT, bool AUX>
+__device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* __restrict__ pi, const int32_t* __restrict__ li,
+                                               const int32_t* __restrict__ deg, int thr, int want_low, int64_t n, float drop_p,
+                                               uint64_t seed, const PairBufs& pb, const float* __restrict__ dpred,
+                                               const int32_t* __restrict__ sel, int n_iter, float* fl, const float* W2s,
+                                               float (*HX)[4][HAND_LDS], int (*XP)[4][TP], int (*XL)[4][TP],
+                                               float (*tail_red)[68], float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
+  const int h = lane >> 5, l31 = lane & 31;
+  float* DOs = fl;                                  // [32] dout (0 for inactive)
+  unsigned* PLo = reinterpret_cast<unsigned*>(DOs + TP);
+  unsigned* PHi = PLo + TP;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const float b2v = H.b2[l31], w3v = H.W3[l31];
+  float w3acc = 0.f, b2acc = 0.f, b3acc = 0.f;
+  f32x16 accW2[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { accW2[0][i] = 0.f; accW2[1][i] = 0.f; }
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + w, n_waves = (int64_t)gridDim.x * 4;
+  // the three-deep load pipeline of k_pair_bwd_mfma (every load unconditional and bounded by a host-sized descriptor)
+  struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
+  const __amdgpu_buffer_rsrc_t sel_d = pair_rsrc(sel ? sel : pi, sel ? (uint32_t)(n * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t io_d = pair_rsrc(pb.io, pb.io_bytes), pid_d = pair_rsrc(pb.pid, pb.pid_bytes);
+  const __amdgpu_buffer_rsrc_t pi_d = pair_rsrc(pi, pb.pair_bytes), li_d = pair_rsrc(li, pb.pair_bytes);
+  const __amdgpu_buffer_rsrc_t dp_d = pair_rsrc(dpred, pb.pair_bytes), deg_d = pair_rsrc(deg, pb.pat_bytes);
+  const __amdgpu_buffer_rsrc_t A_d = pair_rsrc(H.A, pb.a_bytes), B_d = pair_rsrc(H.B, pb.b_bytes);
+  const bool has_sel = sel != nullptr, has_io = pb.io_bytes != 0u, has_pid = pb.pid_bytes != 0u;
+  struct RawMeta { int k, p, l; pu32x2 o2, d2; };
+  auto issue_k = [&](int64_t t) {
+    const int64_t idx = t * TP + l31;
+    return pair_ld_i32(sel_d, (unsigned)(idx < n ? idx : 0) * 4u);
+  };
+  auto fin_k = [&](int kr, int64_t t) {
+    const int64_t idx = t * TP + l31;
+    return idx < n ? (has_sel ? kr : (int)idx) : -1;
+  };
+  auto issue_meta = [&](int k) {
+    const unsigned kc = k >= 0 ? (unsigned)k : 0u;
+    RawMeta r;
+    r.k = k;
+    r.p = pair_ld_i32(pi_d, kc * 4u);
+    r.l = pair_ld_i32(li_d, kc * 4u);
+    if (AUX) {
+      r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, (int)(kc * 8u), 0, 0);
+      r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, (int)(kc * 8u), 0, 0);
+    }
+    return r;
+  };
+  auto fin_meta = [&](const RawMeta& r) {
+    const int kc = r.k >= 0 ? r.k : 0;
+    Meta m;
+    m.k = r.k;
+    m.p_i = ((unsigned)r.k < (pb.pair_bytes >> 2) && (unsigned)r.p < (unsigned)pb.n_pat) ? r.p : -1;
+    m.l_i = r.l;
+    m.o = (AUX && has_io) ? (int)r.o2[0] : kc;
+    m.pid = (AUX && has_pid) ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
+    return m;
+  };
+  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
+    const unsigned pp = m.p_i >= 0 ? (unsigned)m.p_i : 0u;
+    *dg = pair_ld_i32(deg_d, pp * 4u);
+    *dv = __builtin_bit_cast(float, pair_ld_i32(dp_d, (unsigned)m.o * 4u));
+    const unsigned ao = pp * 256u + 128u * h, bo = (unsigned)m.l_i * 256u + 128u * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      ra[q] = pair_ld_f4(A_d, ao + q * 16u);
+      rb[q] = pair_ld_f4(B_d, bo + q * 16u);
+    }
+  };
+  const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
+  int kr2 = issue_k(wave_id + 2 * n_waves);
+  const RawMeta rm0 = issue_meta(fin_k(kr0, wave_id));
+  RawMeta rm1 = issue_meta(fin_k(kr1, wave_id + n_waves));
+  Meta m0 = fin_meta(rm0);
+  f32x4 ra[8], rb[8];
+  int dg0; float dv0;
+  load_rows(m0, ra, rb, &dg0, &dv0);
+  for (int it = 0; it <= n_iter; ++it) {
+    const int par = it & 1;
+    if (it < n_iter) {
+      const int64_t t = wave_id + (int64_t)it * n_waves;
+      float* H1s = HX[par][w];                      // [32][LDH]
+      float* D2s = H1s + TP * LDH;                  // [32][LDD]
+      const Meta mc = m0;
+      const bool active = mc.p_i >= 0 && ((int)(dg0 < thr)) == want_low;
+      const float dout = active ? dv0 : 0.f;
+      f32x4 ca[8], cb[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
+      const Meta m1 = fin_meta(rm1);
+      const int k2 = fin_k(kr2, t + 2 * n_waves);
+      kr2 = issue_k(t + 3 * n_waves);
+      rm1 = issue_meta(k2);
+      load_rows(m1, ra, rb, &dg0, &dv0);           // next tile's rows: in flight during this tile's arithmetic
+      __builtin_amdgcn_sched_barrier(0);
+      m0 = m1;
+      const int p_i = active ? mc.p_i : -1, l_i = mc.l_i;
+      const uint64_t pid = mc.pid;
+      if (h == 0) { XP[par][w][l31] = p_i; XL[par][w][l31] = l_i; }     // (an all -1 patient list = nothing to do for the back wave)
+      if (__ballot(p_i >= 0) != 0ull) {
+        if (h == 0) {
+          DOs[l31] = dout;
+          PLo[l31] = (unsigned)pid; PHi[l31] = (unsigned)(pid >> 32);
+          b3acc += dout;
+        }
+        // ---- h1[pair=l31][k=32h+s]: gather-add, relu, dropout; kept in registers AND written to the hand-off tile
+        float h1a[32];
+        const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          f32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(ca[q][j] + cb[q][j], 0.f);
+          if (drop_p > 0.f) mmg_drop4(v, key1, pid * 64ull + (uint64_t)(32 * h + q * 4), thr1, inv_keep);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) h1a[q * 4 + j] = v[j];
+          *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
+        }
+        // ---- (1) H2pre = H1 . W2^T
+        f32x16 acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(W2s + l31 * LDH + 32 * h + q * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[q * 4 + j], wv[j], acc1, 0, 0, 0);
+        }
+        // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
+        float d2c[16];
+        uint32_t kb[16];
+        if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PLo, PHi, h, l31, kb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = crow(r, h);
+          const float pre = acc1[r] + b2v;
+          float m = pre > 0.f ? 1.f : 0.f;
+          float post = fmaxf(pre, 0.f);
+          if (drop_p > 0.f) {
+            const bool kp = kb[r] >= mmg_keep_threshold(drop_p);
+            m = kp ? m * inv_keep : 0.f;
+            post = kp ? post * inv_keep : 0.f;
+          }
+          const float dr = DOs[row];
+          const float d2 = dr * w3v * m;
+          d2c[r] = d2;
+          w3acc = fmaf(dr, post, w3acc);
+          b2acc += d2;
+          D2s[row * LDD + l31] = d2;
+        }
+        // ---- (2) dW2[u,k] += D2[pair,u] * H1[pair,k]   (A = d2c: already lane = u, step s = pair crow(s,h); B = H1 in
+        //      the column layout, read back from the tile this wave wrote above)
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const float c0 = H1s[crow(s2, h) * LDH + l31], c1 = H1s[crow(s2, h) * LDH + 32 + l31];
+          accW2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2c[s2], c0, accW2[0], 0, 0, 0);
+          accW2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2c[s2], c1, accW2[1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- final flush, front half: the four front waves' dW2 summed through LDS in wave order (the back waves add their dB
+  //      slots in the same four rounds); the hand-off buffers are dead: every wave passed the last barrier of the loop
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (ww == 0) { red[r * 64 + lane] = accW2[0][r]; red[(16 + r) * 64 + lane] = accW2[1][r]; }
+        else { red[r * 64 + lane] += accW2[0][r]; red[(16 + r) * 64 + lane] += accW2[1][r]; }
+      }
+    }
+    __syncthreads();
+  }
+  w3acc += __shfl_xor(w3acc, 32, 64);
+  b2acc += __shfl_xor(b2acc, 32, 64);
+  b3acc = wave_sum(b3acc);
+  if (lane < 32) { tail_red[w][lane] = w3acc; tail_red[w][32 + lane] = b2acc; }
+  if (lane == 0) tail_red[w][64] = b3acc;
+}
+
+template <int LT>
+__device__ __forceinline__ void pair_bwd_back(float* __restrict__ dA, float drop_p, int n_iter, const float* W2s,
+                                              float (*HX)[4][HAND_LDS], int (*XP)[4][TP], int (*XL)[4][TP], float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
+  const int h = lane >> 5, l31 = lane & 31;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  f32x16 accB[LT][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int t = 0; t < LT; ++t) { accB[t][0][i] = 0.f; accB[t][1][i] = 0.f; }
+  for (int it = 0; it <= n_iter; ++it) {
+    if (it >= 1) {
+      const int par = (it - 1) & 1;
+      const int p_i = XP[par][w][l31];
+      if (__ballot(p_i >= 0) != 0ull) {
+        float* H1s = HX[par][w];                    // [32][LDH]  (later: the dH1 tile)
+        const float* D2s = H1s + TP * LDH;          // [32][LDD]
+        // ---- (3) dH1[pair,k] = D2[pair,:] . W2[:,k]     (A = D2[pair=l31][u=16h+s] from the LDS tile)
+        float d2a[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(D2s + l31 * LDD + 16 * h + q * 4);
+          d2a[q * 4 + 0] = v[0]; d2a[q * 4 + 1] = v[1]; d2a[q * 4 + 2] = v[2]; d2a[q * 4 + 3] = v[3];
+        }
+        f32x16 accH[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accH[0][i] = 0.f; accH[1][i] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const float w0 = W2s[(16 * h + s2) * LDH + l31], w1 = W2s[(16 * h + s2) * LDH + 32 + l31];
+          accH[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s2], w0, accH[0], 0, 0, 0);
+          accH[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s2], w1, accH[1], 0, 0, 0);
+        }
+        // through dropout + relu of layer 1 (h1 > 0 <=> kept and positive); C layout: lane = column, reg = pair row
+        float dh[16][2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float c0 = H1s[crow(r, h) * LDH + l31], c1 = H1s[crow(r, h) * LDH + 32 + l31];   // H1 in the column layout
+          dh[r][0] = c0 > 0.f ? accH[0][r] * inv_keep : 0.f;
+          dh[r][1] = c1 > 0.f ? accH[1][r] * inv_keep : 0.f;
+        }
+        // ---- (4) dB[lab,k] += onehot(li[pair])[lab] * dH1[pair,k] on the bf16 matrix cores (exact products: see
+        //      k_pair_bwd_mfma); k index of step t2, lane half h, element j  <->  pair row crow(8 t2 + j, h)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          pbf16x8 bp[2][3];
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float v = dh[8 * t2 + j][ct];
+              const __bf16 a = (__bf16)v;
+              const float r1 = v - (float)a;
+              const __bf16 b = (__bf16)r1;
+              bp[ct][0][j] = a; bp[ct][1][j] = b; bp[ct][2][j] = (__bf16)(r1 - (float)b);
+            }
+          int labs[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) labs[j] = XL[par][w][crow(8 * t2 + j, h)];
+#pragma unroll
+          for (int lt = 0; lt < LT; ++lt) {
+            pbf16x8 oh;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oh[j] = (labs[j] == lt * 32 + l31) ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+                accB[lt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, bp[ct][p], accB[lt][ct], 0, 0, 0);
+          }
+        }
+        // ---- dA[pi] += dH1: tile to LDS (aliases H1: every H1 read of this wave is done, the front wave writes the
+        //      other buffer until the next barrier), then run-length flush (pairs arrive sorted by patient)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          H1s[crow(r, h) * LDH + l31] = dh[r][0];
+          H1s[crow(r, h) * LDH + 32 + l31] = dh[r][1];
+        }
+        {
+          float run = 0.f;
+          int cur = -1;
+#pragma unroll
+          for (int bq = 0; bq < 2; ++bq) {
+            float vq[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vq[q] = H1s[(bq * 16 + q) * LDH + lane];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int pp = __builtin_amdgcn_readlane(p_i, bq * 16 + q);
+              if (pp < 0) continue;
+              if (pp != cur) {
+                if (cur >= 0) atomicAdd(dA + (size_t)cur * 64 + lane, run);
+                cur = pp; run = 0.f;
+              }
+              run += vq[q];
+            }
+          }
+          if (cur >= 0) atomicAdd(dA + (size_t)cur * 64 + lane, run);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- final flush: the four back waves' accumulators summed through LDS in wave order (one slab per workgroup); the
+  //      hand-off buffers are dead: every wave passed the last barrier of the tile loop
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt) {
+          if (ww == 0) {
+            red[(32 + lt * 32 + r) * 64 + lane] = accB[lt][0][r];
+            red[(48 + lt * 32 + r) * 64 + lane] = accB[lt][1][r];
+          } else {
+            red[(32 + lt * 32 + r) * 64 + lane] += accB[lt][0][r];
+            red[(48 + lt * 32 + r) * 64 + lane] += accB[lt][1][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int LT, bool AUX>
+__global__ __launch_bounds__(512) void k_pair_bwd_duo(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
+                                                      const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
+                                                      int thr, int want_low, int64_t n, int n_labs, float drop_p,
+                                                      uint64_t seed, const uint64_t* __restrict__ seed_ptr, PairBufs pb,
+                                                      const float* __restrict__ dpred, const int32_t* __restrict__ sel,
+                                                      const int32_t* __restrict__ n_sel, float* __restrict__ slab) {
+  if (seed_ptr) seed = *seed_ptr;
+  if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }
+  __shared__ __attribute__((aligned(16))) float HX[2][4][HAND_LDS];      // hand-off tiles: [buffer][wave pair]
+  __shared__ __attribute__((aligned(16))) float smf[4 * FRONT_LDS];
+  __shared__ __attribute__((aligned(16))) float W2s[32 * LDH];
+  __shared__ int XP[2][4][TP], XL[2][4][TP];
+  __shared__ float tail_red[4][68];
+  const int tid = threadIdx.x, wid = tid >> 6;
+  for (int i = tid; i < 2048; i += 512) W2s[(i >> 6) * LDH + (i & 63)] = H.W2[i];
+  __syncthreads();
+  // tiles wave_id, wave_id + n_waves, ...: the first front wave of the workgroup has the most -- every wave runs that many
+  // iterations (+ 1: the back waves trail by one) so that all of them meet at the same barriers
+  const int64_t n_tiles = (n + TP - 1) / TP, n_waves = (int64_t)gridDim.x * 4, first = (int64_t)blockIdx.x * 4;
+  const int n_iter = first < n_tiles ? (int)((n_tiles - first + n_waves - 1) / n_waves) : 0;
+  float* red = &HX[0][0][0];
+  constexpr int NR = (2 + 2 * LT) * 16;
+  static_assert(NR * 64 <= 2 * 4 * HAND_LDS, "reduction tile must fit the hand-off buffers");
+  if (wid < 4)
+    pair_bwd_front<LT, AUX>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter, smf + (wid & 3) * FRONT_LDS, W2s,
+                            HX, XP, XL, tail_red, red);
+  else
+    pair_bwd_back<LT>(Gd.dA, drop_p, n_iter, W2s, HX, XP, XL, red);
+  // ---- one partial slab per workgroup (summed over the workgroups in fixed order by mmg_k_reduce_slabs)
+  float* my = slab + (size_t)blockIdx.x * pair_slab_floats(LT);
+  for (int e = tid; e < NR * 64; e += 512) {
+    const int slot = e >> 6, ln = e & 63;
+    const float v = red[e];
+    const int hh = ln >> 5, c31 = ln & 31;
+    if (slot < 32) {
+      const int ct = slot >> 4, r = slot & 15;
+      my[crow(r, hh) * 64 + ct * 32 + c31] = v;
+    } else {
+      const int q = slot - 32, lt = q >> 5, ct = (q >> 4) & 1, r = q & 15;
+      my[2048 + (lt * 32 + crow(r, hh)) * 64 + ct * 32 + c31] = v;
+    }
+  }
+  __syncthreads();                                   // the front waves' tail sums are in tail_red
+  if (tid < 68) {
+    const float t = tid < 65 ? ((tail_red[0][tid] + tail_red[1][tid]) + tail_red[2][tid]) + tail_red[3][tid] : 0.f;
+    const int dst = tid < 32 ? 32 + tid : (tid < 64 ? tid - 32 : tid);
+    my[2048 + LT * 2048 + dst] = t;
+  }
+}
+
 // adds the summed slab into the caller's gradient buffers (single writer per element: plain read-modify-write)
 struct EpiPairFlush {
   float *dW2, *dB, *db2, *dW3, *db3;
@@ -1041,19 +1415,21 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
   HeadGradDev G{grad->dA, grad->dB, grad->dW2, grad->db2, grad->dW3, grad->db3};
   hipStream_t st = (hipStream_t)stream;
   if (n_labs <= 128) {
-    // MFMA path: one wave per 32-pair tile, 4 waves per workgroup, persistent grid
+    // MFMA path: a front and a back wave per 32-pair tile, 4 + 4 waves per workgroup, persistent grid
     int64_t g = ((n_pairs + TP - 1) / TP + 3) / 4;
     if (g > 256) g = 256;                // ONE workgroup is resident per CU; fewer workgroups = fewer partial slabs
     if (g < 1) g = 1;
     MMG_CHECK_ARG(ws && ws_bytes >= mmg_pair_head_bwd_ws_bytes(n_pairs, n_labs), "pair_head_bwd: workspace too small");
     float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-#define MMG_LAUNCH_PBWD(LT_, AUX_)                                                                                    \
-  MMG_LAUNCH(MMG_PROBE_PAIR_BWD, n_pairs, 0, 0, want_low ? 2 : 0, (k_pair_bwd_mfma<LT_, AUX_>), dim3((unsigned)g),      \
-             dim3(256), 0, st, H, G, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed,    \
+    // up to 64 labs: a front and a back wave per tile (k_pair_bwd_duo); beyond (four lab tiles of dB accumulators: 128
+    // registers more in the back wave) the one-wave-per-tile kernel
+#define MMG_LAUNCH_PBWD(KERNEL_, NT_)                                                                                 \
+  MMG_LAUNCH(MMG_PROBE_PAIR_BWD, n_pairs, 0, 0, want_low ? 2 : 0, KERNEL_, dim3((unsigned)g),                          \
+             dim3(NT_), 0, st, H, G, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed,     \
              seed_ptr, pb, dpred, sel, n_sel, slab)
     const bool aux = pair_id != nullptr || io_perm != nullptr;
-    if (n_labs <= 64) { if (aux) MMG_LAUNCH_PBWD(2, true); else MMG_LAUNCH_PBWD(2, false); }
-    else { if (aux) MMG_LAUNCH_PBWD(4, true); else MMG_LAUNCH_PBWD(4, false); }
+    if (n_labs <= 64) { if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, true>), 512); else MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, false>), 512); }
+    else { if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_mfma<4, true>), 256); else MMG_LAUNCH_PBWD((k_pair_bwd_mfma<4, false>), 256); }
 #undef MMG_LAUNCH_PBWD
     const int LT = n_labs <= 64 ? 2 : 4;
     const int64_t n4 = pair_slab_floats(LT) / 4;
