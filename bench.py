@@ -554,6 +554,9 @@ def measure_chain(args, dev, scale, dim, steps):
     try:
         rec = measure(args, 1, 0, dev, scale, False, dim, steps, 3, False, force_comm=True)
     finally:
+        import gc
+        gc.collect()                       # the captured segments of the measurement go before the group they ran under
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
     return rec
 

@@ -440,6 +440,25 @@ int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* 
                       int64_t n_patients, int n_labs,
                       float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
                       float* pred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream);
+/* What autograd would save for the backward of the head (model.py:388-396), per pair k of the pair arrays, written by
+ * mmg_pair_head_fwd_save for every pair it visits and read by mmg_pair_head_bwd_saved for every pair IT visits (a subset:
+ * same head, same gate, pairs with a non-zero upstream gradient):
+ *   h1_bits[2 k + w] bit j = [h1[32 w + j] > 0] -- the first layer's activation survived ReLU and dropout, so
+ *                            h1 = bit ? (A[pi] + B[li]) / (1 - p) : 0 exactly;
+ *   h2[32 k + u]           = the second layer's activation after ReLU and dropout (its sign pattern is the mask).
+ * The backward then needs no RNG, no second-layer product and no epilogue arithmetic per pair (136 B per pair instead);
+ * its layer-2 mask is the forward's own.  NULL `saved` = the plain entry points (the backward recomputes).  Up to 64 labs
+ * on the backward side (beyond: recomputed). */
+typedef struct {
+  uint32_t* h1_bits;      /* [n_total, 2] */
+  float* h2;              /* [n_total, 32] */
+} mmg_pair_saved_t;
+int mmg_pair_head_fwd_save(const mmg_head_t* head, const int32_t* pi, const int32_t* li,
+                           const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total,
+                           int64_t n_patients, int n_labs,
+                           float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
+                           float* pred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
+                           const mmg_pair_saved_t* saved, void* stream);
 /* Backward: the weight-side gradients (dW2, db2, dW3, db3, dB) leave every workgroup as ONE partial slab in `ws` and are
  * summed in fixed order (bitwise reproducible); dA rows are flushed per patient run (pairs sorted by patient: a row
  * receives at most two partial sums unless one patient holds more than 32 listed pairs). */
@@ -451,6 +470,13 @@ int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad,
                       const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred,
                       const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
                       void* ws, size_t ws_bytes, void* stream);
+int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_grad_t* grad,
+                            const int32_t* pi, const int32_t* li, const int32_t* deg, int degree_threshold,
+                            int want_low, int64_t n_pairs, int64_t n_total, int64_t n_patients, int n_labs, float drop_p,
+                            uint64_t seed,
+                            const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred,
+                            const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
+                            const mmg_pair_saved_t* saved, void* ws, size_t ws_bytes, void* stream);
 
 /* Stable two-way compaction of pair positions by head: position k goes to sel_low if deg[pi[k]] < threshold,
  * else to sel_high -- and only if dpred is NULL or dpred[k] != 0.  Order inside a list = pair order (pairs sorted

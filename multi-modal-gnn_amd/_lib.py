@@ -75,6 +75,10 @@ class NextBnT(C.Structure):
                 ("sums", C.c_void_p), ("accumulate", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_size_t)]
 
 
+class PairSavedT(C.Structure):
+    _fields_ = [("h1_bits", C.c_void_p), ("h2", C.c_void_p)]
+
+
 class WgradReduceT(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("n4", C.c_int64), ("n_split", C.c_int), ("dW", C.c_void_p), ("dbias", C.c_void_p),
                 ("nk4", C.c_int64), ("accumulate", C.c_int)]
@@ -158,6 +162,10 @@ SIGNATURES = {
     "mmg_dropout_mask": (C.c_int, [_u64, _vp, _u32, _i64, _i64, _f32, _vp, _vp]),
     "mmg_pair_head_fwd": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _f32, _u64, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp]),
+    "mmg_pair_head_fwd_save": (C.c_int, [_P(HeadT), _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _f32, _u64, _vp, _vp,
+                                         _vp, _vp, _vp, _vp, _P(PairSavedT), _vp]),
+    "mmg_pair_head_bwd_saved": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _f32,
+                                          _u64, _vp, _vp, _vp, _vp, _vp, _vp, _P(PairSavedT), _vp, _sz, _vp]),
     "mmg_pair_head_bwd_ws_bytes": (_sz, [_i64, _i32]),
     "mmg_pair_head_bwd": (C.c_int, [_P(HeadT), _P(HeadGradT), _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _f32,
                                     _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

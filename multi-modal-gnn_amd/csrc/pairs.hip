@@ -624,20 +624,26 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 // summation order per wave and the same slab layout as k_pair_bwd_mfma (dW2 and the three bias-like sums accumulate in
 // the front waves, dB in the back waves).
 constexpr int HAND_LDS = TP * LDH + TP * LDD;      // floats per hand-off buffer: H1 [32][LDH] | D2 [32][LDD]
-constexpr int FRONT_LDS = 3 * TP;                  // floats private to a front wave: dout | pair id lo | hi
+constexpr int FRONT_LDS = 3 * TP + TP * LDD;       // floats private to a front wave: dout | pair id lo | hi | saved h2 tile
 
-template <int LT, bool AUX>
+// SAVED: the forward left the sign bits of h1 and the layer-2 activations of every pair it visited (mmg_pair_saved_t): no
+// RNG, no (1) H2pre product and no layer-2 epilogue arithmetic here -- h1 = bit ? (A + B) / (1 - p) : 0, the layer-2 mask
+// is the sign pattern of the saved activation (which also makes the backward's mask the forward's own: the recomputed
+// product rounds differently from the forward's split-bf16 one at a pre-activation within rounding of 0).
+template <int LT, bool AUX, bool SAVED>
 __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* __restrict__ pi, const int32_t* __restrict__ li,
                                                const int32_t* __restrict__ deg, int thr, int want_low, int64_t n, float drop_p,
                                                uint64_t seed, const PairBufs& pb, const float* __restrict__ dpred,
                                                const int32_t* __restrict__ sel, int n_iter, float* fl, const float* W2s,
                                                float (*HX)[4][HAND_LDS], int (*XP)[4][TP], int (*XL)[4][TP],
-                                               float (*tail_red)[68], float* red) {
+                                               float (*tail_red)[68], float* red, const uint32_t* __restrict__ sv_bits,
+                                               const float* __restrict__ sv_h2) {
   const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
   const int h = lane >> 5, l31 = lane & 31;
   float* DOs = fl;                                  // [32] dout (0 for inactive)
   unsigned* PLo = reinterpret_cast<unsigned*>(DOs + TP);
   unsigned* PHi = PLo + TP;
+  float* T2 = reinterpret_cast<float*>(PHi + TP);   // SAVED: [32][LDD] the tile's saved layer-2 activations, pair-major
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const float b2v = H.b2[l31], w3v = H.W3[l31];
   float w3acc = 0.f, b2acc = 0.f, b3acc = 0.f;
@@ -684,6 +690,8 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
     m.pid = (AUX && has_pid) ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
     return m;
   };
+  uint32_t sbw = 0u;                                 // SAVED: sign bits of this lane's 32 h1 elements / 16 saved activations
+  f32x4 sh2[SAVED ? 4 : 1];
   auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
     const unsigned pp = m.p_i >= 0 ? (unsigned)m.p_i : 0u;
     *dg = pair_ld_i32(deg_d, pp * 4u);
@@ -693,6 +701,12 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
     for (int q = 0; q < 8; ++q) {
       ra[q] = pair_ld_f4(A_d, ao + q * 16u);
       rb[q] = pair_ld_f4(B_d, bo + q * 16u);
+    }
+    if constexpr (SAVED) {          // (a pair that is not one -- p_i < 0 -- reads entry 0: always inside the buffers)
+      const size_t kc = m.p_i >= 0 ? (size_t)m.k : 0;
+      sbw = sv_bits[kc * 2 + h];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sh2[q] = *reinterpret_cast<const f32x4*>(sv_h2 + kc * 32 + 16 * h + 4 * q);
     }
   };
   const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
@@ -715,6 +729,13 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
       f32x4 ca[8], cb[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
+      const uint32_t cbw = sbw;
+      if constexpr (SAVED) {                       // (private to this wave; read back below, after the h1 phase)
+        // a pair of the tile that is not this head's was never written by the forward: its entry is arbitrary memory
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(T2 + l31 * LDD + 16 * h + 4 * q) = active ? sh2[q] : z4;
+      }
       const Meta m1 = fin_meta(rm1);
       const int k2 = fin_k(kr2, t + 2 * n_waves);
       kr2 = issue_k(t + 3 * n_waves);
@@ -732,49 +753,71 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
           b3acc += dout;
         }
         // ---- h1[pair=l31][k=32h+s]: gather-add, relu, dropout; kept in registers AND written to the hand-off tile
-        float h1a[32];
-        const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          f32x4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(ca[q][j] + cb[q][j], 0.f);
-          if (drop_p > 0.f) mmg_drop4(v, key1, pid * 64ull + (uint64_t)(32 * h + q * 4), thr1, inv_keep);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) h1a[q * 4 + j] = v[j];
-          *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
-        }
-        // ---- (1) H2pre = H1 . W2^T
-        f32x16 acc1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(W2s + l31 * LDH + 32 * h + q * 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[q * 4 + j], wv[j], acc1, 0, 0, 0);
-        }
-        // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
         float d2c[16];
-        uint32_t kb[16];
-        if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PLo, PHi, h, l31, kb);
+        if constexpr (SAVED) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = crow(r, h);
-          const float pre = acc1[r] + b2v;
-          float m = pre > 0.f ? 1.f : 0.f;
-          float post = fmaxf(pre, 0.f);
-          if (drop_p > 0.f) {
-            const bool kp = kb[r] >= mmg_keep_threshold(drop_p);
-            m = kp ? m * inv_keep : 0.f;
-            post = kp ? post * inv_keep : 0.f;
+          for (int q = 0; q < 8; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = active && ((cbw >> (q * 4 + j)) & 1u) ? (ca[q][j] + cb[q][j]) * inv_keep : 0.f;
+            *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
           }
-          const float dr = DOs[row];
-          const float d2 = dr * w3v * m;
-          d2c[r] = d2;
-          w3acc = fmaf(dr, post, w3acc);
-          b2acc += d2;
-          D2s[row * LDD + l31] = d2;
+          // ---- layer 2 from the saved activation, in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, h);
+            const float post = T2[row * LDD + l31];
+            const float dr = DOs[row];
+            const float d2 = post > 0.f ? dr * w3v * inv_keep : 0.f;
+            d2c[r] = d2;
+            w3acc = fmaf(dr, post, w3acc);
+            b2acc += d2;
+            D2s[row * LDD + l31] = d2;
+          }
+        } else {
+          float h1a[32];
+          const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(ca[q][j] + cb[q][j], 0.f);
+            if (drop_p > 0.f) mmg_drop4(v, key1, pid * 64ull + (uint64_t)(32 * h + q * 4), thr1, inv_keep);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h1a[q * 4 + j] = v[j];
+            *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
+          }
+          // ---- (1) H2pre = H1 . W2^T
+          f32x16 acc1;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(W2s + l31 * LDH + 32 * h + q * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[q * 4 + j], wv[j], acc1, 0, 0, 0);
+          }
+          // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
+          uint32_t kb[16];
+          if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PLo, PHi, h, l31, kb);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, h);
+            const float pre = acc1[r] + b2v;
+            float m = pre > 0.f ? 1.f : 0.f;
+            float post = fmaxf(pre, 0.f);
+            if (drop_p > 0.f) {
+              const bool kp = kb[r] >= mmg_keep_threshold(drop_p);
+              m = kp ? m * inv_keep : 0.f;
+              post = kp ? post * inv_keep : 0.f;
+            }
+            const float dr = DOs[row];
+            const float d2 = dr * w3v * m;
+            d2c[r] = d2;
+            w3acc = fmaf(dr, post, w3acc);
+            b2acc += d2;
+            D2s[row * LDD + l31] = d2;
+          }
         }
         // ---- (2) dW2[u,k] += D2[pair,u] * H1[pair,k]   (A = d2c: already lane = u, step s = pair crow(s,h); B = H1 in
         //      the column layout, read back from the tile this wave wrote above)
@@ -784,6 +827,9 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
           accW2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2c[s2], c0, accW2[0], 0, 0, 0);
           accW2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2c[s2], c1, accW2[1], 0, 0, 0);
         }
+        // (with the saved state this wave has little vector work left, but giving it (3) dH1 as well -- a nearly pure
+        //  matrix wave of 64 fp32 instructions beside a vector-only back wave -- measured 218 us against 153: the long
+        //  matrix phase starves the other wave's issue; the two contractions stay split between the waves)
       }
     }
     __syncthreads();
@@ -933,13 +979,14 @@ __device__ __forceinline__ void pair_bwd_back(float* __restrict__ dA, float drop
   }
 }
 
-template <int LT, bool AUX>
+template <int LT, bool AUX, bool SAVED>
 __global__ __launch_bounds__(512) void k_pair_bwd_duo(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                       const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                       int thr, int want_low, int64_t n, int n_labs, float drop_p,
                                                       uint64_t seed, const uint64_t* __restrict__ seed_ptr, PairBufs pb,
                                                       const float* __restrict__ dpred, const int32_t* __restrict__ sel,
-                                                      const int32_t* __restrict__ n_sel, float* __restrict__ slab) {
+                                                      const int32_t* __restrict__ n_sel, float* __restrict__ slab,
+                                                      const uint32_t* __restrict__ sv_bits, const float* __restrict__ sv_h2) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }
   __shared__ __attribute__((aligned(16))) float HX[2][4][HAND_LDS];      // hand-off tiles: [buffer][wave pair]
@@ -958,8 +1005,8 @@ __global__ __launch_bounds__(512) void k_pair_bwd_duo(HeadDev H, HeadGradDev Gd,
   constexpr int NR = (2 + 2 * LT) * 16;
   static_assert(NR * 64 <= 2 * 4 * HAND_LDS, "reduction tile must fit the hand-off buffers");
   if (wid < 4)
-    pair_bwd_front<LT, AUX>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter, smf + (wid & 3) * FRONT_LDS, W2s,
-                            HX, XP, XL, tail_red, red);
+    pair_bwd_front<LT, AUX, SAVED>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter,
+                                   smf + (wid & 3) * FRONT_LDS, W2s, HX, XP, XL, tail_red, red, sv_bits, sv_h2);
   else
     pair_bwd_back<LT>(Gd.dA, drop_p, n_iter, W2s, HX, XP, XL, red);
   // ---- one partial slab per workgroup (summed over the workgroups in fixed order by mmg_k_reduce_slabs)
@@ -1015,7 +1062,11 @@ struct EpiPairFlush {
 // mask (registers 4i .. 4i+3 are one aligned RNG group: one hash each), the 32 -> 1 output layer as 16 FMAs -- and
 // one cross-half add finishes a prediction.  No LDS, no shuffles, no barrier.
 constexpr int PF_LDB = 68;           // LDS row stride of the lab-side table (floats): rows land 4 banks apart
-template <bool B_LDS>
+// SAVE (training): the forward leaves what the backward would otherwise recompute per pair k (mmg_pair_saved_t):
+//   sv_bits[2 k + w]  bit j = [h1[32 w + j] > 0]  (kept by dropout AND positive: h1 = bit ? (A + B) / (1 - p) : 0 exactly)
+//   sv_h2[32 k + u]   the layer-2 activation after ReLU and dropout (its sign pattern is the layer-2 mask)
+// 136 B per pair instead of 12 RNG hashes, a 64 x 32 matrix product and its epilogue per pair in the backward.
+template <bool B_LDS, bool SAVE>
 __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32_t* __restrict__ pi,
                                                           const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                           int thr, int want_low, int64_t n, float drop_p, uint64_t seed,
@@ -1023,7 +1074,8 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
                                                           PairBufs pb, float* __restrict__ pred,
                                                           const int32_t* __restrict__ sel,
                                                           const int32_t* __restrict__ n_sel,
-                                                          int n_labs_lds) {
+                                                          int n_labs_lds, uint32_t* __restrict__ sv_bits,
+                                                          float* __restrict__ sv_h2) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }     // never beyond the list's capacity
   // the lab-side first-layer table B (a few dozen 256-B rows, read once per PAIR) lives in LDS when it fits:
@@ -1148,6 +1200,7 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    uint32_t bw[2] = {0u, 0u};                       // SAVE: this lane's 2 x 16 sign bits of h1
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {                 // 16 h1 columns per k-step, this lane: 16 ks + 8 h + 0..7
       float x8[8];
@@ -1159,6 +1212,10 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
         if (drop_p > 0.f) mmg_drop4(x, key1, mc.pid * 64ull + (uint64_t)(16 * ks + 8 * h + 4 * c), thr_keep, inv_keep);
 #pragma unroll
         for (int j = 0; j < 4; ++j) x8[4 * c + j] = x[j];
+      }
+      if constexpr (SAVE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bw[ks >> 1] |= x8[j] > 0.f ? (1u << (16 * (ks & 1) + j)) << (8 * h) : 0u;
       }
       pbf16x8 x1, x2, x3;
 #pragma unroll
@@ -1186,6 +1243,14 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
       if (drop_p > 0.f) mmg_drop4(post, key2, mc.pid * 32ull + (uint64_t)(8 * i + 4 * h), thr_keep, inv_keep);
 #pragma unroll
       for (int e = 0; e < 4; ++e) part = fmaf(w3r[4 * i + e], post[e], part);
+      if constexpr (SAVE) {
+        if (active) *reinterpret_cast<f32x4*>(sv_h2 + (size_t)mc.k * 32 + 8 * i + 4 * h) = post;
+      }
+    }
+    if constexpr (SAVE) {
+      bw[0] |= (uint32_t)__shfl_xor((int)bw[0], 32, 64);
+      bw[1] |= (uint32_t)__shfl_xor((int)bw[1], 32, 64);
+      if (h == 0 && active) *reinterpret_cast<pu32x2*>(sv_bits + (size_t)mc.k * 2) = pu32x2{bw[0], bw[1]};
     }
     part += __shfl_xor(part, 32, 64);
     if (h == 0 && active)          // (a slot past the end of pred is dropped by the descriptor's range check)
@@ -1352,10 +1417,26 @@ static int fill_pair_bufs(PairBufs* pb, const int32_t* pi, const int64_t* pair_i
   return MMG_OK;
 }
 
+extern "C" int mmg_pair_head_fwd_save(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
+                                      int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total,
+                                      int64_t n_patients, int n_labs, float drop_p, uint64_t seed, const uint64_t* seed_ptr,
+                                      const int64_t* pair_id, float* pred, const int32_t* sel, const int32_t* n_sel,
+                                      const int64_t* io_perm, const mmg_pair_saved_t* saved, void* stream);
+
 extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
                                  int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total, int64_t n_patients,
                                  int n_labs, float drop_p, uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id,
                                  float* pred, const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm, void* stream) {
+  return mmg_pair_head_fwd_save(head, pi, li, deg, degree_threshold, want_low, n_pairs, n_total, n_patients, n_labs, drop_p,
+                                seed, seed_ptr, pair_id, pred, sel, n_sel, io_perm, nullptr, stream);
+}
+
+extern "C" int mmg_pair_head_fwd_save(const mmg_head_t* head, const int32_t* pi, const int32_t* li, const int32_t* deg,
+                                      int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total,
+                                      int64_t n_patients, int n_labs, float drop_p, uint64_t seed, const uint64_t* seed_ptr,
+                                      const int64_t* pair_id, float* pred, const int32_t* sel, const int32_t* n_sel,
+                                      const int64_t* io_perm, const mmg_pair_saved_t* saved, void* stream) {
+  MMG_CHECK_ARG(!saved || (saved->h1_bits && saved->h2), "pair_head_fwd_save: saved buffers with a null pointer");
   MMG_CHECK_ARG(n_pairs >= 0, "pair_head_fwd: n_pairs < 0");
   MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_fwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
@@ -1373,17 +1454,25 @@ extern "C" int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, cons
   if (g < 1) g = 1;
   const int n_labs_lds = n_labs <= 256 ? n_labs : 0;       // 256 rows x 272 B = 68 KB: two workgroups per CU
   const size_t lds = (size_t)n_labs_lds * PF_LDB * sizeof(float);
+  uint32_t* svb = saved ? saved->h1_bits : nullptr;
+  float* svh = saved ? saved->h2 : nullptr;
+  constexpr int lds_max = 256 * PF_LDB * (int)sizeof(float);
+#define MMG_LAUNCH_PFWD(BL_, SV_, LDS_, NL_)                                                                           \
+  MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, (want_low ? 2 : 0) | (SV_ ? 512 : 0), (k_pair_fwd_mfma<BL_, SV_>),      \
+             dim3((unsigned)g), dim3(256), LDS_, (hipStream_t)stream, H, pi, li, deg, degree_threshold, want_low ? 1 : 0, \
+             n_pairs, drop_p, seed, seed_ptr, pb, pred, sel, n_sel, NL_, svb, svh)
   if (n_labs_lds) {
-    constexpr int lds_max = 256 * PF_LDB * (int)sizeof(float);
-    MMG_CHECK_HIP((MmgMaxLds<&k_pair_fwd_mfma<true>, lds_max>::set()), "pair_head_fwd(attr)");
-    MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, want_low ? 2 : 0, k_pair_fwd_mfma<true>, dim3((unsigned)g), dim3(256),
-               lds, (hipStream_t)stream, H, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed,
-               seed_ptr, pb, pred, sel, n_sel, n_labs_lds);
+    if (saved) {
+      MMG_CHECK_HIP((MmgMaxLds<&k_pair_fwd_mfma<true, true>, lds_max>::set()), "pair_head_fwd(attr)");
+      MMG_LAUNCH_PFWD(true, true, lds, n_labs_lds);
+    } else {
+      MMG_CHECK_HIP((MmgMaxLds<&k_pair_fwd_mfma<true, false>, lds_max>::set()), "pair_head_fwd(attr)");
+      MMG_LAUNCH_PFWD(true, false, lds, n_labs_lds);
+    }
   } else {
-    MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, want_low ? 2 : 0, k_pair_fwd_mfma<false>, dim3((unsigned)g), dim3(256),
-               0, (hipStream_t)stream, H, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, drop_p, seed,
-               seed_ptr, pb, pred, sel, n_sel, 0);
+    if (saved) MMG_LAUNCH_PFWD(false, true, 0, 0); else MMG_LAUNCH_PFWD(false, false, 0, 0);
   }
+#undef MMG_LAUNCH_PFWD
   MMG_CHECK_LAUNCH("pair_head_fwd");
   return MMG_OK;
 }
@@ -1393,11 +1482,29 @@ extern "C" size_t mmg_pair_head_bwd_ws_bytes(int64_t n_pairs, int n_labs) {
   return (size_t)256 * pair_slab_floats(n_labs <= 64 ? 2 : 4) * sizeof(float) + 256;
 }
 
+extern "C" int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi,
+                                       const int32_t* li, const int32_t* deg, int degree_threshold, int want_low,
+                                       int64_t n_pairs, int64_t n_total, int64_t n_patients, int n_labs, float drop_p,
+                                       uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred,
+                                       const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
+                                       const mmg_pair_saved_t* saved, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi, const int32_t* li,
                                  const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total,
                                  int64_t n_patients, int n_labs, float drop_p, uint64_t seed, const uint64_t* seed_ptr,
                                  const int64_t* pair_id, const float* dpred, const int32_t* sel, const int32_t* n_sel,
                                  const int64_t* io_perm, void* ws, size_t ws_bytes, void* stream) {
+  return mmg_pair_head_bwd_saved(head, grad, pi, li, deg, degree_threshold, want_low, n_pairs, n_total, n_patients, n_labs,
+                                 drop_p, seed, seed_ptr, pair_id, dpred, sel, n_sel, io_perm, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_grad_t* grad, const int32_t* pi,
+                                       const int32_t* li, const int32_t* deg, int degree_threshold, int want_low,
+                                       int64_t n_pairs, int64_t n_total, int64_t n_patients, int n_labs, float drop_p,
+                                       uint64_t seed, const uint64_t* seed_ptr, const int64_t* pair_id, const float* dpred,
+                                       const int32_t* sel, const int32_t* n_sel, const int64_t* io_perm,
+                                       const mmg_pair_saved_t* saved, void* ws, size_t ws_bytes, void* stream) {
+  MMG_CHECK_ARG(!saved || (saved->h1_bits && saved->h2), "pair_head_bwd_saved: saved buffers with a null pointer");
   MMG_CHECK_ARG(n_pairs >= 0 && n_labs >= 0, "pair_head_bwd: negative size");
   MMG_CHECK_ARG((sel == nullptr) == (n_sel == nullptr), "pair_head_bwd: sel and n_sel go together");
   if (n_pairs == 0) return MMG_OK;
@@ -1423,13 +1530,22 @@ extern "C" int mmg_pair_head_bwd(const mmg_head_t* head, const mmg_head_grad_t* 
     float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     // up to 64 labs: a front and a back wave per tile (k_pair_bwd_duo); beyond (four lab tiles of dB accumulators: 128
     // registers more in the back wave) the one-wave-per-tile kernel
-#define MMG_LAUNCH_PBWD(KERNEL_, NT_)                                                                                 \
+#define MMG_LAUNCH_PBWD(KERNEL_, NT_, ...)                                                                            \
   MMG_LAUNCH(MMG_PROBE_PAIR_BWD, n_pairs, 0, 0, want_low ? 2 : 0, KERNEL_, dim3((unsigned)g),                          \
              dim3(NT_), 0, st, H, G, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed,     \
-             seed_ptr, pb, dpred, sel, n_sel, slab)
+             seed_ptr, pb, dpred, sel, n_sel, slab, ##__VA_ARGS__)
     const bool aux = pair_id != nullptr || io_perm != nullptr;
-    if (n_labs <= 64) { if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, true>), 512); else MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, false>), 512); }
-    else { if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_mfma<4, true>), 256); else MMG_LAUNCH_PBWD((k_pair_bwd_mfma<4, false>), 256); }
+    const uint32_t* svb = saved ? saved->h1_bits : nullptr;
+    const float* svh = saved ? saved->h2 : nullptr;
+    if (n_labs <= 64) {
+      if (saved) {
+        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, true, true>), 512, svb, svh);
+        else MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, false, true>), 512, svb, svh);
+      } else {
+        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, true, false>), 512, svb, svh);
+        else MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, false, false>), 512, svb, svh);
+      }
+    } else { if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_mfma<4, true>), 256); else MMG_LAUNCH_PBWD((k_pair_bwd_mfma<4, false>), 256); }
 #undef MMG_LAUNCH_PBWD
     const int LT = n_labs <= 64 ? 2 : 4;
     const int64_t n4 = pair_slab_floats(LT) / 4;

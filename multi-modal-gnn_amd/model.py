@@ -49,6 +49,15 @@ def set_overlap(mode: str):
 # register spills they cause in those two kernels) cost more than the one joint pass they replace -- x100 eICU shape, same
 # box: none 2.468 ms, heads+conv+enc2 2.431 ms, all four 2.465 ms per step.
 NEXT_BN_SITES = frozenset({"heads", "conv", "enc2"})
+# Optional (off): in training the pair heads' forward can save, per visited pair, the sign bits of the first layer and the
+# activations of the second (ops.pair_saved_alloc: 136 B per pair of the pair set), and the backward reads them instead of
+# recomputing twelve dropout hashes, a 64 x 32 product and its epilogue per pair ("store the mask words
+# in the forward ... measure both").  Measured at the x100 shape: backward 189 -> 160 us, forward over the 0.86 M
+# supervised pairs 60 -> 72 us, 2.392 -> 2.385 ms per step (0.3 %); a forward over ALL 4.3 M pairs pays 242 -> 310 us for
+# the same 29 us.  It also makes the supervised-only step equal to the all-pairs step only up to rounding (the saved
+# activation comes from the forward's split-bf16 product, the recomputed one from the fp32 matrix instruction) instead of
+# bit for bit.  Only used where the forward visits the supervision subset alone.
+SAVE_PAIR_STATE = False
 
 
 def set_next_bn(sites):
@@ -1272,10 +1281,14 @@ class _Run:
                 xP = src[ROW_TYPE].index_select(0, low_rows) if want_low else src[ROW_TYPE]
             head, w1a, w1b = self.head_tensors(which, xP, src["lab"], *halves[which])
             sel, n_sel, nb = (sel_low, counts[0:1], n_low) if want_low else (sel_high, counts[1:2], n_high)
+            # training: the forward leaves the first layer's sign bits and the second layer's activations of the pairs it
+            # visits (136 B per pair) -- the backward then recomputes neither the dropout masks nor the 64 x 32 product
+            save = ops.pair_saved_alloc(pi.numel(), self.dev) \
+                if self.T and SAVE_PAIR_STATE and self.forward_select is not None else None
             ops.pair_head_fwd(head, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr, want_low,
                               self.p, self.seed, ids, pred, self.seed_dev,
-                              sel=sel, n_sel=n_sel, n_bound=nb, io_perm=perm)      # written in the caller's pair order
-            rec[which] = (head, w1a, w1b, xP)
+                              sel=sel, n_sel=n_sel, n_bound=nb, io_perm=perm, save=save)   # written in the caller's pair order
+            rec[which] = (head, w1a, w1b, xP, save)
         return pred, rec
 
     def heads_bwd(self, rec, dpred):
@@ -1319,12 +1332,12 @@ class _Run:
             oa += tA.numel()
         gs, join = {}, []
         for which, src, want_low in order:
-            head, w1a, w1b, xP = rec[which]
+            head, w1a, w1b, xP, save = rec[which]
             g = ops.Head(dA[which], *views[which])
             sel, n_sel, nb = (bsel_low, bcounts[0:1], n_low) if want_low else (bsel_high, bcounts[1:2], n_high)
             ops.pair_head_bwd(head, g, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr,
                               want_low, n_lab, self.p, self.seed, ids, dsrc,
-                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb, io_perm=dio)
+                              self.seed_dev, sel=sel, n_sel=n_sel, n_bound=nb, io_perm=dio, saved=save)
             gs[which] = g
             self.acc(f"{which}.mlp.3.weight", g.W2, partial=True)
             self.acc(f"{which}.mlp.3.bias", g.b2, partial=True)
@@ -1346,7 +1359,7 @@ class _Run:
         ops.vec_sums(join)                       # [dW1a | dW1b] of both heads: one launch
         self.allreduce(flat[:n_b])               # lab-side partials dB of both heads from the sharded pairs
         for which, src, want_low in order:
-            head, w1a, w1b, xP = rec[which]
+            head, w1a, w1b, xP, _ = rec[which]
             g = gs[which]
             glab = ops.linear_fwd(g.B, w1b, w_kn=True)
             if want_low:                         # gradient rows of the low-degree patients only: (row ids, rows)

@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import (BnFinT, HeadGradT, HeadT, NextBnT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, WgradReduceT,
+from ._lib import (BnFinT, HeadGradT, HeadT, NextBnT, PairSavedT, PrologueT, RelT, SmallBnBwdT, SmallBnT, SmallFwdT, SmallWgradT, SumJobT, WgradReduceT,
                    check)
 
 BN_MOMENTUM = 0.1
@@ -798,29 +798,53 @@ def _pair_sizes(head: Head, pi, li, deg, pair_id, io_perm, per_pair):
         raise ValueError("pair head: A and B must be [rows, 64]")
 
 
+def pair_saved_alloc(n_total: int, device):
+    """Buffers of mmg_pair_saved_t for a pair set of n_total pairs: (h1 sign bits int32 [n_total, 2], layer-2 activations
+    float32 [n_total, 32]).  The forward fills the entries of the pairs it visits, the backward reads those it visits."""
+    return (torch.empty(max(n_total, 1), 2, dtype=torch.int32, device=device),
+            torch.empty(max(n_total, 1), 32, dtype=torch.float32, device=device))
+
+
+def _pair_saved(saved, n_total: int):
+    if saved is None:
+        return None
+    bits, h2 = saved
+    if bits.dtype != torch.int32 or tuple(bits.shape) != (max(n_total, 1), 2) or h2.dtype != torch.float32 or \
+            tuple(h2.shape) != (max(n_total, 1), 32):
+        raise ValueError("pair head: saved = (int32 [n_total, 2], float32 [n_total, 32]) -- see pair_saved_alloc")
+    return PairSavedT(_p(bits, torch.int32).value, _p(h2).value)
+
+
 def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred, seed_dev=None,
-                  sel=None, n_sel=None, n_bound: Optional[int] = None, io_perm=None):
+                  sel=None, n_sel=None, n_bound: Optional[int] = None, io_perm=None, save=None):
     """sel / n_sel: compacted positions (pair_select) and their device-resident count; n_bound >= that count.
-    io_perm: pred is written to pred[io_perm[k]] (the caller's pair order)."""
+    io_perm: pred is written to pred[io_perm[k]] (the caller's pair order).
+    save = pair_saved_alloc(...): also leave what the backward needs per visited pair (mmg_pair_saved_t)."""
     lib = _lib.load()
     n = pi.numel() if sel is None else int(n_bound)
     if n == 0:
         return
     h = head.c()
     _pair_sizes(head, pi, li, deg, pair_id, io_perm, pred)
+    sv = _pair_saved(save, pi.numel())
     _tok = _pb("pair_head_fwd")
-    check(lib.mmg_pair_head_fwd(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
-                                int(want_low), n, pi.numel(), min(int(head.A.shape[0]), deg.numel()),
-                                int(head.B.shape[0]), float(p), seed & 0xFFFFFFFFFFFFFFFF,
-                                _p(seed_dev, torch.int64),
-                                _p(pair_id, torch.int64), _p(pred), _p(sel, torch.int32), _p(n_sel, torch.int32),
-                                _p(io_perm, torch.int64), _stream()), "mmg_pair_head_fwd")
-    _pe(_tok, "pair_head_fwd", n * 12 + 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (64 * 32 + 32 + 64))
+    check(lib.mmg_pair_head_fwd_save(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
+                                     int(want_low), n, pi.numel(), min(int(head.A.shape[0]), deg.numel()),
+                                     int(head.B.shape[0]), float(p), seed & 0xFFFFFFFFFFFFFFFF,
+                                     _p(seed_dev, torch.int64),
+                                     _p(pair_id, torch.int64), _p(pred), _p(sel, torch.int32), _p(n_sel, torch.int32),
+                                     _p(io_perm, torch.int64), C.byref(sv) if sv is not None else None, _stream()),
+          "mmg_pair_head_fwd_save")
+    _pe(_tok, "pair_head_fwd", n * (12 + (136 if sv is not None else 0)) + 256 * (head.A.shape[0] + head.B.shape[0]),
+        n * 2 * (64 * 32 + 32 + 64))
 
 
 def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool, n_labs: int, p: float, seed: int,
-                  pair_id, dpred, seed_dev=None, sel=None, n_sel=None, n_bound: Optional[int] = None, io_perm=None):
-    """`grads` mirrors `head` (dA,dB,dW2,db2,dW3,db3), accumulated in place."""
+                  pair_id, dpred, seed_dev=None, sel=None, n_sel=None, n_bound: Optional[int] = None, io_perm=None,
+                  saved=None):
+    """`grads` mirrors `head` (dA,dB,dW2,db2,dW3,db3), accumulated in place.
+    saved: what pair_head_fwd(..., save=...) of the SAME head, gate, seed and pair arrays left (it must have visited every
+    pair this call visits); None = recompute."""
     lib = _lib.load()
     n = pi.numel() if sel is None else int(n_bound)
     if n == 0:
@@ -831,13 +855,15 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
     _pair_sizes(head, pi, li, deg, pair_id, io_perm, dpred)
     if tuple(grads.A.shape) != tuple(head.A.shape) or tuple(grads.B.shape) != tuple(head.B.shape):
         raise ValueError("pair_head_bwd: gradient tables must have the shapes of A and B")
+    sv = _pair_saved(saved, pi.numel())
     _tok = _pb("pair_head_bwd")
-    check(lib.mmg_pair_head_bwd(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32),
-                                thr, int(want_low), n, pi.numel(), min(int(head.A.shape[0]), deg.numel()), n_labs, float(p),
-                                seed & 0xFFFFFFFFFFFFFFFF,
-                                _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _p(sel, torch.int32),
-                                _p(n_sel, torch.int32), _p(io_perm, torch.int64), _p(ws, torch.uint8), ws.numel(), _stream()),
-          "mmg_pair_head_bwd")
+    check(lib.mmg_pair_head_bwd_saved(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32),
+                                      _p(deg, torch.int32), thr, int(want_low), n, pi.numel(),
+                                      min(int(head.A.shape[0]), deg.numel()), n_labs, float(p), seed & 0xFFFFFFFFFFFFFFFF,
+                                      _p(seed_dev, torch.int64), _p(pair_id, torch.int64), _p(dpred), _p(sel, torch.int32),
+                                      _p(n_sel, torch.int32), _p(io_perm, torch.int64),
+                                      C.byref(sv) if sv is not None else None, _p(ws, torch.uint8), ws.numel(), _stream()),
+          "mmg_pair_head_bwd_saved")
     _pe(_tok, "pair_head_bwd", n * 12 + 2 * 256 * (head.A.shape[0] + head.B.shape[0]), n * 2 * (4 * 64 * 32))
 
 

@@ -641,6 +641,60 @@ def test_pair_head_fwd_bwd(ops, dev, p, sorted_pairs):
         for name, got, want in zip("A B W2 b2 W3 b3".split(), (g.A, g.B, g.W2, g.b2, g.W3, g.b3), leaf):
             assert rel(got, want.grad) <= 2e-5, (name, want_low)
 
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("listed", [False, True])
+def test_pair_head_backward_from_the_state_the_forward_saved(ops, dev, p, listed):
+    """mmg_pair_head_fwd_save / mmg_pair_head_bwd_saved: the forward leaves the first layer's sign bits and the second
+    layer's activations per visited pair, the backward reads them instead of recomputing masks and the 64 x 32 product --
+    same gradients as the fp64 reference (and as the recomputing backward), full sweep and compacted lists (the backward
+    visits a SUBSET of the forward's pairs: those with a non-zero upstream gradient)."""
+    gen = torch.Generator().manual_seed(57)
+    P, L, n = 700, 50, 9000
+    A, B = torch.randn(P, 64, generator=gen), torch.randn(L, 64, generator=gen)
+    W2, b2 = torch.randn(32, 64, generator=gen) / 8, torch.randn(32, generator=gen) * 0.1
+    W3, b3 = torch.randn(32, generator=gen) / 5, torch.randn(1, generator=gen)
+    pi = torch.randint(0, P, (n,), generator=gen).sort().values
+    li = torch.randint(0, L, (n,), generator=gen)
+    deg = torch.randint(0, 12, (P,), generator=gen)
+    pid = torch.randperm(n, generator=gen)
+    dpred = torch.randn(n, generator=gen) * (torch.rand(n, generator=gen) < 0.3)       # ~70 % of the pairs: exactly 0
+    head = ops.Head(*[t.to(dev) for t in (A, B, W2, b2, W3, b3)])
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    for want_low in (False, True):
+        save = ops.pair_saved_alloc(n, dev)
+        save[0].fill_(-1); save[1].fill_(float("nan"))                                 # an entry that was not written shows
+        pred = torch.zeros(n, device=dev)
+        fsel = bsel = None
+        if listed:
+            lo, hi, cnt = ops.pair_select(i32(pi), i32(deg), 6, None)
+            blo, bhi, bcnt = ops.pair_select(i32(pi), i32(deg), 6, dpred.to(dev))
+            fsel = dict(sel=lo if want_low else hi, n_sel=cnt[0:1] if want_low else cnt[1:2], n_bound=n)
+            bsel = dict(sel=blo if want_low else bhi, n_sel=bcnt[0:1] if want_low else bcnt[1:2], n_bound=n)
+        ops.pair_head_fwd(head, i32(pi), i32(li), i32(deg), 6, want_low, p, 77, pid.to(dev), pred, save=save, **(fsel or {}))
+        ref_pred = torch.zeros(n, device=dev)
+        ops.pair_head_fwd(head, i32(pi), i32(li), i32(deg), 6, want_low, p, 77, pid.to(dev), ref_pred, **(fsel or {}))
+        assert torch.equal(pred, ref_pred)                                             # saving changes nothing in the forward
+        g1 = ops.Head(*[torch.zeros_like(t, device=dev) for t in (A, B, W2, b2, W3, b3)])
+        g0 = ops.Head(*[torch.zeros_like(t, device=dev) for t in (A, B, W2, b2, W3, b3)])
+        ops.pair_head_bwd(head, g1, i32(pi), i32(li), i32(deg), 6, want_low, L, p, 77, pid.to(dev), dpred.to(dev),
+                          saved=save, **(bsel or {}))
+        ops.pair_head_bwd(head, g0, i32(pi), i32(li), i32(deg), 6, want_low, L, p, 77, pid.to(dev), dpred.to(dev),
+                          **(bsel or {}))
+        sel = (deg[pi] < 6) == want_low
+        leaf = [t.double().requires_grad_(True) for t in (A, B, W2, b2, W3, b3)]
+        h1 = torch.relu(leaf[0][pi] + leaf[1][li])
+        if p > 0:
+            h1 = h1 * ops.dropout_mask(77, 64, n, 64, p, dev).cpu().double()[pid] / (1 - p)
+        h2 = torch.relu(h1 @ leaf[2].t() + leaf[3])
+        if p > 0:
+            h2 = h2 * ops.dropout_mask(77, 65, n, 32, p, dev).cpu().double()[pid] / (1 - p)
+        ((h2 @ leaf[4] + leaf[5]) * dpred.double() * sel.double()).sum().backward()
+        for name, got, rec, want in zip("A B W2 b2 W3 b3".split(), (g1.A, g1.B, g1.W2, g1.b2, g1.W3, g1.b3),
+                                        (g0.A, g0.B, g0.W2, g0.b2, g0.W3, g0.b3), leaf):
+            assert rel(got, want.grad) <= 2e-5, (name, want_low)
+            assert rel(got, rec) <= 2e-5, (name, want_low)
+
+
 @pytest.mark.parametrize("n", [1, 2047, 2048, 70001])
 def test_pair_select_stable_two_way(ops, dev, n):
     gen = torch.Generator().manual_seed(n)

@@ -357,7 +357,7 @@ def test_single_graph_step_matches_eager_steps(overlap, monkeypatch):
             assert float((p1 - p2).detach().abs().max()) <= 1e-4 * float(p1.detach().abs().max()) + 1e-6, n
 
 
-def test_rccl_backend_carries_the_sharded_step():
+def test_rccl_backend_carries_the_sharded_step(capfd):
     """The real collective backend under the sharded step: torch.distributed 'nccl' (= RCCL on ROCm) with world_size 1.
     A one-rank group cannot show scaling, but every all-reduce of the step -- Sync-BN statistics (fp64), vocab partial
     sums, the lab-side head gradients, the flat gradient bucket -- goes through ShardComm -> RCCL between the hipGraph
@@ -441,4 +441,13 @@ def test_rccl_backend_carries_the_sharded_step():
             seen.append(step3.sup.clone())
         assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
     finally:
-        dist.destroy_process_group()
+        # Tear the group down with nothing of the step left alive or in flight: the captured segments (and the events the
+        # process group's watchdog thread polls) go first, the device is idle.  Once -- in several hundred runs of this
+        # suite -- the teardown aborted inside destroy_process_group with its C++ message swallowed by pytest's capture:
+        # the capture is off around it so that a recurrence names its cause.
+        step = step3 = m1 = m2 = m3 = opt1 = opt2 = opt3 = comm2 = comm3 = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        with capfd.disabled():
+            dist.destroy_process_group()

@@ -304,3 +304,48 @@ def test_heads_on_the_supervised_pairs_only_change_nothing_a_step_returns(dev, p
     assert torch.equal(p0[sup], p1[sup]) and float(p1[~sup].abs().max()) == 0.0 and float(p0[~sup].abs().max()) > 0.0
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_pair_backward_from_saved_forward_state_in_the_training_step(dev, monkeypatch):
+    """mmgnn.model.SAVE_PAIR_STATE (off by default): the supervised-only heads' forward leaves the first layer's sign bits
+    and the second layer's activations, the backward reads them instead of recomputing masks and the 64 x 32 product.
+    Same step up to rounding (the saved activation comes from the forward's split-bf16 product, the recomputed one from
+    the fp32 matrix instruction): losses 1e-6, parameters after two Adam steps 1e-3 of their largest entry (a Linear bias
+    in front of a BatchNorm has a zero gradient: Adam turns its rounding noise into lr-sized steps -- left out)."""
+    import mmgnn  # noqa: F401
+    import mmgnn.model as mm
+    from mmgnn.data import build_plan
+    from mmgnn.model import build_model
+    from mmgnn.optim import Adam
+    from mmgnn.train import PiecewiseGraphedTrainStep
+    n = (600, 20, 25, 18)
+    cfg = _config(hidden=128, dropout=0.2)
+    g0 = fx.graph_from_frames(fx.det_frames(*n))
+    gv = om.GraphView(g0)
+    sd = fx.det_state(gv.num_nodes, 128)
+    ei, ea = g0["patient", "has_lab", "lab"].edge_index, g0["patient", "has_lab", "lab"].edge_attr
+    tr, _, _ = ot.edge_splits(ei.shape[1])
+    pi, li, y = ei[0][tr].to(dev), ei[1][tr].to(dev), ea[tr].squeeze(-1).to(dev)
+    w = ot.lab_weights(ei[1][tr], ea[tr].squeeze(-1), gv.num_nodes["lab"]).to(dev)
+    sup = (torch.rand(int(tr.sum()), generator=torch.Generator().manual_seed(3)) < 0.2).to(dev)
+    res = []
+    for flag in (False, True):
+        monkeypatch.setattr(mm, "SAVE_PAIR_STATE", flag)
+        torch.manual_seed(99)
+        g = fx.graph_from_frames(fx.det_frames(*n)).to(dev)
+        model = build_model(cfg, (g.node_types, g.edge_types), None).to(dev)
+        model._init_embeddings(g)
+        model.load_state_dict(sd)
+        opt = Adam([q for k, q in model.named_parameters() if not k.startswith("embeddings.")], lr=1e-2)
+        step = PiecewiseGraphedTrainStep(model, build_plan(g, dev, use_cache=False), pi, li, y, w, opt, sup, None,
+                                         supervised_heads_only=True)
+        losses = [float(step.step()) for _ in range(2)]
+        res.append((losses, step.pred.clone(), {k: v.clone() for k, v in model.state_dict().items()}))
+    (l0, p0, s0), (l1, p1, s1) = res
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-6 * abs(a), (l0, l1)
+    for k in s0:
+        if not s0[k].is_floating_point():
+            assert torch.equal(s0[k], s1[k]), k
+        elif not (k.endswith(("patient_transform.0.bias", "patient_transform.4.bias")) or k.endswith(".lin_l.bias")):
+            assert float((s0[k] - s1[k]).abs().max()) <= 1e-3 * float(s0[k].abs().max()) + 1e-7, k
