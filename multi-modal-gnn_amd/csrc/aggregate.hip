@@ -543,6 +543,184 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
   MMG_STAMP(4);
 }
 
+// k_scatter_strip2<NA, NB>: the same strip, its item tiles dealt over TWO waves per SIMD.  k_scatter_strip<9> holds 392
+// registers (144 accumulators + operand ring): ONE wave per SIMD, whose matrix pipe is busy 52 % of its life -- every LUT
+// round trip, every x load it waits for and whatever vector work does not co-issue is exposed.  Here wave w (tiles
+// 0 .. NA-1) and wave w + 4 (tiles NA .. NA+NB-1) of a 512-thread workgroup sit on the same SIMD (profiles/probes/
+// wave_simd) and stream the SAME quarter of the rows, each under 256 registers: while one waits or expands fragments the
+// other multiplies.  Both load and split x themselves (the second reader hits the cache; two splits per SIMD still fit
+// under the matrix time, three -- k_scatter_units at this vocabulary -- did not).  Same arithmetic, same slab layout.
+template <int NT, int RING, int AHEAD>
+__device__ __forceinline__ void strip_main(const RelPack& rp, int64_t n_rows, int n_stage_total, int D, const float* __restrict__ x,
+                                           const unsigned (*lut)[4], int t_first, int q_id, int n_q, f32x16* acc) {
+  constexpr int KS = 8;
+  static_assert((RING & (RING - 1)) == 0 && AHEAD < RING && KS % RING == 0, "ring slots follow the k-step index");
+  const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+  const int d0 = blockIdx.y * 32;
+  const int s_beg = (int)((int64_t)q_id * n_stage_total / n_q);
+  const int s_end = (int)((int64_t)(q_id + 1) * n_stage_total / n_q);
+  const int ns = s_end - s_beg;
+  const int64_t r_beg = (int64_t)s_beg * SB_SR;
+  const int64_t rows_here = ns <= 0 ? 0 : ((n_rows - r_beg) < (int64_t)ns * SB_SR ? (n_rows - r_beg) : (int64_t)ns * SB_SR);
+  const float* xw = x + (size_t)r_beg * D + d0;
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xw), 0, rows_here > 0 ? (int)((rows_here * D - d0) * 4) : 0, 0x00020000);
+  const unsigned row_bytes = (unsigned)D * 4u;
+  const unsigned voff0 = (unsigned)(8 * h) * row_bytes + (unsigned)l31 * 4u;
+  float xq[RING][8];
+  auto loadx = [&](int kg, float* dst) {
+    const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, j * row_bytes, 0));
+  };
+#pragma unroll
+  for (int q = 0; q < AHEAD; ++q) loadx(q, xq[q]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  if (ns <= 0) return;
+  const uint64_t* mb[NT];
+  unsigned ms[NT], lm[NT];
+  const uint64_t* any_mask = nullptr;
+#pragma unroll
+  for (int r = 0; r < MMG_MAX_REL; ++r)
+    if (r < rp.n && rp.r[r].mask && !any_mask) any_mask = rp.r[r].mask;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    mb[t] = any_mask; ms[t] = 0; lm[t] = 0u;
+    const int it = (t_first + t) * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      if (r >= rp.n) continue;
+      const int padc = (rp.r[r].n_cols + 31) & ~31;
+      if (rp.r[r].mask && it >= rp.r[r].acc_off && it < rp.r[r].acc_off + rp.r[r].n_cols) {
+        mb[t] = rp.r[r].mask + ((size_t)s_beg * padc + (it - rp.r[r].acc_off)) * 2 + h;
+        ms[t] = 2u * (unsigned)padc; lm[t] = 0xFF0u;
+      }
+    }
+  }
+  auto loadm = [&](int s, uint64_t* dst) {             // past the end: re-read the last stage (its x reads as 0)
+    const int sc = s < ns ? s : ns - 1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dst[t] = mb[t][(size_t)sc * ms[t]];
+  };
+  auto make_af = [&](const uint64_t* mw, int kq, bf16x8* af) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const unsigned w = (kq & 2) ? (unsigned)(mw[t] >> 32) : (unsigned)mw[t];
+      const unsigned off = (kq & 1) ? ((w >> 16) & lm[t]) : (w & lm[t]);
+      af[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
+    }
+  };
+  uint64_t mc[NT], mn[NT];
+  loadm(0, mc);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the loop is entered with no load in flight
+  bf16x8 afc[NT], bc[3];
+  make_af(mc, 0, afc);
+  split8(xq[0], bc[0], bc[1], bc[2]);
+  const int n2 = (ns + 1) / 2;
+  for (int u = 0; u < n2; ++u) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if ((ks & 3) == 0) loadm(2 * u + (ks >> 2) + 1, mn);
+      loadx(u * KS + ks + AHEAD, xq[(ks + AHEAD) & (RING - 1)]);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 afn[NT], bn[3];
+      make_af((ks & 3) == 3 ? mn : mc, (ks + 1) & 3, afn);
+      split8(xq[(ks + 1) & (RING - 1)], bn[0], bn[1], bn[2]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[p], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) afc[t] = afn[t];
+      bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
+#pragma unroll
+      for (int i = 0; i < 3 * NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, (48 + 3 * NT - 1) / (3 * NT) + 2, 0);   // a slice of the split / expansion work
+        if (i < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one LUT read
+      }
+      if ((ks & 3) == 3) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mc[t] = mn[t];
+      }
+    }
+  }
+}
+
+template <int NA, int NB>
+__global__ __launch_bounds__(512) void k_scatter_strip2(RelPack rp, int64_t n_rows, int n_stage_total, int D, int total_pad,
+                                                        const float* __restrict__ x, float* __restrict__ slab) {
+  constexpr int NP = NA > NB ? NA : NB;                                    // tiles parked per phase
+  __shared__ __attribute__((aligned(16))) unsigned lut[256][4];            // byte -> 8 bf16 in {0, 1}
+  extern __shared__ __attribute__((aligned(16))) float st_red[];           // [4 row quarters][NP * 16][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31, w4 = wid & 3;
+  const int d0 = blockIdx.y * 32;
+  if (tid < 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
+  }
+  __syncthreads();
+  const int q_id = blockIdx.x * 4 + w4, n_q = gridDim.x * 4;
+  float* dst = slab + (size_t)blockIdx.x * total_pad * D + d0 + l31;
+  // fixed-order sum over the four row quarters of the tiles [t_first, t_first + ntp) parked in st_red: every one of the
+  // eight waves sums an eighth of the registers (quarter 0 + 1 + 2 + 3) and stores it
+  auto sum_store = [&](int t_first, int ntp) {
+    const int nreg = ntp * 16;
+    for (int idx = wid * nreg / 8; idx < (wid + 1) * nreg / 8; ++idx) {
+      float v = st_red[((size_t)0 * NP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)1 * NP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)2 * NP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)3 * NP * 16 + idx) * 64 + lane];
+      const int i = idx & 15;
+      const int vrow = (t_first + (idx >> 4)) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      dst[(size_t)vrow * D] = v;
+    }
+  };
+  if (wid < 4) {
+    f32x16 acc[NA];
+    strip_main<NA, 4, 3>(rp, n_rows, n_stage_total, D, x, lut, 0, q_id, n_q, acc);
+#pragma unroll
+    for (int t = 0; t < NA; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st_red[((size_t)w4 * NP * 16 + t * 16 + i) * 64 + lane] = acc[t][i];
+    __syncthreads();
+    sum_store(0, NA);
+    __syncthreads();                                   // the first phase's reads are done
+    __syncthreads();                                   // (the other waves parked theirs)
+    sum_store(NA, NB);
+  } else {
+    f32x16 acc[NB];
+    strip_main<NB, 4, 3>(rp, n_rows, n_stage_total, D, x, lut, NA, q_id, n_q, acc);
+    __syncthreads();
+    sum_store(0, NA);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NB; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st_red[((size_t)w4 * NP * 16 + t * 16 + i) * 64 + lane] = acc[t][i];
+    __syncthreads();
+    sum_store(NA, NB);
+  }
+}
+
+template <int NA, int NB>
+int launch_scatter_strip2(const RelPack& rp, int64_t n_rows, int D, int n_ranges, int total_pad, const float* x, float* slab,
+                          hipStream_t st) {
+  constexpr int lds = 4 * (NA > NB ? NA : NB) * 16 * 64 * 4;
+  MMG_CHECK_HIP((MmgMaxLds<&k_scatter_strip2<NA, NB>, lds>::set()), "scatter_rows(attr)");
+  const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
+  MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, total_pad, 0, (k_scatter_strip2<NA, NB>),
+             dim3((unsigned)n_ranges, (unsigned)(D / 32)), dim3(512), lds, st, rp, n_rows, nst, D, total_pad, x, slab);
+  return MMG_OK;
+}
+
 template <int NT>
 int launch_scatter_strip(const RelPack& rp, int64_t n_rows, int D, int n_ranges, int total_pad, const float* x, float* slab,
                          hipStream_t st) {
@@ -1616,7 +1794,7 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     if (rc3) return rc3;
     if (sp.nt == 4) rc2 = launch_scatter_strip<4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     else if (sp.nt == 8) rc2 = launch_scatter_strip<8>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-    else if (sp.nt == 9) rc2 = launch_scatter_strip<9>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else if (sp.nt == 9) rc2 = launch_scatter_strip2<5, 4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     else rc2 = launch_scatter_strip<10>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     if (rc2) return rc2;
     const int64_t n = (int64_t)sp.total_pad * D;
