@@ -724,6 +724,13 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:
+        # every rank idle and at the same point, the captured segments gone, before the group is torn down (a teardown
+        # with replays or watchdog-polled events still alive aborted once in a world_size-1 test)
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
         torch.distributed.destroy_process_group()
 
 
