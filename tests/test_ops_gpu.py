@@ -603,10 +603,12 @@ def test_l2norm(ops, dev, N):
 
 # ------------------------------------------------------------------------------------------ heads
 @pytest.mark.parametrize("p", [0.0, 0.2])
-@pytest.mark.parametrize("sorted_pairs", [False, True])
-def test_pair_head_fwd_bwd(ops, dev, p, sorted_pairs):
+@pytest.mark.parametrize("sorted_pairs,L", [(False, 50), (True, 50), (True, 100), (True, 200)])
+def test_pair_head_fwd_bwd(ops, dev, p, sorted_pairs, L):
+    """L = labs: up to 64 the backward is k_pair_bwd_duo (two waves per tile), up to 128 k_pair_bwd_mfma<4>, beyond that
+    the fp32 kernel with the lab table in LDS -- three kernels, one contract."""
     gen = torch.Generator().manual_seed(31)
-    P, L, n = 400, 50, 5000
+    P, n = 400, 5000
     A, B = torch.randn(P, 64, generator=gen), torch.randn(L, 64, generator=gen)
     W2, b2 = torch.randn(32, 64, generator=gen) / 8, torch.randn(32, generator=gen) * 0.1
     W3, b3 = torch.randn(32, generator=gen) / 5, torch.randn(1, generator=gen)
