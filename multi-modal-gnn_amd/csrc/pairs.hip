@@ -3,9 +3,10 @@
 // B = x_lab.W1[:, D:]^T + b1), so the per-pair work is a 64-wide gather-add + a 64x32 and a 32x1 layer.
 //
 // One launch serves ONE head over a compacted, patient-sorted list of pair positions (mmg_pair_select).
-// k_pair_fwd_mfma / k_pair_bwd_mfma: one wave per 32-pair tile on the matrix cores (the 64x32 layer as the exact
-// six-term bf16 split in the forward; four chained products in the backward, which recomputes the forward -- nothing
-// per pair is stored), node rows and indices through a software pipeline of unconditional buffer loads.
+// k_pair_fwd_mfma / k_pair_bwd_duo: one wave (forward) / a front and a back wave (backward) per 32-pair tile on the
+// matrix cores (the 64x32 layer as the exact six-term bf16 split in the forward; four chained products in the backward,
+// which recomputes the forward -- nothing per pair is stored unless the caller asks for it, mmg_pair_saved_t), node rows
+// and indices through a software pipeline of unconditional buffer loads.
 // k_pair_bwd (thread-per-pair on the vector ALUs, LDS accumulators for dB) remains for lab vocabularies > 128 rows.
 #include "common.h"
 
@@ -199,14 +200,14 @@ __global__ __launch_bounds__(PT) void k_pair_bwd(HeadDev H, HeadGradDev Gd, cons
 }
 
 // ---------------------------------------------------------------------------- backward on MFMA
-// One WAVE owns a tile of 32 pairs; every contraction of the head backward runs on the fp32 matrix
-// cores (v_mfma_f32_32x32x2_f32), the vector ALUs only do the gather-add, masks and epilogues:
+// A tile of 32 pairs; every contraction of the head backward runs on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32), the vector ALUs only do the gather-add, masks and epilogues:
 //   (1) H2pre[pair,u]   = H1[pair,:] . W2[u,:]            32 MFMA   (A = h1 rows in registers)
 //   (2) dW2[u,k]       += D2[pair,u] * H1[pair,k]          32 MFMA   (A = the C-layout of (1): no lane movement)
 //   (3) dH1[pair,k]     = D2[pair,:] . W2[:,k]             32 MFMA   (A = D2 transposed through a 4 KB LDS tile)
 //   (4) dB[lab,k]      += [li[pair]==lab] * dH1[pair,k]    12*LT bf16 MFMA (exact: one-hot x 3-way bf16 split of dH1)
-// dA[pi] is flushed with run-length pre-reduction (pairs arrive sorted by patient).  No workgroup
-// barrier anywhere: waves are independent.
+// dA[pi] is flushed with run-length pre-reduction (pairs arrive sorted by patient).  Rounds 1-2 ran all of it in ONE wave
+// per tile (k_pair_bwd_mfma: ~500 registers, one wave per SIMD); k_pair_bwd_duo below splits it between two.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
@@ -241,7 +242,6 @@ __device__ __forceinline__ f32x4 pair_ld_f4(__amdgpu_buffer_rsrc_t d, unsigned b
 }
 constexpr int LDH = 68;                // H1 / dH1 tile row stride (floats)
 constexpr int LDD = 36;                // D2 tile row stride
-constexpr int WAVE_LDS = TP * LDH + TP * LDD + 4 * TP + 2 * TP;   // floats per wave
 
 __device__ inline int crow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -280,338 +280,8 @@ __device__ __forceinline__ void layer2_fields(uint32_t key, const unsigned* PLo,
 
 __host__ __device__ constexpr int pair_slab_floats(int LT) { return 2048 + LT * 2048 + 68; }
 
-template <int LT, bool AUX>       // AUX: io_perm and / or pair_id are present (else neither is loaded)
-__global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
-                                                       const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
-                                                       int thr, int want_low, int64_t n, int n_labs, float drop_p,
-                                                       uint64_t seed, const uint64_t* __restrict__ seed_ptr,
-                                                       PairBufs pb,
-                                                       const float* __restrict__ dpred, const int32_t* __restrict__ sel,
-                                                       const int32_t* __restrict__ n_sel,
-                                                       float* __restrict__ slab) {
-  if (seed_ptr) seed = *seed_ptr;
-  // compacted pair list (device-resident length, see mmg_pair_select), never beyond the capacity the launch was sized for
-  if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }
-  __shared__ __attribute__((aligned(16))) float sm[4 * WAVE_LDS];
-  __shared__ __attribute__((aligned(16))) float W2s[32 * LDH];      // W2[u][k], row stride LDH (shared by the 4 waves)
-  __shared__ float tail_red[4][68];                                 // per wave: dW3[32] | db2[32] | db3
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int h = lane >> 5, l31 = lane & 31;
-  float* H1s = sm + wid * WAVE_LDS;                 // [32][LDH]  (later: dH1 tile)
-  float* D2s = H1s + TP * LDH;                      // [32][LDD]
-  int* PIs = reinterpret_cast<int*>(D2s + TP * LDD);   // [32] patient or -1
-  int* LIs = PIs + TP;                              // [32]
-  float* DOs = reinterpret_cast<float*>(LIs + TP);  // [32] dout (0 for inactive)
-  unsigned* PLo = reinterpret_cast<unsigned*>(DOs + TP);   // [32] pair id low / high words
-  unsigned* PHi = PLo + TP;
-  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-
-  // ---- W2 lives in LDS (its two fragment views are re-read per tile: keeps ~64 VGPRs out of the live set)
-  for (int i = tid; i < 2048; i += 256) W2s[(i >> 6) * LDH + (i & 63)] = H.W2[i];
-  __syncthreads();
-  const float b2v = H.b2[l31], w3v = H.W3[l31];
-
-  f32x16 accW2[2], accB[LT][2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    accW2[0][i] = 0.f; accW2[1][i] = 0.f;
-#pragma unroll
-    for (int t = 0; t < LT; ++t) { accB[t][0][i] = 0.f; accB[t][1][i] = 0.f; }
-  }
-  float w3acc = 0.f, b2acc = 0.f, b3acc = 0.f;
-
-  const int64_t n_tiles = (n + TP - 1) / TP;
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid, n_waves = (int64_t)gridDim.x * 4;
-  // Three-deep software pipeline over this wave's tiles, one dependent load per stage:  t+3: list position -> pair
-  // index;  t+2: pair -> patient, lab, rng id, slot of its upstream gradient;  t+1: gate degree, upstream gradient,
-  // the A / B row halves.  A stage only ISSUES loads; they are finalised (selects, clamps) one iteration later by the
-  // next stage.  Every load is unconditional and BOUNDED -- lists, index arrays, node tables and the upstream gradient
-  // go through buffer descriptors sized on the host (PairBufs; zero-sized for an absent array) -- because a branch
-  // around a load makes the compiler's vmcnt waits conservative.
-  struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
-  const __amdgpu_buffer_rsrc_t sel_d = pair_rsrc(sel ? sel : pi, sel ? (uint32_t)(n * 4) : 0u);
-  const __amdgpu_buffer_rsrc_t io_d = pair_rsrc(pb.io, pb.io_bytes), pid_d = pair_rsrc(pb.pid, pb.pid_bytes);
-  const __amdgpu_buffer_rsrc_t pi_d = pair_rsrc(pi, pb.pair_bytes), li_d = pair_rsrc(li, pb.pair_bytes);
-  const __amdgpu_buffer_rsrc_t dp_d = pair_rsrc(dpred, pb.pair_bytes), deg_d = pair_rsrc(deg, pb.pat_bytes);
-  const __amdgpu_buffer_rsrc_t A_d = pair_rsrc(H.A, pb.a_bytes), B_d = pair_rsrc(H.B, pb.b_bytes);
-  const bool has_sel = sel != nullptr, has_io = pb.io_bytes != 0u, has_pid = pb.pid_bytes != 0u;
-  struct RawMeta { int k, p, l; pu32x2 o2, d2; };
-  auto issue_k = [&](int64_t t) {                    // raw list entry of tile t (0 past the end / without a list)
-    const int64_t idx = t * TP + l31;
-    return pair_ld_i32(sel_d, (unsigned)(idx < n ? idx : 0) * 4u);
-  };
-  auto fin_k = [&](int kr, int64_t t) {
-    const int64_t idx = t * TP + l31;
-    return idx < n ? (has_sel ? kr : (int)idx) : -1;
-  };
-  auto issue_meta = [&](int k) {
-    const unsigned kc = k >= 0 ? (unsigned)k : 0u;
-    RawMeta r;
-    r.k = k;
-    r.p = pair_ld_i32(pi_d, kc * 4u);
-    r.l = pair_ld_i32(li_d, kc * 4u);
-    if (AUX) {
-      r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, (int)(kc * 8u), 0, 0);
-      r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, (int)(kc * 8u), 0, 0);
-    }
-    return r;
-  };
-  auto fin_meta = [&](const RawMeta& r) {
-    const int kc = r.k >= 0 ? r.k : 0;
-    Meta m;
-    m.k = r.k;
-    // a list entry outside the pair arrays, or a row id outside the table, is not a pair (nothing is read or written for it)
-    m.p_i = ((unsigned)r.k < (pb.pair_bytes >> 2) && (unsigned)r.p < (unsigned)pb.n_pat) ? r.p : -1;
-    m.l_i = r.l;
-    m.o = (AUX && has_io) ? (int)r.o2[0] : kc;
-    m.pid = (AUX && has_pid) ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
-    return m;
-  };
-  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
-    const unsigned pp = m.p_i >= 0 ? (unsigned)m.p_i : 0u;
-    *dg = pair_ld_i32(deg_d, pp * 4u);
-    *dv = __builtin_bit_cast(float, pair_ld_i32(dp_d, (unsigned)m.o * 4u));   // (masked when the position is past the end)
-    const unsigned ao = pp * 256u + 128u * h, bo = (unsigned)m.l_i * 256u + 128u * h;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      ra[q] = pair_ld_f4(A_d, ao + q * 16u);
-      rb[q] = pair_ld_f4(B_d, bo + q * 16u);
-    }
-  };
-  const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
-  int kr2 = issue_k(wave_id + 2 * n_waves);
-  const RawMeta rm0 = issue_meta(fin_k(kr0, wave_id));
-  RawMeta rm1 = issue_meta(fin_k(kr1, wave_id + n_waves));
-  Meta m0 = fin_meta(rm0);
-  f32x4 ra[8], rb[8];
-  int dg0; float dv0;
-  load_rows(m0, ra, rb, &dg0, &dv0);
-  for (int64_t t = wave_id; t < n_tiles; t += n_waves) {
-    const Meta mc = m0;
-    const bool active = mc.p_i >= 0 && ((int)(dg0 < thr)) == want_low;
-    const float dout = active ? dv0 : 0.f;
-    f32x4 ca[8], cb[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
-    const Meta m1 = fin_meta(rm1);               // issued one iteration ago
-    const int k2 = fin_k(kr2, t + 2 * n_waves);
-    kr2 = issue_k(t + 3 * n_waves);
-    rm1 = issue_meta(k2);
-    load_rows(m1, ra, rb, &dg0, &dv0);           // next tile's rows: in flight during this tile's MFMAs
-    __builtin_amdgcn_sched_barrier(0);           // the three stages' loads stay ahead of this tile's arithmetic
-    m0 = m1;
-    const int p_i = active ? mc.p_i : -1, l_i = mc.l_i;
-    const uint64_t pid = mc.pid;
-    if (__ballot(p_i >= 0) == 0ull) continue;    // no pair of this tile belongs to this head (wave-uniform)
-    if (h == 0) {
-      PIs[l31] = p_i; LIs[l31] = l_i; DOs[l31] = dout;
-      PLo[l31] = (unsigned)pid; PHi[l31] = (unsigned)(pid >> 32);
-      b3acc += dout;
-    }
-    // ---- (b) h1[pair=l31][k=32h+s]: gather-add, relu, dropout; kept in registers AND written to LDS
-    float h1a[32];
-    const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {                    // one aligned RNG group of 4 per q: one hash
-      f32x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(ca[q][j] + cb[q][j], 0.f);
-      if (drop_p > 0.f) mmg_drop4(v, key1, pid * 64ull + (uint64_t)(32 * h + q * 4), thr1, inv_keep);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) h1a[q * 4 + j] = v[j];
-      *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
-    }
-    // ---- (1) H2pre = H1 . W2^T
-    f32x16 acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {       // B of (1): W2[u=l31][k=32h+4q..]
-      const f32x4 w = *reinterpret_cast<const f32x4*>(W2s + l31 * LDH + 32 * h + q * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(h1a[q * 4 + j], w[j], acc1, 0, 0, 0);
-    }
-    // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
-    float d2c[16];
-    uint32_t kb[16];
-    if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PLo, PHi, h, l31, kb);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = crow(r, h);
-      const float pre = acc1[r] + b2v;
-      float m = pre > 0.f ? 1.f : 0.f;
-      float post = fmaxf(pre, 0.f);
-      if (drop_p > 0.f) {
-        const bool kp = kb[r] >= mmg_keep_threshold(drop_p);
-        m = kp ? m * inv_keep : 0.f;
-        post = kp ? post * inv_keep : 0.f;
-      }
-      const float dr = DOs[row];
-      const float d2 = dr * w3v * m;
-      d2c[r] = d2;
-      w3acc = fmaf(dr, post, w3acc);
-      b2acc += d2;
-      D2s[row * LDD + l31] = d2;
-    }
-    // ---- H1 in the column layout: h1c[s][ct] = H1[pair crow(s,h)][ct*32 + l31]
-    float h1c[16][2];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      h1c[s][0] = H1s[crow(s, h) * LDH + l31];
-      h1c[s][1] = H1s[crow(s, h) * LDH + 32 + l31];
-    }
-    // ---- (2) dW2[u,k] += D2[pair,u] * H1[pair,k]   (A = d2c: already lane=u, step s = pair crow(s,h))
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      accW2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2c[s], h1c[s][0], accW2[0], 0, 0, 0);
-      accW2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2c[s], h1c[s][1], accW2[1], 0, 0, 0);
-    }
-    // ---- (3) dH1[pair,k] = D2[pair,:] . W2[:,k]     (A = D2[pair=l31][u=16h+s] from the LDS tile)
-    float d2a[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(D2s + l31 * LDD + 16 * h + q * 4);
-      d2a[q * 4 + 0] = v[0]; d2a[q * 4 + 1] = v[1]; d2a[q * 4 + 2] = v[2]; d2a[q * 4 + 3] = v[3];
-    }
-    f32x16 accH[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { accH[0][i] = 0.f; accH[1][i] = 0.f; }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {      // B of (3): W2[u=16h+s][k=ct*32+l31]
-      const float w0 = W2s[(16 * h + s) * LDH + l31], w1 = W2s[(16 * h + s) * LDH + 32 + l31];
-      accH[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s], w0, accH[0], 0, 0, 0);
-      accH[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d2a[s], w1, accH[1], 0, 0, 0);
-    }
-    // through dropout+relu of layer 1 (h1 > 0 <=> kept and positive); C layout: lane = column, reg = pair row
-    float dh[16][2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dh[r][0] = h1c[r][0] > 0.f ? accH[0][r] * inv_keep : 0.f;
-      dh[r][1] = h1c[r][1] > 0.f ? accH[1][r] * inv_keep : 0.f;
-    }
-    // ---- (4) dB[lab,k] += onehot(li[pair])[lab] * dH1[pair,k] on the bf16 matrix cores: the one-hot is exact
-    //      in bf16 and dH1 splits exactly into three bf16 pieces, so the products are exact and the fp32
-    //      accumulation matches the fp32 path up to order -- at 1/5 of its matrix time.  k index of step t,
-    //      lane half h, element j  <->  pair row crow(8t + j, h): exactly the C-layout registers 8t..8t+7.
-#pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2) {
-      pbf16x8 bp[2][3];
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = dh[8 * t2 + j][ct];
-          const __bf16 a = (__bf16)v;
-          const float r1 = v - (float)a;
-          const __bf16 b = (__bf16)r1;
-          bp[ct][0][j] = a; bp[ct][1][j] = b; bp[ct][2][j] = (__bf16)(r1 - (float)b);
-        }
-      int labs[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) labs[j] = LIs[crow(8 * t2 + j, h)];
-#pragma unroll
-      for (int lt = 0; lt < LT; ++lt) {
-        pbf16x8 oh;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) oh[j] = (labs[j] == lt * 32 + l31) ? (__bf16)1.0f : (__bf16)0.0f;
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int p = 0; p < 3; ++p)
-            accB[lt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, bp[ct][p], accB[lt][ct], 0, 0, 0);
-      }
-    }
-    // ---- dA[pi] += dH1: tile to LDS (aliases H1s: all H1 reads are done), then run-length flush
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      H1s[crow(r, h) * LDH + l31] = dh[r][0];
-      H1s[crow(r, h) * LDH + 32 + l31] = dh[r][1];
-    }
-    {   // patient ids come from registers (readlane), the 32 tile rows are read from LDS in two batches
-      float run = 0.f;
-      int cur = -1;
-#pragma unroll
-      for (int bq = 0; bq < 2; ++bq) {
-        float vq[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) vq[q] = H1s[(bq * 16 + q) * LDH + lane];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int pp = __builtin_amdgcn_readlane(p_i, bq * 16 + q);
-          if (pp < 0) continue;
-          if (pp != cur) {
-            if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
-            cur = pp; run = 0.f;
-          }
-          run += vq[q];
-        }
-      }
-      if (cur >= 0) atomicAdd(Gd.dA + (size_t)cur * 64 + lane, run);
-    }
-  }
-  // ---- final flush: the four waves' accumulators are summed through LDS first (one workgroup = one set of global
-  //      atomics: every dW2 / dB address is hit once per workgroup, not once per wave)
-  __syncthreads();                                   // every wave is done with its tile buffers in `sm`
-  float* red = sm;                                   // [(2 + 2 LT) x 16 regs][64 lanes], the waves add in turn
-  constexpr int NR = (2 + 2 * LT) * 16;
-  static_assert(NR * 64 <= 4 * WAVE_LDS, "reduction tile must fit the per-wave buffers");
-  for (int w = 0; w < 4; ++w) {
-    if (wid == w) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if (w == 0) {
-          red[r * 64 + lane] = accW2[0][r];
-          red[(16 + r) * 64 + lane] = accW2[1][r];
-#pragma unroll
-          for (int lt = 0; lt < LT; ++lt) {
-            red[(32 + lt * 32 + r) * 64 + lane] = accB[lt][0][r];
-            red[(48 + lt * 32 + r) * 64 + lane] = accB[lt][1][r];
-          }
-        } else {
-          red[r * 64 + lane] += accW2[0][r];
-          red[(16 + r) * 64 + lane] += accW2[1][r];
-#pragma unroll
-          for (int lt = 0; lt < LT; ++lt) {
-            red[(32 + lt * 32 + r) * 64 + lane] += accB[lt][0][r];
-            red[(48 + lt * 32 + r) * 64 + lane] += accB[lt][1][r];
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // One partial slab per workgroup, summed over the workgroups in FIXED order by mmg_k_reduce_slabs (global float
-  // atomics here made the weight gradients depend on the order in which the workgroups finished):
-  //   [0, 2048) dW2[u][k] | [2048, 2048 + LT * 2048) dB[lab][k] | db2[32] | dW3[32] | db3, padded to 68
-  float* my = slab + (size_t)blockIdx.x * pair_slab_floats(LT);
-  for (int e = tid; e < NR * 64; e += 256) {         // element e = (slot, lane'): slot = which accumulator register
-    const int slot = e >> 6, ln = e & 63;
-    const float v = red[e];
-    const int hh = ln >> 5, c31 = ln & 31;
-    if (slot < 32) {                                 // dW2: slot = ct * 16 + r
-      const int ct = slot >> 4, r = slot & 15;
-      my[crow(r, hh) * 64 + ct * 32 + c31] = v;
-    } else {                                         // dB: slot - 32 = lt * 32 + ct * 16 + r
-      const int q = slot - 32, lt = q >> 5, ct = (q >> 4) & 1, r = q & 15;
-      my[2048 + (lt * 32 + crow(r, hh)) * 64 + ct * 32 + c31] = v;
-    }
-  }
-  w3acc += __shfl_xor(w3acc, 32, 64);
-  b2acc += __shfl_xor(b2acc, 32, 64);
-  b3acc = wave_sum(b3acc);
-  if (lane < 32) { tail_red[wid][lane] = w3acc; tail_red[wid][32 + lane] = b2acc; }
-  if (lane == 0) tail_red[wid][64] = b3acc;
-  __syncthreads();
-  if (tid < 68) {
-    const float t = tid < 65 ? ((tail_red[0][tid] + tail_red[1][tid]) + tail_red[2][tid]) + tail_red[3][tid] : 0.f;
-    // slab order: db2 | dW3 | db3  (tail_red holds dW3 first)
-    const int dst = tid < 32 ? 32 + tid : (tid < 64 ? tid - 32 : tid);
-    my[2048 + LT * 2048 + dst] = t;
-  }
-}
-
 // ---------------------------------------------------------------------------- backward on MFMA, two waves per tile
-// k_pair_bwd_mfma above needs ~500 registers per wave: ONE wave per SIMD, so nothing issues while its fp32 matrix
+// One wave per tile needs ~500 registers: ONE wave per SIMD, so nothing issues while its fp32 matrix
 // instructions run and its matrix pipe idles through every vector phase (measured: 35 % matrix-busy, the rest gather-add,
 // RNG, masks, splits, LDS round trips, the run-length flush).  Here a tile is worked on by TWO waves of the same SIMD in
 // turn, each under 256 registers:
@@ -621,8 +291,8 @@ __global__ __launch_bounds__(256) void k_pair_bwd_mfma(HeadDev H, HeadGradDev Gd
 // the flush behind: about even.)  The front hands H1, D2 and the tile's patient / lab ids to its back wave through
 // double-buffered LDS tiles; ONE workgroup barrier per tile orders both buffers: the front of tile t + 1 runs beside the
 // back of tile t, one wave's vector instructions issue under the other's matrix instructions.  Same arithmetic, same
-// summation order per wave and the same slab layout as k_pair_bwd_mfma (dW2 and the three bias-like sums accumulate in
-// the front waves, dB in the back waves).
+// summation order per wave and the same slab layout as the one-wave kernel had (dW2 and the three bias-like sums
+// accumulate in the front waves, dB in the back waves).
 constexpr int HAND_LDS = TP * LDH + TP * LDD;      // floats per hand-off buffer: H1 [32][LDH] | D2 [32][LDD]
 constexpr int FRONT_LDS = 3 * TP + TP * LDD;       // floats private to a front wave: dout | pair id lo | hi | saved h2 tile
 
@@ -651,7 +321,10 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
 #pragma unroll
   for (int i = 0; i < 16; ++i) { accW2[0][i] = 0.f; accW2[1][i] = 0.f; }
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + w, n_waves = (int64_t)gridDim.x * 4;
-  // the three-deep load pipeline of k_pair_bwd_mfma (every load unconditional and bounded by a host-sized descriptor)
+  // Three-deep software pipeline over this wave's tiles, one dependent load per stage:  t+3: list position -> pair
+  // index;  t+2: pair -> patient, lab, rng id, slot of its upstream gradient;  t+1: gate degree, upstream gradient, the
+  // A / B row halves.  A stage only ISSUES loads; they are finalised one iteration later.  Every load is unconditional and
+  // BOUNDED by a host-sized descriptor (a branch around a load makes the compiler's vmcnt waits conservative).
   struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
   const __amdgpu_buffer_rsrc_t sel_d = pair_rsrc(sel ? sel : pi, sel ? (uint32_t)(n * 4) : 0u);
   const __amdgpu_buffer_rsrc_t io_d = pair_rsrc(pb.io, pb.io_bytes), pid_d = pair_rsrc(pb.pid, pb.pid_bytes);
@@ -896,7 +569,9 @@ __device__ __forceinline__ void pair_bwd_back(float* __restrict__ dA, float drop
           dh[r][1] = c1 > 0.f ? accH[1][r] * inv_keep : 0.f;
         }
         // ---- (4) dB[lab,k] += onehot(li[pair])[lab] * dH1[pair,k] on the bf16 matrix cores (exact products: see
-        //      k_pair_bwd_mfma); k index of step t2, lane half h, element j  <->  pair row crow(8 t2 + j, h)
+        //      below); k index of step t2, lane half h, element j  <->  pair row crow(8 t2 + j, h): exactly the C-layout
+        //      registers 8 t2 .. 8 t2 + 7.  The one-hot is exact in bf16 and dH1 splits exactly into three bf16 pieces, so the
+        //      products are exact and the fp32 accumulation matches the fp32 path up to order -- at 1/5 of its matrix time.
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
           pbf16x8 bp[2][3];
@@ -1528,8 +1203,7 @@ extern "C" int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_gr
     if (g < 1) g = 1;
     MMG_CHECK_ARG(ws && ws_bytes >= mmg_pair_head_bwd_ws_bytes(n_pairs, n_labs), "pair_head_bwd: workspace too small");
     float* slab = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    // up to 64 labs: a front and a back wave per tile (k_pair_bwd_duo); beyond (four lab tiles of dB accumulators: 128
-    // registers more in the back wave) the one-wave-per-tile kernel
+    // a front and a back wave per 32-pair tile (k_pair_bwd_duo), two or four lab tiles of dB accumulators
 #define MMG_LAUNCH_PBWD(KERNEL_, NT_, ...)                                                                            \
   MMG_LAUNCH(MMG_PROBE_PAIR_BWD, n_pairs, 0, 0, want_low ? 2 : 0, KERNEL_, dim3((unsigned)g),                          \
              dim3(NT_), 0, st, H, G, pi, li, deg, degree_threshold, want_low ? 1 : 0, n_pairs, n_labs, drop_p, seed,     \
@@ -1545,7 +1219,10 @@ extern "C" int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_gr
         if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, true, false>), 512, svb, svh);
         else MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, false, false>), 512, svb, svh);
       }
-    } else { if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_mfma<4, true>), 256); else MMG_LAUNCH_PBWD((k_pair_bwd_mfma<4, false>), 256); }
+    } else {                                   // 65 .. 128 labs: four lab tiles of dB in the back wave (the saved state is not used)
+      if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<4, true, false>), 512, svb, svh);
+      else MMG_LAUNCH_PBWD((k_pair_bwd_duo<4, false, false>), 512, svb, svh);
+    }
 #undef MMG_LAUNCH_PBWD
     const int LT = n_labs <= 64 ? 2 : 4;
     const int64_t n4 = pair_slab_floats(LT) / 4;
