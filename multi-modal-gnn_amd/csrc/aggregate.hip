@@ -1639,8 +1639,8 @@ static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_ro
         MMG_CHECK_LAUNCH("gather_rows(bits)");
         return mmg_next_bn_finish(next, nb_partial, D, g, stream);
       }
-      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<4, 4, 4, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
-      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<4, 4, 4, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
+      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<4, 4, 4, true, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
+      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<4, 4, 4, false, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
       MMG_CHECK_LAUNCH("gather_rows(bits)");
       if (next) return mmg_next_bn_fallback(out, n_rows, D, next, "gather_rows_next_bn", stream);
       if (col_sums) return mmg_partial_sum_bn(partial, col_sums, D, g, fin, stream);
@@ -1658,8 +1658,8 @@ static int gather_rows_stats_impl(const mmg_rel_t* rels, int n_rel, int64_t n_ro
         MMG_CHECK_LAUNCH("gather_rows(bits)");
         return mmg_next_bn_finish(next, nb_partial, D, g, stream);
       }
-      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<20, 4, 12, true>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
-      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<20, 4, 12, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
+      if (accumulate) MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 1, (k_gather_bits<20, 4, 12, true, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
+      else MMG_LAUNCH(MMG_PROBE_GATHER, n_rows, D, total_cols, 0, (k_gather_bits<20, 4, 12, false, false>), grid, dim3(512), 0, st, rp, n_rows, n_tiles, D, out, partial, next_bn_none());
       MMG_CHECK_LAUNCH("gather_rows(bits)");
       if (next) return mmg_next_bn_fallback(out, n_rows, D, next, "gather_rows_next_bn", stream);
       if (col_sums) return mmg_partial_sum_bn(partial, col_sums, D, g, fin, stream);
