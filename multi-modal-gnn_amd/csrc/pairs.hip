@@ -706,6 +706,452 @@ __global__ __launch_bounds__(512) void k_pair_bwd_duo(HeadDev H, HeadGradDev Gd,
   }
 }
 
+// ---------------------------------------------------------------------------- backward, all contractions on the bf16 pipe
+// The fp32 matrix instruction (v_mfma_f32_32x32x2_f32) shares the vector ALU's multipliers: while one runs, NO wave of
+// the SIMD issues vector work, so the 96 of them per tile in k_pair_bwd_duo (6,144 cycles) simply ADD to the vector time
+// of both waves -- measured: front alone 151 us, back alone 116 us, both 193 us; raising the matrix wave's priority
+// (s_setprio) changes nothing.  The bf16 matrix pipe runs BESIDE the vector ALU.  Here (1), (2) and (3) use the exact
+// six-term bf16 split of gemm.hip (fp32-grade: the three pieces of an fp32 value are exact, six of the nine cross terms
+// are kept, fp32 accumulation), 24 matrix instructions of 32 cycles each instead of 32 of 64, and what the split costs in
+// vector instructions issues in their shadow or in the other wave's:
+//   front wave: load pipeline, h1 -> its three bf16 pieces (registers: A of (1); row-major LDS planes: B of (2) through
+//               the transposing LDS read), (1) H2pre = H1 . W2^T in the FORWARD's own term order (the recomputed
+//               pre-activation is the forward's bit for bit), layer-2 epilogue -> D2 (registers: A of (2); fp32 tile for the
+//               back wave), (2) dW2 += D2^T . H1, the sign bits of h1 (64 per pair) for the back wave
+//   back wave : (3) dH1 = D2 . W2 (A = D2 rows from the tile, split here; B = W2^T pieces held in registers), the layer-1
+//               mask from the sign bits, (4) dB, the run-length flush of dA
+// Hand-off per tile: D2 [32][36] fp32 + 2 words of sign bits + the patient / lab ids, double-buffered, one workgroup
+// barrier per tile.  K index of a k-step of (2) and (4): lane half h, element j <-> pair row crow(8 t + j, h), i.e. the
+// C-layout registers 8 t .. 8 t + 7 (A from registers) and two transposing reads at rows 16 t + 4 h and 16 t + 8 + 4 h (B).
+constexpr int P1S = 80;                              // row stride of an h1 plane (bf16): 160 B, the 4 rows of a transposing
+                                                     // read land on 4 disjoint 8-dword bank spans
+constexpr int F6_LDS = 3 * TP * 4 + 3 * TP * P1S * 2;    // bytes private to a front wave: dout | pair id lo | hi | 3 planes
+constexpr int B6_LDS = TP * LDH * 4;                 // bytes private to a back wave: the dH1 tile of the flush
+constexpr int H6_LDS = TP * LDD * 4 + TP * 2 * 4;    // bytes per hand-off buffer: D2 tile | sign bits
+
+__device__ __forceinline__ void psplit8(const float* v, pbf16x8& p0, pbf16x8& p1, pbf16x8& p2) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 a = (__bf16)v[j];
+    const float r1 = v[j] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    p0[j] = a; p1[j] = b; p2[j] = (__bf16)(r1 - (float)b);
+  }
+}
+// six exact products, small terms first (the order of k_pair_fwd_mfma and gemm.hip)
+#define MMG_X6(acc, a, b)                                                     \
+  do {                                                                        \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);  \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);  \
+  } while (0)
+
+typedef short ps16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pbf16x8 tr_pair(const __bf16* p_lo, const __bf16* p_hi) {   // 4 + 4 rows of this lane's column
+  const ps16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4*)p_lo);
+  const ps16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4*)p_hi);
+  typedef short ps16x8 __attribute__((ext_vector_type(8)));
+  const ps16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(pbf16x8, v);
+}
+
+template <int LT, bool AUX>
+__device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t* __restrict__ pi, const int32_t* __restrict__ li,
+                                                const int32_t* __restrict__ deg, int thr, int want_low, int64_t n, float drop_p,
+                                                uint64_t seed, const PairBufs& pb, const float* __restrict__ dpred,
+                                                const int32_t* __restrict__ sel, int n_iter, unsigned char* fl,
+                                                unsigned char (*HX)[4][H6_LDS], int (*XP)[4][TP], int (*XL)[4][TP],
+                                                float (*tail_red)[68], float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
+  const int h = lane >> 5, l31 = lane & 31;
+  float* DOs = reinterpret_cast<float*>(fl);        // [32] dout (0 for inactive)
+  unsigned* PLo = reinterpret_cast<unsigned*>(DOs + TP);
+  unsigned* PHi = PLo + TP;
+  __bf16* P1 = reinterpret_cast<__bf16*>(PHi + TP);  // [3][32][P1S] the pieces of h1, row-major
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t thr_keep = mmg_keep_threshold(drop_p);
+  const uint32_t key1 = mmg_rng_key(seed, SITE_H1);
+  const float b2v = H.b2[l31], w3v = H.W3[l31];
+  // B of (1): W2[unit = l31][k = 16 ks + 8 h + j] as three exact bf16 pieces
+  pbf16x8 w2p[4][3];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = H.W2[l31 * 64 + 16 * ks + 8 * h + j];
+    psplit8(v, w2p[ks][0], w2p[ks][1], w2p[ks][2]);
+  }
+  float w3acc = 0.f, b2acc = 0.f, b3acc = 0.f;
+  f32x16 accW2[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { accW2[0][i] = 0.f; accW2[1][i] = 0.f; }
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + w, n_waves = (int64_t)gridDim.x * 4;
+  // the three-deep load pipeline of k_pair_bwd_duo; the row halves in the FORWARD's order: register q of a lane holds
+  // k = 16 (q >> 1) + 8 h + 4 (q & 1) + 0..3, so that a k-step's eight values are lane-local
+  struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
+  const __amdgpu_buffer_rsrc_t sel_d = pair_rsrc(sel ? sel : pi, sel ? (uint32_t)(n * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t io_d = pair_rsrc(pb.io, pb.io_bytes), pid_d = pair_rsrc(pb.pid, pb.pid_bytes);
+  const __amdgpu_buffer_rsrc_t pi_d = pair_rsrc(pi, pb.pair_bytes), li_d = pair_rsrc(li, pb.pair_bytes);
+  const __amdgpu_buffer_rsrc_t dp_d = pair_rsrc(dpred, pb.pair_bytes), deg_d = pair_rsrc(deg, pb.pat_bytes);
+  const __amdgpu_buffer_rsrc_t A_d = pair_rsrc(H.A, pb.a_bytes), B_d = pair_rsrc(H.B, pb.b_bytes);
+  const bool has_sel = sel != nullptr, has_io = pb.io_bytes != 0u, has_pid = pb.pid_bytes != 0u;
+  struct RawMeta { int k, p, l; pu32x2 o2, d2; };
+  auto issue_k = [&](int64_t t) {
+    const int64_t idx = t * TP + l31;
+    return pair_ld_i32(sel_d, (unsigned)(idx < n ? idx : 0) * 4u);
+  };
+  auto fin_k = [&](int kr, int64_t t) {
+    const int64_t idx = t * TP + l31;
+    return idx < n ? (has_sel ? kr : (int)idx) : -1;
+  };
+  auto issue_meta = [&](int k) {
+    const unsigned kc = k >= 0 ? (unsigned)k : 0u;
+    RawMeta r;
+    r.k = k;
+    r.p = pair_ld_i32(pi_d, kc * 4u);
+    r.l = pair_ld_i32(li_d, kc * 4u);
+    if (AUX) {
+      r.o2 = __builtin_amdgcn_raw_buffer_load_b64(io_d, (int)(kc * 8u), 0, 0);
+      r.d2 = __builtin_amdgcn_raw_buffer_load_b64(pid_d, (int)(kc * 8u), 0, 0);
+    }
+    return r;
+  };
+  auto fin_meta = [&](const RawMeta& r) {
+    const int kc = r.k >= 0 ? r.k : 0;
+    Meta m;
+    m.k = r.k;
+    m.p_i = ((unsigned)r.k < (pb.pair_bytes >> 2) && (unsigned)r.p < (unsigned)pb.n_pat) ? r.p : -1;
+    m.l_i = r.l;
+    m.o = (AUX && has_io) ? (int)r.o2[0] : kc;
+    m.pid = (AUX && has_pid) ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
+    return m;
+  };
+  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
+    const unsigned pp = m.p_i >= 0 ? (unsigned)m.p_i : 0u;
+    *dg = pair_ld_i32(deg_d, pp * 4u);
+    *dv = __builtin_bit_cast(float, pair_ld_i32(dp_d, (unsigned)m.o * 4u));
+    const unsigned ao = pp * 256u + 32u * h, bo = (unsigned)m.l_i * 256u + 32u * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      ra[q] = pair_ld_f4(A_d, ao + (q >> 1) * 64u + (q & 1) * 16u);
+      rb[q] = pair_ld_f4(B_d, bo + (q >> 1) * 64u + (q & 1) * 16u);
+    }
+  };
+  // transposing-read lane roles (see k_linear_wgrad_x6): group g = lane >> 4 supplies row q of columns 16 (g & 1) + 4 p
+  const int trq = (lane >> 2) & 3, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
+  int kr2 = issue_k(wave_id + 2 * n_waves);
+  const RawMeta rm0 = issue_meta(fin_k(kr0, wave_id));
+  RawMeta rm1 = issue_meta(fin_k(kr1, wave_id + n_waves));
+  Meta m0 = fin_meta(rm0);
+  f32x4 ra[8], rb[8];
+  int dg0; float dv0;
+  load_rows(m0, ra, rb, &dg0, &dv0);
+  for (int it = 0; it <= n_iter; ++it) {
+    const int par = it & 1;
+    if (it < n_iter) {
+      const int64_t t = wave_id + (int64_t)it * n_waves;
+      float* D2s = reinterpret_cast<float*>(HX[par][w]);                 // [32][LDD]
+      unsigned* XB = reinterpret_cast<unsigned*>(D2s + TP * LDD);         // [32][2] sign bits of h1
+      const Meta mc = m0;
+      const bool active = mc.p_i >= 0 && ((int)(dg0 < thr)) == want_low;
+      const float dout = active ? dv0 : 0.f;
+      const Meta m1 = fin_meta(rm1);
+      const int k2 = fin_k(kr2, t + 2 * n_waves);
+      kr2 = issue_k(t + 3 * n_waves);
+      rm1 = issue_meta(k2);
+      m0 = m1;
+      const int p_i = active ? mc.p_i : -1, l_i = mc.l_i;
+      const uint64_t pid = mc.pid;
+      if (h == 0) { XP[par][w][l31] = p_i; XL[par][w][l31] = l_i; }     // (an all -1 patient list = nothing to do for the back wave)
+      const bool any = __ballot(p_i >= 0) != 0ull;                      // wave-uniform
+      f32x16 acc1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+      if (any) {
+        if (h == 0) {
+          DOs[l31] = dout;
+          PLo[l31] = (unsigned)pid; PHi[l31] = (unsigned)(pid >> 32);
+          b3acc += dout;
+        }
+        // ---- h1 (gather-add, relu, dropout), k-step by k-step: pieces -> (1) and the planes, sign bits
+        uint32_t bw[2] = {0u, 0u};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          float x8[8];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {                // one aligned RNG group of 4 per chunk: one hash
+            f32x4 x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = fmaxf(ra[2 * ks + c][j] + rb[2 * ks + c][j], 0.f);
+            if (drop_p > 0.f) mmg_drop4(x, key1, pid * 64ull + (uint64_t)(16 * ks + 8 * h + 4 * c), thr_keep, inv_keep);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x8[4 * c + j] = x[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bw[ks >> 1] |= x8[j] > 0.f ? (1u << (16 * (ks & 1) + j)) << (8 * h) : 0u;
+          pbf16x8 xp[3];
+          psplit8(x8, xp[0], xp[1], xp[2]);
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            *reinterpret_cast<pbf16x8*>(P1 + (pc * TP + l31) * P1S + 16 * ks + 8 * h) = xp[pc];
+          // (1) C[pair rows, unit] = H1 . W2^T: the forward's six products in the forward's order (operands swapped)
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][2], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[2], w2p[ks][0], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[1], w2p[ks][1], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][1], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[1], w2p[ks][0], acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][0], acc1, 0, 0, 0);
+        }
+        bw[0] |= (uint32_t)__shfl_xor((int)bw[0], 32, 64);
+        bw[1] |= (uint32_t)__shfl_xor((int)bw[1], 32, 64);
+        if (h == 0) *reinterpret_cast<pu32x2*>(XB + 2 * l31) = pu32x2{bw[0], bw[1]};
+      }
+      // the row registers are consumed: the next tile's rows are requested now and have the rest of this tile to arrive
+      __builtin_amdgcn_sched_barrier(0);
+      load_rows(m1, ra, rb, &dg0, &dv0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (any) {
+        // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
+        float d2c[16];
+        uint32_t kb[16];
+        if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PLo, PHi, h, l31, kb);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = crow(r, h);
+          const float pre = acc1[r] + b2v;
+          float m = pre > 0.f ? 1.f : 0.f;
+          float post = fmaxf(pre, 0.f);
+          if (drop_p > 0.f) {
+            const bool kp = kb[r] >= thr_keep;
+            m = kp ? m * inv_keep : 0.f;
+            post = kp ? post * inv_keep : 0.f;
+          }
+          const float dr = DOs[row];
+          const float d2 = dr * w3v * m;
+          d2c[r] = d2;
+          w3acc = fmaf(dr, post, w3acc);
+          b2acc += d2;
+          D2s[row * LDD + l31] = d2;
+        }
+        // ---- (2) dW2[u,k] += D2[pair,u] * H1[pair,k]: A = d2c pieces (lane = u), B = h1 pieces of column ct * 32 + l31
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          pbf16x8 ap[3];
+          psplit8(d2c + 8 * t2, ap[0], ap[1], ap[2]);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            pbf16x8 bp[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+              const __bf16* base = P1 + (pc * TP + 16 * t2 + 4 * h + trq) * P1S + ct * 32 + trc;
+              bp[pc] = tr_pair(base, base + 8 * P1S);
+            }
+            MMG_X6(accW2[ct], ap, bp);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- final flush, front half: the four front waves' dW2 summed through LDS in wave order (the back waves add their dB
+  //      slots in the same four rounds); every wave passed the last barrier of the loop
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (ww == 0) { red[r * 64 + lane] = accW2[0][r]; red[(16 + r) * 64 + lane] = accW2[1][r]; }
+        else { red[r * 64 + lane] += accW2[0][r]; red[(16 + r) * 64 + lane] += accW2[1][r]; }
+      }
+    }
+    __syncthreads();
+  }
+  w3acc += __shfl_xor(w3acc, 32, 64);
+  b2acc += __shfl_xor(b2acc, 32, 64);
+  b3acc = wave_sum(b3acc);
+  if (lane < 32) { tail_red[w][lane] = w3acc; tail_red[w][32 + lane] = b2acc; }
+  if (lane == 0) tail_red[w][64] = b3acc;
+}
+
+template <int LT>
+__device__ __forceinline__ void pair_bwd6_back(const HeadDev& H, float* __restrict__ dA, float drop_p, int n_iter,
+                                               unsigned char* bl, unsigned char (*HX)[4][H6_LDS], int (*XP)[4][TP],
+                                               int (*XL)[4][TP], float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
+  const int h = lane >> 5, l31 = lane & 31;
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  float* T = reinterpret_cast<float*>(bl);          // [32][LDH] the dH1 tile of the flush
+  // B of (3): W2[u = 16 kq + 8 h + j][k = ct * 32 + l31] as three exact bf16 pieces
+  pbf16x8 w2t[2][2][3];
+#pragma unroll
+  for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = H.W2[(16 * kq + 8 * h + j) * 64 + ct * 32 + l31];
+      psplit8(v, w2t[kq][ct][0], w2t[kq][ct][1], w2t[kq][ct][2]);
+    }
+  f32x16 accB[LT][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int t = 0; t < LT; ++t) { accB[t][0][i] = 0.f; accB[t][1][i] = 0.f; }
+  for (int it = 0; it <= n_iter; ++it) {
+    if (it >= 1) {
+      const int par = (it - 1) & 1;
+      const int p_i = XP[par][w][l31];
+      if (__ballot(p_i >= 0) != 0ull) {
+        const float* D2s = reinterpret_cast<const float*>(HX[par][w]);    // [32][LDD]
+        const unsigned* XB = reinterpret_cast<const unsigned*>(D2s + TP * LDD);
+        // ---- (3) dH1[pair,k] = D2[pair,:] . W2[:,k]: A = the pair's D2 row (u = 16 kq + 8 h + j), split here
+        f32x16 accH[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accH[0][i] = 0.f; accH[1][i] = 0.f; }
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(D2s + l31 * LDD + 16 * kq + 8 * h);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(D2s + l31 * LDD + 16 * kq + 8 * h + 4);
+          const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          pbf16x8 ap[3];
+          psplit8(v, ap[0], ap[1], ap[2]);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) MMG_X6(accH[ct], ap, w2t[kq][ct]);
+        }
+        // through dropout + relu of layer 1: the sign bit of h1[pair crow(r,h)][ct * 32 + l31]
+        float dh[16][2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const pu32x2 bwv = *reinterpret_cast<const pu32x2*>(XB + 2 * crow(r, h));
+          dh[r][0] = (bwv[0] >> l31) & 1u ? accH[0][r] * inv_keep : 0.f;
+          dh[r][1] = (bwv[1] >> l31) & 1u ? accH[1][r] * inv_keep : 0.f;
+        }
+        // ---- (4) dB[lab,k] += onehot(li[pair])[lab] * dH1[pair,k] (exact: one-hot x three bf16 pieces of dH1)
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          pbf16x8 bp[2][3];
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = dh[8 * t2 + j][ct];
+            psplit8(v, bp[ct][0], bp[ct][1], bp[ct][2]);
+          }
+          int labs[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) labs[j] = XL[par][w][crow(8 * t2 + j, h)];
+#pragma unroll
+          for (int lt = 0; lt < LT; ++lt) {
+            pbf16x8 oh;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oh[j] = (labs[j] == lt * 32 + l31) ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+              for (int p = 0; p < 3; ++p)
+                accB[lt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, bp[ct][p], accB[lt][ct], 0, 0, 0);
+          }
+        }
+        // ---- dA[pi] += dH1: tile to this wave's LDS, then run-length flush (pairs arrive sorted by patient)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          T[crow(r, h) * LDH + l31] = dh[r][0];
+          T[crow(r, h) * LDH + 32 + l31] = dh[r][1];
+        }
+        {
+          float run = 0.f;
+          int cur = -1;
+#pragma unroll
+          for (int bq = 0; bq < 2; ++bq) {
+            float vq[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vq[q] = T[(bq * 16 + q) * LDH + lane];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int pp = __builtin_amdgcn_readlane(p_i, bq * 16 + q);
+              if (pp < 0) continue;
+              if (pp != cur) {
+                if (cur >= 0) atomicAdd(dA + (size_t)cur * 64 + lane, run);
+                cur = pp; run = 0.f;
+              }
+              run += vq[q];
+            }
+          }
+          if (cur >= 0) atomicAdd(dA + (size_t)cur * 64 + lane, run);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int ww = 0; ww < 4; ++ww) {
+    if (w == ww) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int lt = 0; lt < LT; ++lt) {
+          if (ww == 0) {
+            red[(32 + lt * 32 + r) * 64 + lane] = accB[lt][0][r];
+            red[(48 + lt * 32 + r) * 64 + lane] = accB[lt][1][r];
+          } else {
+            red[(32 + lt * 32 + r) * 64 + lane] += accB[lt][0][r];
+            red[(48 + lt * 32 + r) * 64 + lane] += accB[lt][1][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int LT, bool AUX>
+__global__ __launch_bounds__(512) void k_pair_bwd_duo6(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
+                                                       const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
+                                                       int thr, int want_low, int64_t n, int n_labs, float drop_p,
+                                                       uint64_t seed, const uint64_t* __restrict__ seed_ptr, PairBufs pb,
+                                                       const float* __restrict__ dpred, const int32_t* __restrict__ sel,
+                                                       const int32_t* __restrict__ n_sel, float* __restrict__ slab) {
+  if (seed_ptr) seed = *seed_ptr;
+  if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }
+  __shared__ __attribute__((aligned(16))) unsigned char smf[4][F6_LDS];      // front-private (later: the reduction tile)
+  __shared__ __attribute__((aligned(16))) unsigned char smb[4][B6_LDS];      // back-private
+  __shared__ __attribute__((aligned(16))) unsigned char HX[2][4][H6_LDS];    // hand-off: [buffer][wave pair]
+  __shared__ int XP[2][4][TP], XL[2][4][TP];
+  __shared__ float tail_red[4][68];
+  const int tid = threadIdx.x, wid = tid >> 6;
+  const int64_t n_tiles = (n + TP - 1) / TP, n_waves = (int64_t)gridDim.x * 4, first = (int64_t)blockIdx.x * 4;
+  const int n_iter = first < n_tiles ? (int)((n_tiles - first + n_waves - 1) / n_waves) : 0;
+  float* red = reinterpret_cast<float*>(&smf[0][0]);
+  constexpr int NR = (2 + 2 * LT) * 16;
+  static_assert(NR * 64 * 4 <= 4 * F6_LDS, "reduction tile must fit the front waves' buffers");
+  if (wid < 4)
+    pair_bwd6_front<LT, AUX>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter, smf[wid & 3], HX, XP, XL,
+                             tail_red, red);
+  else
+    pair_bwd6_back<LT>(H, Gd.dA, drop_p, n_iter, smb[wid & 3], HX, XP, XL, red);
+  float* my = slab + (size_t)blockIdx.x * pair_slab_floats(LT);
+  for (int e = tid; e < NR * 64; e += 512) {
+    const int slot = e >> 6, ln = e & 63;
+    const float v = red[e];
+    const int hh = ln >> 5, c31 = ln & 31;
+    if (slot < 32) {
+      const int ct = slot >> 4, r = slot & 15;
+      my[crow(r, hh) * 64 + ct * 32 + c31] = v;
+    } else {
+      const int q = slot - 32, lt = q >> 5, ct = (q >> 4) & 1, r = q & 15;
+      my[2048 + (lt * 32 + crow(r, hh)) * 64 + ct * 32 + c31] = v;
+    }
+  }
+  __syncthreads();                                   // the front waves' tail sums are in tail_red
+  if (tid < 68) {
+    const float t = tid < 65 ? ((tail_red[0][tid] + tail_red[1][tid]) + tail_red[2][tid]) + tail_red[3][tid] : 0.f;
+    const int dst = tid < 32 ? 32 + tid : (tid < 64 ? tid - 32 : tid);
+    my[2048 + LT * 2048 + dst] = t;
+  }
+}
+
 // adds the summed slab into the caller's gradient buffers (single writer per element: plain read-modify-write)
 struct EpiPairFlush {
   float *dW2, *dB, *db2, *dW3, *db3;
@@ -1216,8 +1662,8 @@ extern "C" int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_gr
         if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, true, true>), 512, svb, svh);
         else MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, false, true>), 512, svb, svh);
       } else {
-        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, true, false>), 512, svb, svh);
-        else MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, false, false>), 512, svb, svh);
+        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true>), 512);
+        else MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, false>), 512);
       }
     } else {                                   // 65 .. 128 labs: four lab tiles of dB in the back wave (the saved state is not used)
       if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<4, true, false>), 512, svb, svh);

@@ -309,9 +309,10 @@ def test_heads_on_the_supervised_pairs_only_change_nothing_a_step_returns(dev, p
 def test_pair_backward_from_saved_forward_state_in_the_training_step(dev, monkeypatch):
     """mmgnn.model.SAVE_PAIR_STATE (off by default): the supervised-only heads' forward leaves the first layer's sign bits
     and the second layer's activations, the backward reads them instead of recomputing masks and the 64 x 32 product.
-    Same step up to rounding (the saved activation comes from the forward's split-bf16 product, the recomputed one from
-    the fp32 matrix instruction): losses 1e-6, parameters after two Adam steps 1e-3 of their largest entry (a Linear bias
-    in front of a BatchNorm has a zero gradient: Adam turns its rounding noise into lr-sized steps -- left out)."""
+    Same step up to rounding (the two backward kernels do not sum in the same order): losses 1e-6; parameters after two
+    Adam steps within 0.2 lr for at least 99 % of every tensor's entries -- Adam normalises every gradient entry to an
+    lr-sized step, so an entry whose gradient is at rounding level (a Linear bias in front of a BatchNorm has a ZERO
+    gradient, some weights nearly so) moves by a noise-driven, lr-sized amount in either run."""
     import mmgnn  # noqa: F401
     import mmgnn.model as mm
     from mmgnn.data import build_plan
@@ -348,4 +349,7 @@ def test_pair_backward_from_saved_forward_state_in_the_training_step(dev, monkey
         if not s0[k].is_floating_point():
             assert torch.equal(s0[k], s1[k]), k
         elif not (k.endswith(("patient_transform.0.bias", "patient_transform.4.bias")) or k.endswith(".lin_l.bias")):
-            assert float((s0[k] - s1[k]).abs().max()) <= 1e-3 * float(s0[k].abs().max()) + 1e-7, k
+            # (zero-gradient biases: pure noise, left out; elsewhere at most 1 % of a tensor's entries may sit at such a
+            #  rounding-level gradient and differ by more than 0.2 lr)
+            far = ((s0[k] - s1[k]).abs() > 0.2 * 1e-2).float().mean()
+            assert float(far) <= 1e-2, (k, float(far))
