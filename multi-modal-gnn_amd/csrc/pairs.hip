@@ -726,7 +726,7 @@ __global__ __launch_bounds__(512) void k_pair_bwd_duo(HeadDev H, HeadGradDev Gd,
 constexpr int P1S = 80;                              // row stride of an h1 plane (bf16): 160 B, the 4 rows of a transposing
                                                      // read land on 4 disjoint 8-dword bank spans
 constexpr int F6_LDS = 3 * TP * 4 + 3 * TP * P1S * 2;    // bytes private to a front wave: dout | pair id lo | hi | 3 planes
-constexpr int B6_LDS = TP * LDH * 4;                 // bytes private to a back wave: the dH1 tile of the flush
+constexpr int B6_LDS = 2 * TP * 4;                   // bytes private to a back wave: run id per pair | patient per run
 constexpr int H6_LDS = TP * LDD * 4 + TP * 2 * 4;    // bytes per hand-off buffer: D2 tile | sign bits
 
 __device__ __forceinline__ void psplit8(const float* v, pbf16x8& p0, pbf16x8& p1, pbf16x8& p2) {
@@ -983,7 +983,8 @@ __device__ __forceinline__ void pair_bwd6_back(const HeadDev& H, float* __restri
   const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
   const int h = lane >> 5, l31 = lane & 31;
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  float* T = reinterpret_cast<float*>(bl);          // [32][LDH] the dH1 tile of the flush
+  int* RI = reinterpret_cast<int*>(bl);             // [32] run id of a pair (-1: not a pair of this head)
+  int* RP = RI + TP;                                // [32] patient of a run
   // B of (3): W2[u = 16 kq + 8 h + j][k = ct * 32 + l31] as three exact bf16 pieces
   pbf16x8 w2t[2][2][3];
 #pragma unroll
@@ -1007,6 +1008,19 @@ __device__ __forceinline__ void pair_bwd6_back(const HeadDev& H, float* __restri
       if (__ballot(p_i >= 0) != 0ull) {
         const float* D2s = reinterpret_cast<const float*>(HX[par][w]);    // [32][LDD]
         const unsigned* XB = reinterpret_cast<const unsigned*>(D2s + TP * LDD);
+        // ---- runs of equal patients among the tile's pairs (sorted by patient; pairs of the other head lie between):
+        //      pair j starts a run when the nearest pair of this head before it has another patient
+        const unsigned am = (unsigned)__ballot(p_i >= 0);                  // (both lane halves hold the same 32 pairs)
+        const unsigned below = am & ((1u << l31) - 1u);
+        const int p_prev = __shfl(p_i, below ? 31 - __clz((int)below) : 0, 64);
+        const bool start = p_i >= 0 && (below == 0u || p_prev != p_i);
+        const unsigned sm = (unsigned)__ballot(start);
+        const int rid = p_i >= 0 ? __popc(sm & ((2u << l31) - 1u)) - 1 : -1;
+        const int n_runs = __popc(sm);
+        if (h == 0) { RI[l31] = rid; if (start) RP[rid] = p_i; }
+        f32x16 accR[2];                                                    // dA partial sums: [run][column]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { accR[0][i] = 0.f; accR[1][i] = 0.f; }
         // ---- (3) dH1[pair,k] = D2[pair,:] . W2[:,k]: A = the pair's D2 row (u = 16 kq + 8 h + j), split here
         f32x16 accH[2];
 #pragma unroll
@@ -1054,33 +1068,27 @@ __device__ __forceinline__ void pair_bwd6_back(const HeadDev& H, float* __restri
               for (int p = 0; p < 3; ++p)
                 accB[lt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oh, bp[ct][p], accB[lt][ct], 0, 0, 0);
           }
+          // ---- dA[pi] += dH1, run by run, the same way: [run == row]^T . dH1 (one-hot x the same three pieces)
+          pbf16x8 ohr;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ohr[j] = (RI[crow(8 * t2 + j, h)] == l31) ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+              accR[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ohr, bp[ct][p], accR[ct], 0, 0, 0);
         }
-        // ---- dA[pi] += dH1: tile to this wave's LDS, then run-length flush (pairs arrive sorted by patient)
+        // one atomic per (run, 32 columns): register r holds run row crow(r, h) of column ct * 32 + l31.  (A patient whose
+        // pairs straddle two tiles receives two partial sums -- a + b in either order; more than two only beyond 32 pairs.)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          T[crow(r, h) * LDH + l31] = dh[r][0];
-          T[crow(r, h) * LDH + 32 + l31] = dh[r][1];
-        }
-        {
-          float run = 0.f;
-          int cur = -1;
-#pragma unroll
-          for (int bq = 0; bq < 2; ++bq) {
-            float vq[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) vq[q] = T[(bq * 16 + q) * LDH + lane];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const int pp = __builtin_amdgcn_readlane(p_i, bq * 16 + q);
-              if (pp < 0) continue;
-              if (pp != cur) {
-                if (cur >= 0) atomicAdd(dA + (size_t)cur * 64 + lane, run);
-                cur = pp; run = 0.f;
-              }
-              run += vq[q];
-            }
+          if (crow(r, 0) >= n_runs) continue;                              // wave-uniform: neither half has such a run
+          const int row = crow(r, h);
+          if (row < n_runs) {
+            float* dst = dA + (size_t)RP[row] * 64 + l31;
+            atomicAdd(dst, accR[0][r]);
+            atomicAdd(dst + 32, accR[1][r]);
           }
-          if (cur >= 0) atomicAdd(dA + (size_t)cur * 64 + lane, run);
         }
       }
     }
