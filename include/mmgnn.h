@@ -447,8 +447,8 @@ int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* 
  *                            h1 = bit ? (A[pi] + B[li]) / (1 - p) : 0 exactly;
  *   h2[32 k + u]           = the second layer's activation after ReLU and dropout (its sign pattern is the mask).
  * The backward then needs no RNG, no second-layer product and no epilogue arithmetic per pair (136 B per pair instead);
- * its layer-2 mask is the forward's own.  NULL `saved` = the plain entry points (the backward recomputes).  Up to 64 labs
- * on the backward side (beyond: recomputed). */
+ * NULL `saved` = the plain entry points: the backward recomputes -- in the forward's own order, so both variants return
+ * the same bits.  Up to 64 labs on the backward side (beyond: recomputed). */
 typedef struct {
   uint32_t* h1_bits;      /* [n_total, 2] */
   float* h2;              /* [n_total, 32] */

@@ -294,26 +294,20 @@ __host__ __device__ constexpr int pair_slab_floats(int LT) { return 2048 + LT * 
 // summation order per wave and the same slab layout as the one-wave kernel had (dW2 and the three bias-like sums
 // accumulate in the front waves, dB in the back waves).
 constexpr int HAND_LDS = TP * LDH + TP * LDD;      // floats per hand-off buffer: H1 [32][LDH] | D2 [32][LDD]
-constexpr int FRONT_LDS = 3 * TP + TP * LDD;       // floats private to a front wave: dout | pair id lo | hi | saved h2 tile
+constexpr int FRONT_LDS = 3 * TP;                  // floats private to a front wave: dout | pair id lo | hi
 
-// SAVED: the forward left the sign bits of h1 and the layer-2 activations of every pair it visited (mmg_pair_saved_t): no
-// RNG, no (1) H2pre product and no layer-2 epilogue arithmetic here -- h1 = bit ? (A + B) / (1 - p) : 0, the layer-2 mask
-// is the sign pattern of the saved activation (which also makes the backward's mask the forward's own: the recomputed
-// product rounds differently from the forward's split-bf16 one at a pre-activation within rounding of 0).
-template <int LT, bool AUX, bool SAVED>
+template <int LT, bool AUX>
 __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* __restrict__ pi, const int32_t* __restrict__ li,
                                                const int32_t* __restrict__ deg, int thr, int want_low, int64_t n, float drop_p,
                                                uint64_t seed, const PairBufs& pb, const float* __restrict__ dpred,
                                                const int32_t* __restrict__ sel, int n_iter, float* fl, const float* W2s,
                                                float (*HX)[4][HAND_LDS], int (*XP)[4][TP], int (*XL)[4][TP],
-                                               float (*tail_red)[68], float* red, const uint32_t* __restrict__ sv_bits,
-                                               const float* __restrict__ sv_h2) {
+                                               float (*tail_red)[68], float* red) {
   const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
   const int h = lane >> 5, l31 = lane & 31;
   float* DOs = fl;                                  // [32] dout (0 for inactive)
   unsigned* PLo = reinterpret_cast<unsigned*>(DOs + TP);
   unsigned* PHi = PLo + TP;
-  float* T2 = reinterpret_cast<float*>(PHi + TP);   // SAVED: [32][LDD] the tile's saved layer-2 activations, pair-major
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const float b2v = H.b2[l31], w3v = H.W3[l31];
   float w3acc = 0.f, b2acc = 0.f, b3acc = 0.f;
@@ -363,8 +357,6 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
     m.pid = (AUX && has_pid) ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
     return m;
   };
-  uint32_t sbw = 0u;                                 // SAVED: sign bits of this lane's 32 h1 elements / 16 saved activations
-  f32x4 sh2[SAVED ? 4 : 1];
   auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
     const unsigned pp = m.p_i >= 0 ? (unsigned)m.p_i : 0u;
     *dg = pair_ld_i32(deg_d, pp * 4u);
@@ -374,12 +366,6 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
     for (int q = 0; q < 8; ++q) {
       ra[q] = pair_ld_f4(A_d, ao + q * 16u);
       rb[q] = pair_ld_f4(B_d, bo + q * 16u);
-    }
-    if constexpr (SAVED) {          // (a pair that is not one -- p_i < 0 -- reads entry 0: always inside the buffers)
-      const size_t kc = m.p_i >= 0 ? (size_t)m.k : 0;
-      sbw = sv_bits[kc * 2 + h];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sh2[q] = *reinterpret_cast<const f32x4*>(sv_h2 + kc * 32 + 16 * h + 4 * q);
     }
   };
   const int kr0 = issue_k(wave_id), kr1 = issue_k(wave_id + n_waves);
@@ -402,13 +388,6 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
       f32x4 ca[8], cb[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) { ca[q] = ra[q]; cb[q] = rb[q]; }
-      const uint32_t cbw = sbw;
-      if constexpr (SAVED) {                       // (private to this wave; read back below, after the h1 phase)
-        // a pair of the tile that is not this head's was never written by the forward: its entry is arbitrary memory
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(T2 + l31 * LDD + 16 * h + 4 * q) = active ? sh2[q] : z4;
-      }
       const Meta m1 = fin_meta(rm1);
       const int k2 = fin_k(kr2, t + 2 * n_waves);
       kr2 = issue_k(t + 3 * n_waves);
@@ -427,27 +406,7 @@ __device__ __forceinline__ void pair_bwd_front(const HeadDev& H, const int32_t* 
         }
         // ---- h1[pair=l31][k=32h+s]: gather-add, relu, dropout; kept in registers AND written to the hand-off tile
         float d2c[16];
-        if constexpr (SAVED) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            f32x4 v;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = active && ((cbw >> (q * 4 + j)) & 1u) ? (ca[q][j] + cb[q][j]) * inv_keep : 0.f;
-            *reinterpret_cast<f32x4*>(H1s + l31 * LDH + 32 * h + q * 4) = v;
-          }
-          // ---- layer 2 from the saved activation, in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = crow(r, h);
-            const float post = T2[row * LDD + l31];
-            const float dr = DOs[row];
-            const float d2 = post > 0.f ? dr * w3v * inv_keep : 0.f;
-            d2c[r] = d2;
-            w3acc = fmaf(dr, post, w3acc);
-            b2acc += d2;
-            D2s[row * LDD + l31] = d2;
-          }
-        } else {
+        {
           float h1a[32];
           const uint32_t key1 = mmg_rng_key(seed, SITE_H1), thr1 = mmg_keep_threshold(drop_p);
 #pragma unroll
@@ -654,14 +613,13 @@ __device__ __forceinline__ void pair_bwd_back(float* __restrict__ dA, float drop
   }
 }
 
-template <int LT, bool AUX, bool SAVED>
+template <int LT, bool AUX>
 __global__ __launch_bounds__(512) void k_pair_bwd_duo(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                       const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                       int thr, int want_low, int64_t n, int n_labs, float drop_p,
                                                       uint64_t seed, const uint64_t* __restrict__ seed_ptr, PairBufs pb,
                                                       const float* __restrict__ dpred, const int32_t* __restrict__ sel,
-                                                      const int32_t* __restrict__ n_sel, float* __restrict__ slab,
-                                                      const uint32_t* __restrict__ sv_bits, const float* __restrict__ sv_h2) {
+                                                      const int32_t* __restrict__ n_sel, float* __restrict__ slab) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }
   __shared__ __attribute__((aligned(16))) float HX[2][4][HAND_LDS];      // hand-off tiles: [buffer][wave pair]
@@ -680,8 +638,8 @@ __global__ __launch_bounds__(512) void k_pair_bwd_duo(HeadDev H, HeadGradDev Gd,
   constexpr int NR = (2 + 2 * LT) * 16;
   static_assert(NR * 64 <= 2 * 4 * HAND_LDS, "reduction tile must fit the hand-off buffers");
   if (wid < 4)
-    pair_bwd_front<LT, AUX, SAVED>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter,
-                                   smf + (wid & 3) * FRONT_LDS, W2s, HX, XP, XL, tail_red, red, sv_bits, sv_h2);
+    pair_bwd_front<LT, AUX>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter, smf + (wid & 3) * FRONT_LDS,
+                            W2s, HX, XP, XL, tail_red, red);
   else
     pair_bwd_back<LT>(Gd.dA, drop_p, n_iter, W2s, HX, XP, XL, red);
   // ---- one partial slab per workgroup (summed over the workgroups in fixed order by mmg_k_reduce_slabs)
@@ -725,7 +683,7 @@ __global__ __launch_bounds__(512) void k_pair_bwd_duo(HeadDev H, HeadGradDev Gd,
 // C-layout registers 8 t .. 8 t + 7 (A from registers) and two transposing reads at rows 16 t + 4 h and 16 t + 8 + 4 h (B).
 constexpr int P1S = 80;                              // row stride of an h1 plane (bf16): 160 B, the 4 rows of a transposing
                                                      // read land on 4 disjoint 8-dword bank spans
-constexpr int F6_LDS = 3 * TP * 4 + 3 * TP * P1S * 2;    // bytes private to a front wave: dout | pair id lo | hi | 3 planes
+constexpr int F6_LDS = 3 * TP * 4 + 3 * TP * P1S * 2 + TP * LDD * 4;   // bytes private to a front wave: dout | pair id lo | hi | 3 planes | saved h2 tile
 constexpr int B6_LDS = 2 * TP * 4;                   // bytes private to a back wave: run id per pair | patient per run
 constexpr int H6_LDS = TP * LDD * 4 + TP * 2 * 4;    // bytes per hand-off buffer: D2 tile | sign bits
 
@@ -758,31 +716,39 @@ __device__ __forceinline__ pbf16x8 tr_pair(const __bf16* p_lo, const __bf16* p_h
   return __builtin_bit_cast(pbf16x8, v);
 }
 
-template <int LT, bool AUX>
+// SAVED: the forward left the sign bits of h1 and the layer-2 activations of every pair it visited (mmg_pair_saved_t):
+// no RNG, no (1) and no layer-2 epilogue arithmetic -- h1 = bit ? (A + B) / (1 - p) : 0, the layer-2 mask is the sign
+// pattern of the saved activation.  Because (1) above reproduces the forward's pre-activation bit for bit, the saved and
+// the recomputing variant return the SAME bits.
+template <int LT, bool AUX, bool SAVED>
 __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t* __restrict__ pi, const int32_t* __restrict__ li,
                                                 const int32_t* __restrict__ deg, int thr, int want_low, int64_t n, float drop_p,
                                                 uint64_t seed, const PairBufs& pb, const float* __restrict__ dpred,
                                                 const int32_t* __restrict__ sel, int n_iter, unsigned char* fl,
                                                 unsigned char (*HX)[4][H6_LDS], int (*XP)[4][TP], int (*XL)[4][TP],
-                                                float (*tail_red)[68], float* red) {
+                                                float (*tail_red)[68], float* red, const uint32_t* __restrict__ sv_bits,
+                                                const float* __restrict__ sv_h2) {
   const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
   const int h = lane >> 5, l31 = lane & 31;
   float* DOs = reinterpret_cast<float*>(fl);        // [32] dout (0 for inactive)
   unsigned* PLo = reinterpret_cast<unsigned*>(DOs + TP);
   unsigned* PHi = PLo + TP;
   __bf16* P1 = reinterpret_cast<__bf16*>(PHi + TP);  // [3][32][P1S] the pieces of h1, row-major
+  float* T2 = reinterpret_cast<float*>(P1 + 3 * TP * P1S);   // SAVED: [32][LDD] the tile's saved layer-2 activations
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thr_keep = mmg_keep_threshold(drop_p);
   const uint32_t key1 = mmg_rng_key(seed, SITE_H1);
   const float b2v = H.b2[l31], w3v = H.W3[l31];
   // B of (1): W2[unit = l31][k = 16 ks + 8 h + j] as three exact bf16 pieces
-  pbf16x8 w2p[4][3];
+  pbf16x8 w2p[SAVED ? 1 : 4][3];
+  if constexpr (!SAVED) {
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    float v[8];
+    for (int ks = 0; ks < 4; ++ks) {
+      float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = H.W2[l31 * 64 + 16 * ks + 8 * h + j];
-    psplit8(v, w2p[ks][0], w2p[ks][1], w2p[ks][2]);
+      for (int j = 0; j < 8; ++j) v[j] = H.W2[l31 * 64 + 16 * ks + 8 * h + j];
+      psplit8(v, w2p[ks][0], w2p[ks][1], w2p[ks][2]);
+    }
   }
   float w3acc = 0.f, b2acc = 0.f, b3acc = 0.f;
   f32x16 accW2[2];
@@ -791,6 +757,8 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + w, n_waves = (int64_t)gridDim.x * 4;
   // the three-deep load pipeline of k_pair_bwd_duo; the row halves in the FORWARD's order: register q of a lane holds
   // k = 16 (q >> 1) + 8 h + 4 (q & 1) + 0..3, so that a k-step's eight values are lane-local
+  pu32x2 sbw = {0u, 0u};                            // SAVED: the pair's 64 sign bits / this lane's 16 saved activations
+  f32x4 sh2[SAVED ? 4 : 1];
   struct Meta { int k; int p_i; int l_i; int o; uint64_t pid; };
   const __amdgpu_buffer_rsrc_t sel_d = pair_rsrc(sel ? sel : pi, sel ? (uint32_t)(n * 4) : 0u);
   const __amdgpu_buffer_rsrc_t io_d = pair_rsrc(pb.io, pb.io_bytes), pid_d = pair_rsrc(pb.pid, pb.pid_bytes);
@@ -839,6 +807,12 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
       ra[q] = pair_ld_f4(A_d, ao + (q >> 1) * 64u + (q & 1) * 16u);
       rb[q] = pair_ld_f4(B_d, bo + (q >> 1) * 64u + (q & 1) * 16u);
     }
+    if constexpr (SAVED) {          // (a pair that is not one -- p_i < 0 -- reads entry 0: always inside the buffers)
+      const size_t kc = m.p_i >= 0 ? (size_t)m.k : 0;
+      sbw = *reinterpret_cast<const pu32x2*>(sv_bits + kc * 2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sh2[q] = *reinterpret_cast<const f32x4*>(sv_h2 + kc * 32 + 16 * h + 4 * q);
+    }
   };
   // transposing-read lane roles (see k_linear_wgrad_x6): group g = lane >> 4 supplies row q of columns 16 (g & 1) + 4 p
   const int trq = (lane >> 2) & 3, trc = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -877,38 +851,60 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
           PLo[l31] = (unsigned)pid; PHi[l31] = (unsigned)(pid >> 32);
           b3acc += dout;
         }
-        // ---- h1 (gather-add, relu, dropout), k-step by k-step: pieces -> (1) and the planes, sign bits
-        uint32_t bw[2] = {0u, 0u};
+        if constexpr (SAVED) {
+          // a pair of the tile that is not this head's was never written by the forward: its entry is arbitrary memory
+          const pu32x2 bwv = active ? sbw : pu32x2{0u, 0u};
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          float x8[8];
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(T2 + l31 * LDD + 16 * h + 4 * q) = active ? sh2[q] : z4;
+          if (h == 0) *reinterpret_cast<pu32x2*>(XB + 2 * l31) = bwv;
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {                // one aligned RNG group of 4 per chunk: one hash
-            f32x4 x;
+          for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t wbits = (bwv[ks >> 1] >> (16 * (ks & 1) + 8 * h)) & 0xFFu;
+            float x8[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = fmaxf(ra[2 * ks + c][j] + rb[2 * ks + c][j], 0.f);
-            if (drop_p > 0.f) mmg_drop4(x, key1, pid * 64ull + (uint64_t)(16 * ks + 8 * h + 4 * c), thr_keep, inv_keep);
+            for (int j = 0; j < 8; ++j)
+              x8[j] = (wbits >> j) & 1u ? (ra[2 * ks + (j >> 2)][j & 3] + rb[2 * ks + (j >> 2)][j & 3]) * inv_keep : 0.f;
+            pbf16x8 xp[3];
+            psplit8(x8, xp[0], xp[1], xp[2]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) x8[4 * c + j] = x[j];
+            for (int pc = 0; pc < 3; ++pc)
+              *reinterpret_cast<pbf16x8*>(P1 + (pc * TP + l31) * P1S + 16 * ks + 8 * h) = xp[pc];
           }
+        } else {
+          // ---- h1 (gather-add, relu, dropout), k-step by k-step: pieces -> (1) and the planes, sign bits
+          uint32_t bw[2] = {0u, 0u};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bw[ks >> 1] |= x8[j] > 0.f ? (1u << (16 * (ks & 1) + j)) << (8 * h) : 0u;
-          pbf16x8 xp[3];
-          psplit8(x8, xp[0], xp[1], xp[2]);
+          for (int ks = 0; ks < 4; ++ks) {
+            float x8[8];
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
-            *reinterpret_cast<pbf16x8*>(P1 + (pc * TP + l31) * P1S + 16 * ks + 8 * h) = xp[pc];
-          // (1) C[pair rows, unit] = H1 . W2^T: the forward's six products in the forward's order (operands swapped)
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][2], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[2], w2p[ks][0], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[1], w2p[ks][1], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][1], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[1], w2p[ks][0], acc1, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][0], acc1, 0, 0, 0);
+            for (int c = 0; c < 2; ++c) {                // one aligned RNG group of 4 per chunk: one hash
+              f32x4 x;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) x[j] = fmaxf(ra[2 * ks + c][j] + rb[2 * ks + c][j], 0.f);
+              if (drop_p > 0.f) mmg_drop4(x, key1, pid * 64ull + (uint64_t)(16 * ks + 8 * h + 4 * c), thr_keep, inv_keep);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) x8[4 * c + j] = x[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bw[ks >> 1] |= x8[j] > 0.f ? (1u << (16 * (ks & 1) + j)) << (8 * h) : 0u;
+            pbf16x8 xp[3];
+            psplit8(x8, xp[0], xp[1], xp[2]);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+              *reinterpret_cast<pbf16x8*>(P1 + (pc * TP + l31) * P1S + 16 * ks + 8 * h) = xp[pc];
+            // (1) C[pair rows, unit] = H1 . W2^T: the forward's six products in the forward's order (operands swapped)
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][2], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[2], w2p[ks][0], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[1], w2p[ks][1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][1], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[1], w2p[ks][0], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xp[0], w2p[ks][0], acc1, 0, 0, 0);
+          }
+          bw[0] |= (uint32_t)__shfl_xor((int)bw[0], 32, 64);
+          bw[1] |= (uint32_t)__shfl_xor((int)bw[1], 32, 64);
+          if (h == 0) *reinterpret_cast<pu32x2*>(XB + 2 * l31) = pu32x2{bw[0], bw[1]};
         }
-        bw[0] |= (uint32_t)__shfl_xor((int)bw[0], 32, 64);
-        bw[1] |= (uint32_t)__shfl_xor((int)bw[1], 32, 64);
-        if (h == 0) *reinterpret_cast<pu32x2*>(XB + 2 * l31) = pu32x2{bw[0], bw[1]};
       }
       // the row registers are consumed: the next tile's rows are requested now and have the rest of this tile to arrive
       __builtin_amdgcn_sched_barrier(0);
@@ -917,25 +913,44 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
       if (any) {
         // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
         float d2c[16];
-        uint32_t kb[16];
-        if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PLo, PHi, h, l31, kb);
+        if constexpr (SAVED) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = crow(r, h);
-          const float pre = acc1[r] + b2v;
-          float m = pre > 0.f ? 1.f : 0.f;
-          float post = fmaxf(pre, 0.f);
-          if (drop_p > 0.f) {
-            const bool kp = kb[r] >= thr_keep;
-            m = kp ? m * inv_keep : 0.f;
-            post = kp ? post * inv_keep : 0.f;
+          for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, h);
+            const float post = T2[row * LDD + l31];
+            const float dr = DOs[row];
+            float d2 = dr * w3v * (post > 0.f ? inv_keep : 0.f);
+            asm volatile("" : "+v"(d2));               // d2 is ROUNDED here, in both variants (see the other one)
+            d2c[r] = d2;
+            w3acc = fmaf(dr, post, w3acc);
+            b2acc += d2;
+            D2s[row * LDD + l31] = d2;
           }
-          const float dr = DOs[row];
-          const float d2 = dr * w3v * m;
-          d2c[r] = d2;
-          w3acc = fmaf(dr, post, w3acc);
-          b2acc += d2;
-          D2s[row * LDD + l31] = d2;
+        } else {
+          uint32_t kb[16];
+          if (drop_p > 0.f) layer2_fields(mmg_rng_key(seed, SITE_H2), PLo, PHi, h, l31, kb);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = crow(r, h);
+            const float pre = acc1[r] + b2v;
+            float m = pre > 0.f ? 1.f : 0.f;
+            float post = fmaxf(pre, 0.f);
+            if (drop_p > 0.f) {
+              const bool kp = kb[r] >= thr_keep;
+              m = kp ? m * inv_keep : 0.f;
+              post = kp ? post * inv_keep : 0.f;
+            }
+            const float dr = DOs[row];
+            float d2 = dr * w3v * m;
+            // d2 is ROUNDED here, in both variants: left to the compiler, the product is contracted into the additions and
+            // subtractions that consume it (bias sum, piece residuals) in one variant and not in the other, and the saved and
+            // the recomputing kernel stop agreeing bit for bit
+            asm volatile("" : "+v"(d2));
+            d2c[r] = d2;
+            w3acc = fmaf(dr, post, w3acc);
+            b2acc += d2;
+            D2s[row * LDD + l31] = d2;
+          }
         }
         // ---- (2) dW2[u,k] += D2[pair,u] * H1[pair,k]: A = d2c pieces (lane = u), B = h1 pieces of column ct * 32 + l31
 #pragma unroll
@@ -1114,13 +1129,14 @@ __device__ __forceinline__ void pair_bwd6_back(const HeadDev& H, float* __restri
   }
 }
 
-template <int LT, bool AUX>
+template <int LT, bool AUX, bool SAVED>
 __global__ __launch_bounds__(512) void k_pair_bwd_duo6(HeadDev H, HeadGradDev Gd, const int32_t* __restrict__ pi,
                                                        const int32_t* __restrict__ li, const int32_t* __restrict__ deg,
                                                        int thr, int want_low, int64_t n, int n_labs, float drop_p,
                                                        uint64_t seed, const uint64_t* __restrict__ seed_ptr, PairBufs pb,
                                                        const float* __restrict__ dpred, const int32_t* __restrict__ sel,
-                                                       const int32_t* __restrict__ n_sel, float* __restrict__ slab) {
+                                                       const int32_t* __restrict__ n_sel, float* __restrict__ slab,
+                                                       const uint32_t* __restrict__ sv_bits, const float* __restrict__ sv_h2) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }
   __shared__ __attribute__((aligned(16))) unsigned char smf[4][F6_LDS];      // front-private (later: the reduction tile)
@@ -1135,8 +1151,8 @@ __global__ __launch_bounds__(512) void k_pair_bwd_duo6(HeadDev H, HeadGradDev Gd
   constexpr int NR = (2 + 2 * LT) * 16;
   static_assert(NR * 64 * 4 <= 4 * F6_LDS, "reduction tile must fit the front waves' buffers");
   if (wid < 4)
-    pair_bwd6_front<LT, AUX>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter, smf[wid & 3], HX, XP, XL,
-                             tail_red, red);
+    pair_bwd6_front<LT, AUX, SAVED>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter, smf[wid & 3], HX,
+                                    XP, XL, tail_red, red, sv_bits, sv_h2);
   else
     pair_bwd6_back<LT>(H, Gd.dA, drop_p, n_iter, smb[wid & 3], HX, XP, XL, red);
   float* my = slab + (size_t)blockIdx.x * pair_slab_floats(LT);
@@ -1667,15 +1683,15 @@ extern "C" int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_gr
     const float* svh = saved ? saved->h2 : nullptr;
     if (n_labs <= 64) {
       if (saved) {
-        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, true, true>), 512, svb, svh);
-        else MMG_LAUNCH_PBWD((k_pair_bwd_duo<2, false, true>), 512, svb, svh);
+        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true, true>), 512, svb, svh);
+        else MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, false, true>), 512, svb, svh);
       } else {
-        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true>), 512);
-        else MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, false>), 512);
+        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true, false>), 512, svb, svh);
+        else MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, false, false>), 512, svb, svh);
       }
     } else {                                   // 65 .. 128 labs: four lab tiles of dB in the back wave (the saved state is not used)
-      if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<4, true, false>), 512, svb, svh);
-      else MMG_LAUNCH_PBWD((k_pair_bwd_duo<4, false, false>), 512, svb, svh);
+      if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<4, true>), 512);
+      else MMG_LAUNCH_PBWD((k_pair_bwd_duo<4, false>), 512);
     }
 #undef MMG_LAUNCH_PBWD
     const int LT = n_labs <= 64 ? 2 : 4;

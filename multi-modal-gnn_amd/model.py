@@ -49,15 +49,13 @@ def set_overlap(mode: str):
 # register spills they cause in those two kernels) cost more than the one joint pass they replace -- x100 eICU shape, same
 # box: none 2.468 ms, heads+conv+enc2 2.431 ms, all four 2.465 ms per step.
 NEXT_BN_SITES = frozenset({"heads", "conv", "enc2"})
-# Optional (off): in training the pair heads' forward can save, per visited pair, the sign bits of the first layer and the
-# activations of the second (ops.pair_saved_alloc: 136 B per pair of the pair set), and the backward reads them instead of
-# recomputing twelve dropout hashes, a 64 x 32 product and its epilogue per pair ("store the mask words
-# in the forward ... measure both").  Measured at the x100 shape: backward 189 -> 160 us, forward over the 0.86 M
-# supervised pairs 60 -> 72 us, 2.392 -> 2.385 ms per step (0.3 %); a forward over ALL 4.3 M pairs pays 242 -> 310 us for
-# the same 29 us.  It also makes the supervised-only step equal to the all-pairs step only up to rounding (the saved
-# activation comes from the forward's split-bf16 product, the recomputed one from the fp32 matrix instruction) instead of
-# bit for bit.  Only used where the forward visits the supervision subset alone.
-SAVE_PAIR_STATE = False
+# In training the pair heads' forward saves, per visited pair, the sign bits of the first layer and the activations of the
+# second (ops.pair_saved_alloc: 136 B per pair of the pair set), and the backward reads them instead of recomputing twelve
+# dropout hashes, a 64 x 32 product and its epilogue per pair ("store the mask words in the forward ...
+# measure both").  The recomputing backward takes that product in the forward's own order, so both variants return the same
+# bits.  Used where the forward visits the supervision subset alone (a forward over ALL 4.3 M pairs would pay 68 us for the
+# 30 us the backward gains).
+SAVE_PAIR_STATE = True
 
 
 def set_next_bn(sites):

@@ -694,7 +694,10 @@ def test_pair_head_backward_from_the_state_the_forward_saved(ops, dev, p, listed
         for name, got, rec, want in zip("A B W2 b2 W3 b3".split(), (g1.A, g1.B, g1.W2, g1.b2, g1.W3, g1.b3),
                                         (g0.A, g0.B, g0.W2, g0.b2, g0.W3, g0.b3), leaf):
             assert rel(got, want.grad) <= 2e-5, (name, want_low)
-            assert rel(got, rec) <= 2e-5, (name, want_low)
+            # the recomputing kernel takes the layer-2 product in the forward's own order: what it recomputes IS what the
+            # forward saved, bit for bit (dA: the same run sums, added by atomics whose order is free only where a patient's
+            # pairs straddle two tiles -- two partial sums, a + b either way)
+            assert torch.equal(got, rec), (name, want_low)
 
 
 @pytest.mark.parametrize("n", [1, 2047, 2048, 70001])
