@@ -727,7 +727,7 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
                                                 const int32_t* __restrict__ sel, int n_iter, unsigned char* fl,
                                                 unsigned char (*HX)[4][H6_LDS], int (*XP)[4][TP], int (*XL)[4][TP],
                                                 float (*tail_red)[68], float* red, const uint32_t* __restrict__ sv_bits,
-                                                const float* __restrict__ sv_h2) {
+                                                const float* __restrict__ sv_h2, int sv_by_pos) {
   const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
   const int h = lane >> 5, l31 = lane & 31;
   float* DOs = reinterpret_cast<float*>(fl);        // [32] dout (0 for inactive)
@@ -797,7 +797,7 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
     m.pid = (AUX && has_pid) ? ((uint64_t)r.d2[1] << 32 | r.d2[0]) : (uint64_t)kc;
     return m;
   };
-  auto load_rows = [&](const Meta& m, f32x4* ra, f32x4* rb, int* dg, float* dv) {
+  auto load_rows = [&](const Meta& m, int64_t tile, f32x4* ra, f32x4* rb, int* dg, float* dv) {
     const unsigned pp = m.p_i >= 0 ? (unsigned)m.p_i : 0u;
     *dg = pair_ld_i32(deg_d, pp * 4u);
     *dv = __builtin_bit_cast(float, pair_ld_i32(dp_d, (unsigned)m.o * 4u));
@@ -808,7 +808,7 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
       rb[q] = pair_ld_f4(B_d, bo + (q >> 1) * 64u + (q & 1) * 16u);
     }
     if constexpr (SAVED) {          // (a pair that is not one -- p_i < 0 -- reads entry 0: always inside the buffers)
-      const size_t kc = m.p_i >= 0 ? (size_t)m.k : 0;
+      const size_t kc = m.p_i >= 0 ? (size_t)(sv_by_pos ? tile * TP + l31 : (int64_t)m.k) : 0;
       sbw = *reinterpret_cast<const pu32x2*>(sv_bits + kc * 2);
 #pragma unroll
       for (int q = 0; q < 4; ++q) sh2[q] = *reinterpret_cast<const f32x4*>(sv_h2 + kc * 32 + 16 * h + 4 * q);
@@ -823,7 +823,7 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
   Meta m0 = fin_meta(rm0);
   f32x4 ra[8], rb[8];
   int dg0; float dv0;
-  load_rows(m0, ra, rb, &dg0, &dv0);
+  load_rows(m0, wave_id, ra, rb, &dg0, &dv0);
   for (int it = 0; it <= n_iter; ++it) {
     const int par = it & 1;
     if (it < n_iter) {
@@ -908,7 +908,7 @@ __device__ __forceinline__ void pair_bwd6_front(const HeadDev& H, const int32_t*
       }
       // the row registers are consumed: the next tile's rows are requested now and have the rest of this tile to arrive
       __builtin_amdgcn_sched_barrier(0);
-      load_rows(m1, ra, rb, &dg0, &dv0);
+      load_rows(m1, t + n_waves, ra, rb, &dg0, &dv0);
       __builtin_amdgcn_sched_barrier(0);
       if (any) {
         // ---- epilogue of layer 2 in the C layout: lane = unit u (l31), reg r = pair row crow(r,h)
@@ -1136,7 +1136,8 @@ __global__ __launch_bounds__(512) void k_pair_bwd_duo6(HeadDev H, HeadGradDev Gd
                                                        uint64_t seed, const uint64_t* __restrict__ seed_ptr, PairBufs pb,
                                                        const float* __restrict__ dpred, const int32_t* __restrict__ sel,
                                                        const int32_t* __restrict__ n_sel, float* __restrict__ slab,
-                                                       const uint32_t* __restrict__ sv_bits, const float* __restrict__ sv_h2) {
+                                                       const uint32_t* __restrict__ sv_bits, const float* __restrict__ sv_h2,
+                                                       int sv_by_pos) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }
   __shared__ __attribute__((aligned(16))) unsigned char smf[4][F6_LDS];      // front-private (later: the reduction tile)
@@ -1152,7 +1153,7 @@ __global__ __launch_bounds__(512) void k_pair_bwd_duo6(HeadDev H, HeadGradDev Gd
   static_assert(NR * 64 * 4 <= 4 * F6_LDS, "reduction tile must fit the front waves' buffers");
   if (wid < 4)
     pair_bwd6_front<LT, AUX, SAVED>(H, pi, li, deg, thr, want_low, n, drop_p, seed, pb, dpred, sel, n_iter, smf[wid & 3], HX,
-                                    XP, XL, tail_red, red, sv_bits, sv_h2);
+                                    XP, XL, tail_red, red, sv_bits, sv_h2, sv_by_pos);
   else
     pair_bwd6_back<LT>(H, Gd.dA, drop_p, n_iter, smb[wid & 3], HX, XP, XL, red);
   float* my = slab + (size_t)blockIdx.x * pair_slab_floats(LT);
@@ -1220,7 +1221,7 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
                                                           const int32_t* __restrict__ sel,
                                                           const int32_t* __restrict__ n_sel,
                                                           int n_labs_lds, uint32_t* __restrict__ sv_bits,
-                                                          float* __restrict__ sv_h2) {
+                                                          float* __restrict__ sv_h2, int sv_by_pos) {
   if (seed_ptr) seed = *seed_ptr;
   if (sel) { const int64_t nl = *n_sel; n = nl < 0 ? 0 : (nl < n ? nl : n); }     // never beyond the list's capacity
   // the lab-side first-layer table B (a few dozen 256-B rows, read once per PAIR) lives in LDS when it fits:
@@ -1389,13 +1390,14 @@ __global__ __launch_bounds__(256, 2) void k_pair_fwd_mfma(HeadDev H, const int32
 #pragma unroll
       for (int e = 0; e < 4; ++e) part = fmaf(w3r[4 * i + e], post[e], part);
       if constexpr (SAVE) {
-        if (active) *reinterpret_cast<f32x4*>(sv_h2 + (size_t)mc.k * 32 + 8 * i + 4 * h) = post;
+        if (active) *reinterpret_cast<f32x4*>(sv_h2 + (size_t)(sv_by_pos ? t * TP + l31 : (int64_t)mc.k) * 32 + 8 * i + 4 * h) = post;
       }
     }
     if constexpr (SAVE) {
       bw[0] |= (uint32_t)__shfl_xor((int)bw[0], 32, 64);
       bw[1] |= (uint32_t)__shfl_xor((int)bw[1], 32, 64);
-      if (h == 0 && active) *reinterpret_cast<pu32x2*>(sv_bits + (size_t)mc.k * 2) = pu32x2{bw[0], bw[1]};
+      if (h == 0 && active)
+        *reinterpret_cast<pu32x2*>(sv_bits + (size_t)(sv_by_pos ? t * TP + l31 : (int64_t)mc.k) * 2) = pu32x2{bw[0], bw[1]};
     }
     part += __shfl_xor(part, 32, 64);
     if (h == 0 && active)          // (a slot past the end of pred is dropped by the descriptor's range check)
@@ -1601,11 +1603,13 @@ extern "C" int mmg_pair_head_fwd_save(const mmg_head_t* head, const int32_t* pi,
   const size_t lds = (size_t)n_labs_lds * PF_LDB * sizeof(float);
   uint32_t* svb = saved ? saved->h1_bits : nullptr;
   float* svh = saved ? saved->h2 : nullptr;
+  const int sv_pos = saved && saved->by_position ? 1 : 0;
+  MMG_CHECK_ARG(!sv_pos || sel, "pair_head_fwd_save: by_position needs a pair list");
   constexpr int lds_max = 256 * PF_LDB * (int)sizeof(float);
 #define MMG_LAUNCH_PFWD(BL_, SV_, LDS_, NL_)                                                                           \
   MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, (want_low ? 2 : 0) | (SV_ ? 512 : 0), (k_pair_fwd_mfma<BL_, SV_>),      \
              dim3((unsigned)g), dim3(256), LDS_, (hipStream_t)stream, H, pi, li, deg, degree_threshold, want_low ? 1 : 0, \
-             n_pairs, drop_p, seed, seed_ptr, pb, pred, sel, n_sel, NL_, svb, svh)
+             n_pairs, drop_p, seed, seed_ptr, pb, pred, sel, n_sel, NL_, svb, svh, sv_pos)
   if (n_labs_lds) {
     if (saved) {
       MMG_CHECK_HIP((MmgMaxLds<&k_pair_fwd_mfma<true, true>, lds_max>::set()), "pair_head_fwd(attr)");
@@ -1681,13 +1685,15 @@ extern "C" int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_gr
     const bool aux = pair_id != nullptr || io_perm != nullptr;
     const uint32_t* svb = saved ? saved->h1_bits : nullptr;
     const float* svh = saved ? saved->h2 : nullptr;
+    const int sv_pos = saved && saved->by_position ? 1 : 0;
+    MMG_CHECK_ARG(!sv_pos || sel, "pair_head_bwd_saved: by_position needs the pair list the forward ran over");
     if (n_labs <= 64) {
       if (saved) {
-        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true, true>), 512, svb, svh);
-        else MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, false, true>), 512, svb, svh);
+        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true, true>), 512, svb, svh, sv_pos);
+        else MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, false, true>), 512, svb, svh, sv_pos);
       } else {
-        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true, false>), 512, svb, svh);
-        else MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, false, false>), 512, svb, svh);
+        if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true, false>), 512, svb, svh, 0);
+        else MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, false, false>), 512, svb, svh, 0);
       }
     } else {                                   // 65 .. 128 labs: four lab tiles of dB in the back wave (the saved state is not used)
       if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo<4, true>), 512);

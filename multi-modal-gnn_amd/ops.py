@@ -806,13 +806,16 @@ def pair_saved_alloc(n_total: int, device):
 
 
 def _pair_saved(saved, n_total: int):
+    """saved = (bits, h2) or (bits, h2, by_position): by_position -- entries indexed by the position in the pair list
+    instead of the pair index (dense); forward and backward must then run over the same list."""
     if saved is None:
         return None
-    bits, h2 = saved
+    bits, h2 = saved[0], saved[1]
+    by_pos = bool(saved[2]) if len(saved) > 2 else False
     if bits.dtype != torch.int32 or tuple(bits.shape) != (max(n_total, 1), 2) or h2.dtype != torch.float32 or \
             tuple(h2.shape) != (max(n_total, 1), 32):
         raise ValueError("pair head: saved = (int32 [n_total, 2], float32 [n_total, 32]) -- see pair_saved_alloc")
-    return PairSavedT(_p(bits, torch.int32).value, _p(h2).value)
+    return PairSavedT(_p(bits, torch.int32).value, _p(h2).value, int(by_pos))
 
 
 def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred, seed_dev=None,

@@ -644,7 +644,7 @@ def test_pair_head_fwd_bwd(ops, dev, p, sorted_pairs, L):
             assert rel(got, want.grad) <= 2e-5, (name, want_low)
 
 @pytest.mark.parametrize("p", [0.0, 0.3])
-@pytest.mark.parametrize("listed", [False, True])
+@pytest.mark.parametrize("listed", [False, True, "same"])
 def test_pair_head_backward_from_the_state_the_forward_saved(ops, dev, p, listed):
     """mmg_pair_head_fwd_save / mmg_pair_head_bwd_saved: the forward leaves the first layer's sign bits and the second
     layer's activations per visited pair, the backward reads them instead of recomputing masks and the 64 x 32 product --
@@ -672,6 +672,9 @@ def test_pair_head_backward_from_the_state_the_forward_saved(ops, dev, p, listed
             blo, bhi, bcnt = ops.pair_select(i32(pi), i32(deg), 6, dpred.to(dev))
             fsel = dict(sel=lo if want_low else hi, n_sel=cnt[0:1] if want_low else cnt[1:2], n_bound=n)
             bsel = dict(sel=blo if want_low else bhi, n_sel=bcnt[0:1] if want_low else bcnt[1:2], n_bound=n)
+            if listed == "same":            # forward and backward over the SAME list: the state may be indexed by list position
+                fsel = bsel
+                save = save + (True,)
         ops.pair_head_fwd(head, i32(pi), i32(li), i32(deg), 6, want_low, p, 77, pid.to(dev), pred, save=save, **(fsel or {}))
         ref_pred = torch.zeros(n, device=dev)
         ops.pair_head_fwd(head, i32(pi), i32(li), i32(deg), 6, want_low, p, 77, pid.to(dev), ref_pred, **(fsel or {}))
