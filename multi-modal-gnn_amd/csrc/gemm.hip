@@ -490,7 +490,9 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
 // per SIMD has 512), so an X tile is staged once per CU, a fragment read feeds two products, and the staging of tile t+1
 // is woven between the products of tile t (one pass per two k-steps; its input register is refilled at once with tile
 // t+2, so ONE tile of X in registers keeps a full tile time of load latency).
-template <bool PRO, bool ACC>
+// PRO: 0 = none, 1 = any prologue (run-time tests), 2 = scale + shift and dropout both present: no branch inside a
+// staging pass, so a pass stays in the basic block of the products it is woven between.
+template <int PRO, bool ACC>
 __global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
     const float* __restrict__ X, ProDev pr, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, int64_t M, int N, int flags, double* __restrict__ stat_partial) {
@@ -565,13 +567,13 @@ __global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
     f32x4 v = nx[p];
     if (PRO) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (pr.scale) {
+      if (PRO == 2 || pr.scale) {
         sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
         sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], sc[j], sh[j]), floor_v);
-      if (drop)
+      if (PRO == 2 || drop)
         mmg_drop4(v, pr.key, (uint64_t)(pr.row_offset + row0 + r) * (uint64_t)K + (uint64_t)(kc4 * 4), pr.thr, pr.inv_keep);
     }
     xbf16x4 q0, q1, q2;
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
   }
 }
 
-template <bool PRO, bool ACC>
+template <int PRO, bool ACC>
 int launch_fwd_x6_k256_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                          int flags, hipStream_t st, double* stat_partial, int64_t gy) {
   constexpr int lds = 2 * 3 * 32 * (256 + 8) * 2;
@@ -698,10 +700,13 @@ int launch_fwd_x6_k256(const float* X, const ProDev& pr, const float* W, const f
                        int flags, hipStream_t st, double* stat_partial) {
   const bool pro = pr.scale || pr.relu || pr.p > 0.f, acc = (flags & MMG_LIN_ACCUMULATE) != 0;
   const int64_t gy = fwd_k256_rows(M, N);
-  if (pro) return acc ? launch_fwd_x6_k256_v<true, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
-                      : launch_fwd_x6_k256_v<true, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
-  return acc ? launch_fwd_x6_k256_v<false, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
-             : launch_fwd_x6_k256_v<false, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
+  if (pro && pr.scale && pr.p > 0.f)
+    return acc ? launch_fwd_x6_k256_v<2, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+               : launch_fwd_x6_k256_v<2, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
+  if (pro) return acc ? launch_fwd_x6_k256_v<1, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+                      : launch_fwd_x6_k256_v<1, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
+  return acc ? launch_fwd_x6_k256_v<0, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+             : launch_fwd_x6_k256_v<0, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
 }
 
 inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y of the bf16-split forward (= partial stat rows)
