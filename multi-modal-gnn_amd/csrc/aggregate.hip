@@ -1274,6 +1274,10 @@ __global__ __launch_bounds__(512) void k_gather_bits(RelPack rp, int64_t n_rows,
 // unit-0 wave, which also accumulates into `out` and takes the BatchNorm column sums.  Same arithmetic as k_gather_bits.
 constexpr int GU_KU = 8;          // k-steps per unit (128 items): 96 registers of table pieces
 constexpr int GU_MAXU = 6;        // units per launch
+#ifndef MMG_GU_DEPTH
+#define MMG_GU_DEPTH 3
+#endif
+constexpr int GU_DEPTH = MMG_GU_DEPTH;   // tiles of look-ahead of the inputs
 struct GaUnits {
   int rel[GU_MAXU], ks0[GU_MAXU], nks[GU_MAXU];   // relation, first k-step inside it (even), k-steps (even, <= GU_KU)
   int nf[GU_MAXU];                                // uint16 fields per (row, half) of that relation = padded items / 16
@@ -1335,8 +1339,12 @@ __global__ __launch_bounds__(512) void k_gather_units(GaUnits gu, RelPack rp, in
   const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)(unsigned)(n_rows * D * 4), 0x00020000);
   const unsigned row_bytes = (unsigned)D * 4u;
   const unsigned* mrow = reinterpret_cast<const unsigned*>(R.mask_r);
-  unsigned mcur[GU_KU / 2], mnxt[GU_KU / 2];
-  float rsn = 1.f, prev[16];
+  // Inputs run GU_DEPTH tiles ahead in as many register sets (iteration i uses set i % GU_DEPTH): a tile takes less time
+  // than a loaded HBM round trip, so with one tile of look-ahead the loop ran at one round trip per tile whatever the tile
+  // held.  A set is refilled right after its last use in an iteration (the masks after the indicator reads, the previous
+  // output after the store), which needs no copy: two sets take the registers that one set + its copy took before.
+  unsigned mS_[GU_DEPTH][GU_KU / 2];
+  float rsS_[GU_DEPTH], pS_[GU_DEPTH][16];
   auto loadm = [&](int tile, unsigned* dst) {                       // this lane's patient (l31) and item half (h)
     int64_t row = (int64_t)tile * 32 + l31;
     if (row > last_row) row = last_row;
@@ -1357,35 +1365,32 @@ __global__ __launch_bounds__(512) void k_gather_units(GaUnits gu, RelPack rp, in
   };
   float* rss = rss_all + wid * 32;
   double cs1 = 0.0, cs2 = 0.0;
-  int tile = blockIdx.x;
-  if (tile < n_tile_total) {
-    loadm(tile, mcur); rsn = loadrs(tile);
-    if (ACCUM && u == 0) loadprev(tile, prev);
-  }
-  int par = 0;
-  for (; tile < n_tile_total; tile += t_step, par ^= 1) {
-    const int tn = tile + t_step < n_tile_total ? tile + t_step : tile;
-    loadm(tn, mnxt);
-    if (h == 0) rss[l31] = rsn;                                      // private to this wave
-    rsn = loadrs(tn);
-    float pc[16];
-    if (ACCUM && u == 0) {
+  const int t_beg = blockIdx.x;
+  if (t_beg < n_tile_total) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pc[i] = prev[i];
-      loadprev(tn, prev);
+    for (int d = 0; d < GU_DEPTH; ++d) {
+      const int td = t_beg + d * t_step < n_tile_total ? t_beg + d * t_step : t_beg;
+      loadm(td, mS_[d]); rsS_[d] = loadrs(td);
+      if (ACCUM && u == 0) loadprev(td, pS_[d]);
     }
+  }
+  auto tile_body = [&](int tile, int par, unsigned* mS, float& rsS, float* pS) __attribute__((always_inline)) {
+    const int tn = tile + GU_DEPTH * t_step < n_tile_total ? tile + GU_DEPTH * t_step : tile;     // (any valid tile: loaded, never used)
+    if (h == 0) rss[l31] = rsS;                                      // private to this wave
+    rsS = loadrs(tn);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int q = 0; q < GU_KU; ++q)
       if (q < nks) {                                                 // wave-uniform
-        const unsigned off = __builtin_amdgcn_ubfe(mcur[q >> 1], 16u * (q & 1), 12u);
+        const unsigned off = __builtin_amdgcn_ubfe(mS[q >> 1], 16u * (q & 1), 12u);
         const bf16x8 af = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, tb[q][2], acc, 0, 0, 0);
       }
+    loadm(tn, mS);
     // scaled partial in the C layout: register i <-> patient row (i & 3) + 8 (i >> 2) + 4 h, lane <-> feature column
     float v[16];
 #pragma unroll
@@ -1416,14 +1421,23 @@ __global__ __launch_bounds__(512) void k_gather_units(GaUnits gu, RelPack rp, in
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         float t = tt[i];
-        if (ACCUM) t += pc[i];
+        if (ACCUM) t += pS[i];
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), osrc, vo, ((i & 3) + 8 * (i >> 2)) * row_bytes, 0);
         if ((i & 3) + 8 * (i >> 2) + 4 * h < rows_left) { t1 += t; t2 = fmaf(t, t, t2); }
       }
       if (stat_partial) { cs1 += (double)t1; cs2 += (double)t2; }
+      if (ACCUM) loadprev(tn, pS);
     }
+  };
+  // (peeling the first round, as k_gather_bits does, made this loop slower: 113 us against 94 at the MIMIC-III shape)
+  int par = 0;
+  for (int tile = t_beg; tile < n_tile_total; tile += GU_DEPTH * t_step) {
 #pragma unroll
-    for (int i = 0; i < GU_KU / 2; ++i) mcur[i] = mnxt[i];
+    for (int d = 0; d < GU_DEPTH; ++d)
+      if (tile + d * t_step < n_tile_total) {                                          // (workgroup-uniform)
+        tile_body(tile + d * t_step, par, mS_[d], rsS_[d], pS_[d]);
+        par ^= 1;
+      }
   }
   if (stat_partial && u == 0) {               // the two lane halves hold different rows of the same column
     cs1 += __shfl_xor(cs1, 32, 64);
