@@ -1661,8 +1661,14 @@ static int linear_fwd_stats_impl(const float* X, const mmg_prologue_t* pro, cons
       stats_done = true;
     }
   } else {
-    // K = 256 with a 64-wide output (the heads' first layer at 256-d): fp32 matrix cores, one workgroup per CU
-    launch_fwd<256, 1, 1, 1>(X, pr, W, bias, Y, M, N, accumulate, st);
+    // K = 256 with a 64-wide output (the heads' first layer at 256-d)
+    int rc = launch_fwd_x6<256, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
+    if (rc) return rc;
+    if (col_sums) {
+      int rc2 = mmg_partial_sum_bn(partial, col_sums, N, (int)fwd_x6_rows(M, N, 64, K), fin, stream);
+      if (rc2) return rc2;
+      stats_done = true;
+    }
   }
   MMG_CHECK_LAUNCH("linear_fwd");
   if (col_sums && !stats_done) {          // small-M / fp32 kernels: a separate pass over Y
