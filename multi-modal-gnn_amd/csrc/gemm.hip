@@ -8,8 +8,7 @@
 //
 // linear_fwd : Y[M,N] = prologue(X)[M,K] . W[N,K]^T + b.  The W pieces stay resident in registers; X tiles are
 //              prologue'd and split ONCE while staged to three bf16 LDS planes (double-buffered, one barrier per
-//              32-row tile).  k_linear_small serves the vocab-side tables (M <= 512); k_linear_fwd (fp32 MFMA,
-//              v_mfma_f32_32x32x2_f32) remains for the one shape the split kernel has no instance for (K = 256, N = 64).
+//              32-row tile).  k_linear_small serves the vocab-side tables (M <= 512).
 // linear_wgrad: dW[N,K] = dY^T . prologue(X): contraction over the rows; every workgroup reduces a set of 32-row
 //              stages into a [TN,TK] register tile, writes one partial slab, a second kernel sums the slabs in
 //              fixed order (bitwise reproducible).  The bias gradient (column sums of dY) rides in the same pass.
@@ -19,126 +18,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int BM = 64;
-
-// Y tile = 64 rows x (64*NTW) columns per workgroup; 4 waves as 2(M) x 2(N).
-// The W fragments live in REGISTERS for the whole kernel (lane (c=l&31, h=l>>5) of an N-tile holds
-// W[col c][k in h*K/2 ..]), so LDS only carries the streamed X tile (34 KB at K=128): two workgroups
-// fit per CU and one stages its next tile while the other issues MFMAs.  The next X tile is fetched
-// into registers one tile ahead.
-template <int K, int NTW, int OCC, int PF>
-__global__ __launch_bounds__(256, OCC) void k_linear_fwd(const float* __restrict__ X, ProDev pr,
-                                                       const float* __restrict__ W, const float* __restrict__ bias,
-                                                       float* __restrict__ Y, int64_t M, int N, int flags) {
-  pr.resolve();
-  const int accumulate = flags & MMG_LIN_ACCUMULATE;
-  constexpr int LDK = K + 4;            // row stride (floats): shifts rows by one 16-B slot
-  constexpr int BN = 64 * NTW;
-  __shared__ __attribute__((aligned(16))) float Xs[BM * LDK];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int h = lane >> 5, l31 = lane & 31;
-  const int n0 = blockIdx.x * BN + wn * (32 * NTW);
-
-  // ---- W fragments: wr[nt][s] = W[n0 + nt*32 + l31][h*K/2 + s]
-  float wr[NTW][K / 2];
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    if (flags & MMG_LIN_W_KN) {
-      const float* wp = W + (size_t)(h * (K / 2)) * N + n0 + nt * 32 + l31;
-#pragma unroll
-      for (int s = 0; s < K / 2; ++s) wr[nt][s] = wp[(size_t)s * N];
-    } else {
-      const float* wp = W + (size_t)(n0 + nt * 32 + l31) * K + h * (K / 2);
-#pragma unroll
-      for (int q = 0; q < K / 8; ++q) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(wp + q * 4);
-        wr[nt][q * 4 + 0] = w[0]; wr[nt][q * 4 + 1] = w[1]; wr[nt][q * 4 + 2] = w[2]; wr[nt][q * 4 + 3] = w[3];
-      }
-    }
-  }
-  float bv[NTW];
-#pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) bv[nt] = bias ? bias[n0 + nt * 32 + l31] : 0.f;
-
-  // per-thread prologue constants: this thread always touches the same 4 k's
-  constexpr int K4 = K / 4;
-  const int kc4 = tid % K4;               // float4 column
-  constexpr int ROWS_PER_PASS = 256 / K4; // rows covered by one pass of the workgroup
-
-  const int64_t n_tiles = (M + BM - 1) / BM;
-  constexpr int NP = BM / ROWS_PER_PASS;   // 16-B loads per thread per tile
-  const int prow = tid / K4;
-  f32x4 nx[NP];                            // next tile, raw
-  auto fetch = [&](int64_t tile) {
-    const int64_t row0 = tile * BM;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int64_t gr = row0 + p * ROWS_PER_PASS + prow;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      nx[p] = gr < M ? *reinterpret_cast<const f32x4*>(X + (size_t)gr * K + kc4 * 4) : z;
-    }
-  };
-  if (PF && (int64_t)blockIdx.y < n_tiles) fetch(blockIdx.y);
-  for (int64_t t = blockIdx.y; t < n_tiles; t += gridDim.y) {
-    const int64_t row0 = t * BM;
-    if (!PF) fetch(t);   // no register prefetch: a second resident workgroup hides the latency instead
-    __syncthreads();   // previous tile's MFMA reads are done
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int r = p * ROWS_PER_PASS + prow;
-      const int64_t gr = row0 + r;
-      f32x4 v = nx[p];
-      if (gr < M && (pr.scale || pr.relu || pr.p > 0.f)) {
-        // scale/shift are re-read per tile (L1-resident): keeps 8 VGPRs out of the MFMA loop's live set
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (pr.scale) {
-          sc = *reinterpret_cast<const f32x4*>(pr.scale + kc4 * 4);
-          sh = *reinterpret_cast<const f32x4*>(pr.shift + kc4 * 4);
-        }
-        mmg_pro_apply4(pr, v, sc, sh, gr, kc4 * 4, K);
-      }
-      *reinterpret_cast<f32x4*>(Xs + r * LDK + kc4 * 4) = v;
-    }
-    __syncthreads();
-    if (PF && t + gridDim.y < n_tiles) fetch(t + gridDim.y);
-
-    f32x16 acc[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
-
-    const float* ap = Xs + (wm * 32 + l31) * LDK + h * (K / 2);
-#pragma unroll
-    for (int q = 0; q < K / 8; ++q) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ap + q * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wr[nt][q * 4 + j], acc[nt], 0, 0, 0);
-    }
-
-    // ---- epilogue: C/D map col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const int col = n0 + nt * 32 + l31;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int64_t gr = row0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (gr < M) {
-          float* dst = Y + (size_t)gr * N + col;
-          float v = acc[nt][i] + bv[nt];
-          if (accumulate) v += *dst;
-          *dst = v;
-        }
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------- fp32 GEMM on the bf16 matrix cores
 // An fp32 value is EXACTLY hi + mid + lo with three bf16 pieces (8 significant bits each), so
@@ -213,7 +92,7 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
   if (PRO) pr.resolve();
   double cs1 = 0.0, cs2 = 0.0;          // column statistics of the output (BatchNorm batch stats) ride along: lane = column
   constexpr int LDP = K + 8;            // plane row stride in bf16 (K*2 + 16 bytes: fragment reads hit 64 distinct banks)
-  constexpr int BN = 32 * WN, NK = K / 16, NTHR = 64 * WN, BM = 32;   // BM shadows the file-level tile height
+  constexpr int BN = 32 * WN, NK = K / 16, NTHR = 64 * WN, BM = 32;
   extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -1519,20 +1398,6 @@ WgradPlan plan_wgrad(int64_t M, int N, int K) {
   p.n_split = (int)((M + rps - 1) / rps);
   if (p.n_split < 1) p.n_split = 1;
   return p;
-}
-
-template <int K, int NTW, int OCC, int PF>
-int launch_fwd(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
-               int accumulate, hipStream_t st) {
-  constexpr int BN = 64 * NTW;
-  const int n_slices = N / BN;
-  const int64_t n_tiles = (M + BM - 1) / BM;
-  int64_t gy = (OCC * 256) / n_slices;    // OCC resident workgroups per CU, persistent over the row tiles
-  if (gy < 1) gy = 1;
-  if (gy > n_tiles) gy = n_tiles;
-  hipLaunchKernelGGL((k_linear_fwd<K, NTW, OCC, PF>), dim3((unsigned)n_slices, (unsigned)gy), dim3(256), 0, st, X, pr, W, bias,
-                     Y, M, N, accumulate);
-  return 0;
 }
 
 template <int K>
