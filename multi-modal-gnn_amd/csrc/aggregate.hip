@@ -732,6 +732,380 @@ int launch_scatter_strip(const RelPack& rp, int64_t n_rows, int D, int n_ranges,
   return MMG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT, diagnostic builds only (-DMMG_SR_ABL=<bits>, profiles/probes/scatter_ab.sh; the shipped library does not
+// contain it): a role-specialised form of the strip kernel, built to find out whether a different decomposition of the
+// dense-indicator product reaches half of the HBM roofline.  It does not: see DESIGN section 5,
+// "Round 3, third session" and profiles/probes/scatter_roles_mi355x.log.  bits: 1 no bit-plane loads, 2 no x loads, 4 one
+// matrix instruction per pass, 8 no main loop, 16 k_scatter_strip2 instead (the shipped kernel, as the reference line),
+// 1024 / 2048 four / two k-steps of x in flight, 4096 non-temporal x loads, 8192 (with 2) x loads issued and never
+// used, 16384 two f16 pieces of 256 x instead of three bf16 pieces.
+#ifdef MMG_SR_ABL
+// k_scatter_roles<NT>: the same strip with the two kinds of work on two KINDS of wave.  In k_scatter_strip / strip2 every wave
+// loads x, splits it, expands its indicator fragments and multiplies, and the time of a k-step is close to the SUM of its
+// matrix and vector issue: a wave's own vector work hides behind its matrix instructions only two or
+// three instructions at a time.  Here waves 0..3 (one per SIMD) ONLY multiply: per k-step 3 x NT matrix instructions, NT
+// table reads for the next fragments (one behind each matrix instruction of the third pass), one vector instruction per
+// tile; their operands arrive through LDS.  Waves 4..7 (wave w + 4 shares the SIMD of wave w) ONLY produce: they stream x
+// (ring of 8 k-steps, 6 in flight), split it into the three bf16 pieces in the MFMA B layout (the lane that loads a
+// column is the lane that multiplies it: ds_write_b128 / ds_read_b128 at lane * 16, no conflicts) and pass the bit-plane
+// words of each 64-row stage on (8 k-steps ahead of their use).  One workgroup barrier per k-step, placed in the
+// multipliers BETWEEN their second and third pass over the tiles: the operand reads of the next k-step were issued two
+// passes earlier (nothing to wait for), and the table reads of the third pass stay in flight across the iteration
+// boundary.  Measured on the way (profiles/probes/scatter_ab.sh, x100 eICU shape): the producer's vector work hides behind
+// the partner's matrix instructions ONLY as plain vector instructions -- with v_pk_add_f32 / v_cvt_pk_bf16_f32 in the
+// split the two waves' times add up (42.9 us without loads), with the truncating split below (v_and / v_sub / v_perm)
+// they overlap (33.4 us).  The pieces differ from k_scatter_strip's (truncated, not rounded), their sum is x either way.
+constexpr float SR_F16_SCALE = 256.f;    // the f16 experiment: X = 256 x (|x| < 255.9)
+constexpr int SR_AHEAD = (MMG_SR_ABL & 2048) ? 2 : ((MMG_SR_ABL & 1024) ? 4 : 6), SR_RING = 8;
+template <int NT> struct SrLds {
+  static constexpr int B_BYTES = 3 * 64 * 16;             // one k-step of B pieces
+  static constexpr int W_BYTES = NT * 64 * 8;             // one stage of bit-plane words (lane-major per tile)
+  static constexpr int PAIR = 2 * (B_BYTES + W_BYTES);    // both double-buffered
+  static constexpr int RED = 4 * ST_TP * 16 * 64 * 4;     // the final cross-wave sum (aliases the pair buffers)
+  static constexpr int TOTAL = 4 * PAIR > RED ? 4 * PAIR : RED;
+};
+
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+// the three bf16 pieces of 8 values by TRUNCATION (upper 16 bits of a, of a - hi, of a - hi - mid: each exactly a bf16,
+// their sum is a): v_perm / v_and / v_sub only.  Element j of a piece sits in half j & 1 of dword j / 2 = the MFMA
+// operand order.
+__device__ __forceinline__ void split8_tr(const float* v, u32x4s& p0, u32x4s& p1, u32x4s& p2) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * j]), a1 = __builtin_bit_cast(unsigned, v[2 * j + 1]);
+    p0[j] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    const float r0 = v[2 * j] - __builtin_bit_cast(float, a0 & 0xFFFF0000u);
+    const float r1 = v[2 * j + 1] - __builtin_bit_cast(float, a1 & 0xFFFF0000u);
+    const unsigned b0 = __builtin_bit_cast(unsigned, r0), b1 = __builtin_bit_cast(unsigned, r1);
+    p1[j] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    const float s0 = r0 - __builtin_bit_cast(float, b0 & 0xFFFF0000u);
+    const float s1 = r1 - __builtin_bit_cast(float, b1 & 0xFFFF0000u);
+    p2[j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+  }
+}
+
+// TWO f16 pieces of 8 scaled values (hi = f16(X), lo = f16(X - hi): 22 significant bits, relative error <= 2^-22 while
+// 2^-3 <= |X| < 65504; below that the residual is an f16 denormal, absolute error 2^-25)
+typedef _Float16 f16x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8_h(const float* v, float scale, u32x4s& p0, u32x4s& p1) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a0 = v[2 * j] * scale, a1 = v[2 * j + 1] * scale;
+    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
+    const f16x2s hh = {h0, h1}, ll = {l0, l1};
+    p0[j] = __builtin_bit_cast(unsigned, hh); p1[j] = __builtin_bit_cast(unsigned, ll);
+  }
+}
+
+template <int NT, bool F16>
+__device__ __forceinline__ void roles_producer(const RelPack& rp, int64_t n_rows, int n_stage_total, int D,
+                                               const float* __restrict__ x, int s_beg, int ns, int G, unsigned char* pl) {
+  using L = SrLds<NT>;
+  const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+  const int d0 = blockIdx.y * 32;
+  const int64_t r_beg = (int64_t)s_beg * SB_SR;
+  int64_t rows_here = n_rows - r_beg;
+  if (rows_here > (int64_t)ns * SB_SR) rows_here = (int64_t)ns * SB_SR;
+  if (rows_here < 0) rows_here = 0;
+  const float* xw = x + (size_t)(rows_here > 0 ? r_beg : 0) * D + d0;
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(xw), 0, rows_here > 0 ? (int)((rows_here * D - d0) * 4) : 0, 0x00020000);
+  // x: lane (r = lane / 8, c = lane % 8) loads 16 bytes of row r and of row r + 8 of the k-step (two instructions per
+  // k-step instead of eight dword loads: the texture addresser takes a wave instruction per ~16 cycles whatever its
+  // width, and with 8 + 9 loads per k-step and wave it, not HBM, paced the kernel; 64 loads in flight also saturate vmcnt)
+  const unsigned row_bytes = (unsigned)D * 4u;
+  const unsigned voff0 = (unsigned)(lane >> 3) * row_bytes + (unsigned)(lane & 7) * 16u;
+  float xq[SR_RING][8];
+  auto loadx = [&](int kg, float* dst) {
+    const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
+    if (MMG_SR_ABL & 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = __builtin_bit_cast(float, vo + j);
+      if (MMG_SR_ABL & 8192) {                         // the loads are issued, nothing waits for them
+        f32x4s t0, t1;
+        asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen"
+                     : "=&v"(t0), "=&v"(t1) : "v"(vo), "s"(xsrc), "s"(8 * row_bytes));
+      }
+      return;
+    }
+    // (bit-cast to a FLOAT vector: cast to an unsigned ext_vector, this clang narrows the load to one dword and splats it)
+    const f32x4s a = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(xsrc, vo, 0, (MMG_SR_ABL & 4096) ? 2 : 0));
+    const f32x4s b = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(xsrc, vo, 8 * row_bytes, (MMG_SR_ABL & 4096) ? 2 : 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dst[j] = a[j]; dst[4 + j] = b[j]; }
+  };
+#pragma unroll
+  for (int q = 0; q < SR_RING; ++q) loadx(q, xq[q]);
+  // Bit-plane rows of this lane's items: the relations are packed back to back (a tile may straddle two of them), so
+  // every lane has its own pointer and stage stride per tile.  A lane without an item reads some valid word and drops
+  // it (lm) when the word goes to LDS.
+  const uint64_t* mb[NT];
+  unsigned ms[NT], lm[NT];
+  const uint64_t* any_mask = nullptr;
+#pragma unroll
+  for (int r = 0; r < MMG_MAX_REL; ++r)
+    if (r < rp.n && rp.r[r].mask && !any_mask) any_mask = rp.r[r].mask;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    mb[t] = any_mask; ms[t] = 0; lm[t] = 0u;
+    const int it = t * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < MMG_MAX_REL; ++r) {
+      if (r >= rp.n) continue;
+      const int padc = (rp.r[r].n_cols + 31) & ~31;
+      if (rp.r[r].mask && it >= rp.r[r].acc_off && it < rp.r[r].acc_off + rp.r[r].n_cols) {
+        mb[t] = rp.r[r].mask + (size_t)(it - rp.r[r].acc_off) * 2 + h;
+        ms[t] = 2u * (unsigned)padc; lm[t] = ~0u;
+      }
+    }
+  }
+  auto loadm = [&](int s, uint64_t* dst) {             // stage s of this pair, clamped to the planes (x reads as 0 past the end)
+    int sc = s_beg + s;
+    sc = sc < n_stage_total ? sc : n_stage_total - 1;
+    if (MMG_SR_ABL & 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) dst[t] = (uint64_t)((unsigned)(sc * 16 + t * 48 + lane * 16) & 0xFF0u) * 0x0001000100010001ull;
+      return;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) dst[t] = mb[t][(size_t)sc * ms[t]];
+  };
+  auto storem = [&](const uint64_t* w, int buf) {      // a stage's words, lane-major per tile
+    unsigned char* wb = pl + 2 * L::B_BYTES + buf * L::W_BYTES + lane * 8;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const u32x2s q = {(unsigned)w[t] & lm[t], (unsigned)(w[t] >> 32) & lm[t]};
+      *reinterpret_cast<u32x2s*>(wb + t * 512) = q;
+    }
+  };
+  uint64_t mw[2][NT];
+  loadm(0, mw[0]);
+  loadm(1, mw[1]);
+  // one k-step: the pieces of x -> B[buf], ROW-major ([piece][16 rows][32 columns] bf16, 64-byte rows): this lane's 4 + 4
+  // values are 8 bytes of row r and of row r + 8; the multipliers fetch their column slices with the transposing read
+  auto produce = [&](const float* xs, int buf) {
+    u32x4s b[3];
+    if (F16) split8_h(xs, SR_F16_SCALE, b[0], b[1]);
+    else split8_tr(xs, b[0], b[1], b[2]);
+    unsigned char* bb = pl + buf * L::B_BYTES + lane * 8;
+#pragma unroll
+    for (int p = 0; p < (F16 ? 2 : 3); ++p) {
+      const u32x2s lo = {b[p][0], b[p][1]}, hi = {b[p][2], b[p][3]};
+      *reinterpret_cast<u32x2s*>(bb + p * 1024) = lo;
+      *reinterpret_cast<u32x2s*>(bb + p * 1024 + 512) = hi;
+    }
+  };
+  storem(mw[0], 0);
+  loadm(2, mw[0]);
+  produce(xq[0], 0);
+  produce(xq[1], 1);
+  if (MMG_SR_ABL & 8) G = 0;
+  __syncthreads();                                     // (A) k-steps 0 and 1 and the words of stage 0 are in LDS
+  __syncthreads();                                     // (B) the multipliers hold k-step 0: its buffer may be rewritten
+  // iteration g produces k-step g + 2; the first k-step of stage s (g = 4 s - 2) takes the stage's words along, and the
+  // register slot (s & 1) is refilled with stage s + 2 at once: 8 k-steps of lead
+  for (int u = 0; u < G; u += SR_RING) {
+#pragma unroll
+    for (int ks = 0; ks < SR_RING; ++ks) {
+      if (u + ks >= G) break;
+      if ((ks & 3) == 2) {
+        const int s = (u + ks + 2) >> 2;               // 2 (u / 8) + 1 or + 2
+        storem(mw[((ks + 2) >> 2) & 1], ((ks + 2) >> 2) & 1);
+        loadm(s + 2, mw[((ks + 2) >> 2) & 1]);
+      }
+      produce(xq[(ks + 2) & (SR_RING - 1)], ks & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      loadx(u + ks + 2 + SR_AHEAD, xq[(ks + 2 + SR_AHEAD) & (SR_RING - 1)]);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    }
+  }
+  if (MMG_SR_ABL & 8192) asm volatile("s_waitcnt vmcnt(0)");
+}
+
+template <int NT, bool F16>
+__device__ __forceinline__ void roles_multiplier(const unsigned (*lut)[4], int G, const unsigned char* pl, f32x16* acc) {   // (G by value: an ablation build zeroes it)
+  using L = SrLds<NT>;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // B fragment (rows 8 h .. 8 h + 7 of column n = lane % 32) from the row-major image: ds_read_b64_tr_b16 hands a 16-lane
+  // group a block of 4 rows x 16 columns, lane 4 q + p supplying the address of row q, columns 4 p .. 4 p + 3
+  const int grp = lane >> 4, gi = lane & 15;
+  const unsigned char* bb = pl + (8 * (grp >> 1) + (gi >> 2)) * 64 + (16 * (grp & 1) + 4 * (gi & 3)) * 2;
+  const unsigned char* wb = pl + 2 * L::B_BYTES + lane * 8;
+  const unsigned char* lutb = reinterpret_cast<const unsigned char*>(&lut[0][0]);
+  bf16x8 af[NT], bc[3], bn[3];
+  u32x2s mwd[2][NT];                                   // the bit-plane words of the stage, slot = stage & 1
+  auto read_b = [&](int buf, bf16x8* b) {
+    typedef short s16x4s __attribute__((ext_vector_type(4)));
+    typedef short s16x8s __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int p = 0; p < (F16 ? 2 : 3); ++p) {
+      const unsigned char* q = bb + buf * L::B_BYTES + p * 1024;
+      const s16x4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4s*)q);
+      const s16x4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4s*)(q + 256));
+      const s16x8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      b[p] = __builtin_bit_cast(bf16x8, v);
+    }
+  };
+  auto read_w = [&](int buf, u32x2s* w) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const u32x2s*>(wb + buf * L::W_BYTES + t * 512);
+  };
+  // field kq (k-step inside the stage) of a word = (8 patient bits) << 4 = the byte offset of the table entry
+  auto frag = [&](const u32x2s* w, int kq, int t) -> bf16x8 {
+    const unsigned d = w[t][(kq >> 1) & 1];
+    const unsigned off = (kq & 1) ? (d >> 16) : (d & 0xFFFFu);
+    return *reinterpret_cast<const bf16x8*>(lutb + off);
+  };
+  if (MMG_SR_ABL & 8) G = 0;
+  __syncthreads();                                     // (A)
+  read_b(0, bc);
+  read_w(0, mwd[0]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) af[t] = frag(mwd[0], 0, t);
+  __syncthreads();                                     // (B) (its lgkmcnt(0): k-step 0 has left LDS)
+  for (int u = 0; u < G; u += 8) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (u + ks >= G) break;
+      constexpr int dummy = 0; (void)dummy;
+      const int sn = ((ks + 1) >> 2) & 1;              // slot of the stage of k-step g + 1
+      read_b((ks + 1) & 1, bn);                        // k-step g + 1 (written one barrier ago or earlier)
+      if ((ks & 3) == 3) read_w(sn, mwd[sn]);          // ... opens a stage: its words (written five barriers ago)
+      typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+      auto mma = [&](int t, int p) {
+        if ((MMG_SR_ABL & 4) && t != 0) return;
+        if (F16) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, af[t]), __builtin_bit_cast(f16x8s, bc[p]), acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bc[p], acc[t], 0, 0, 0);
+      };
+      constexpr int NP = F16 ? 2 : 3, NRD = 2 * NP;    // passes over the tiles; LDS reads of a k-step's pieces
+#pragma unroll
+      for (int p = 0; p < NP - 1; ++p)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mma(t, p);
+      // one LDS read behind each of the first matrix instructions (a cluster of reads in front of them stalls the
+      // in-order wave on the LDS queue)
+#pragma unroll
+      for (int i = 0; i < (NP - 1) * NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < NRD + ((ks & 3) == 3 ? NT : 0)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, NRD + NT, 0);    // (what did not fit behind the first pass of the f16 form)
+      __builtin_amdgcn_sched_barrier(0);               // (matrix instructions are not memory operations: unpinned, the
+      __syncthreads();                                 //  barrier and its wait rise to the top of the iteration)
+      __builtin_amdgcn_sched_barrier(0);               // operands of g + 1 are in registers: the producer may rewrite them
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        mma(t, NP - 1);
+        af[t] = frag(mwd[sn], (ks + 1) & 3, t);        // the tile's fragment of k-step g + 1, in flight across the back edge
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
+    }
+  }
+}
+
+template <int NT, bool F16>
+__global__ __launch_bounds__(512) void k_scatter_roles(RelPack rp, int64_t n_rows, int n_stage_total, int D, int total_pad,
+                                                       const float* __restrict__ x, float* __restrict__ slab) {
+  __shared__ __attribute__((aligned(16))) unsigned lut[256][4];            // byte -> 8 bf16 in {0, 1}
+  extern __shared__ __attribute__((aligned(16))) unsigned char sr_lds[];   // 4 pair buffers, later [4][ST_TP * 16][64] floats
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31, w4 = wid & 3;
+  const int d0 = blockIdx.y * 32;
+  if (tid < 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      lut[tid][q] = ((tid >> (2 * q)) & 1 ? (F16 ? 0x3C00u : 0x3F80u) : 0u) | ((tid >> (2 * q + 1)) & 1 ? (F16 ? 0x3C000000u : 0x3F800000u) : 0u);
+  }
+  // 64-row stages dealt over (workgroup, pair): pair q takes base (+ 1 for the first rem pairs); G = the k-steps of the
+  // longest share of this workgroup (every wave runs G barriers).  Scalar on purpose: a share that reaches the per-lane
+  // pointer set-up in a vector register makes every buffer descriptor derived from it "divergent" (waterfall loops).
+  const unsigned n_q = gridDim.x * 4u;
+  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)n_stage_total / n_q), rem = (unsigned)n_stage_total - base * n_q;
+  const unsigned q_id = blockIdx.x * 4u + (unsigned)w4;
+  const int G = 4 * (int)(base + (blockIdx.x * 4u < rem ? 1u : 0u));
+  const int s_beg = __builtin_amdgcn_readfirstlane((int)(q_id * base + (q_id < rem ? q_id : rem)));
+  const int ns = __builtin_amdgcn_readfirstlane((int)(base + (q_id < rem ? 1u : 0u)));
+  unsigned char* pl = sr_lds + w4 * SrLds<NT>::PAIR;
+  float* st_red = reinterpret_cast<float*>(sr_lds);
+  float* dst = slab + (size_t)blockIdx.x * total_pad * D + d0 + l31;
+  auto sum_store = [&](int t_first, int ntp) {         // every wave sums an eighth of the parked registers over the four pairs
+    const int nreg = ntp * 16;
+    for (int idx = wid * nreg / 8; idx < (wid + 1) * nreg / 8; ++idx) {
+      float v = st_red[((size_t)0 * ST_TP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)1 * ST_TP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)2 * ST_TP * 16 + idx) * 64 + lane];
+      v += st_red[((size_t)3 * ST_TP * 16 + idx) * 64 + lane];
+      const int i = idx & 15;
+      const int vrow = (t_first + (idx >> 4)) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      dst[(size_t)vrow * D] = v;
+    }
+  };
+#ifdef MMG_STAMPS
+#define SR_STAMP(i) do { if (lane == 0 && wid < 4) { \
+    g_stamps[(size_t)(blockIdx.y * gridDim.x * 4 + blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    g_stamps[(size_t)(blockIdx.y * gridDim.x * 4 + blockIdx.x * 4 + wid) * 8 + 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define SR_STAMP(i) do { } while (0)
+#endif
+  SR_STAMP(0);
+  __syncthreads();                                     // the table
+  if (wid >= 4) {
+    roles_producer<NT, F16>(rp, n_rows, n_stage_total, D, x, s_beg, ns, G, pl);
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += ST_TP) {
+      __syncthreads();                                 // the pair buffers (or the previous phase) are dead
+      __syncthreads();                                 // parked
+      sum_store(t0, (NT - t0) < ST_TP ? (NT - t0) : ST_TP);
+    }
+  } else {
+    f32x16 acc[NT];
+    SR_STAMP(1);
+    roles_multiplier<NT, F16>(lut, G, pl, acc);
+    SR_STAMP(2);
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += ST_TP) {
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < ST_TP; ++t)
+        if (t0 + t < NT) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) st_red[((size_t)w4 * ST_TP * 16 + t * 16 + i) * 64 + lane] = F16 ? acc[t0 + t][i] * (1.f / SR_F16_SCALE) : acc[t0 + t][i];
+        }
+      __syncthreads();
+      sum_store(t0, (NT - t0) < ST_TP ? (NT - t0) : ST_TP);
+    }
+    SR_STAMP(3);
+  }
+}
+
+template <int NT, bool F16>
+int launch_scatter_roles(const RelPack& rp, int64_t n_rows, int D, int n_ranges, int total_pad, const float* x, float* slab,
+                         hipStream_t st) {
+  constexpr int lds = SrLds<NT>::TOTAL;
+  MMG_CHECK_HIP((MmgMaxLds<&k_scatter_roles<NT, F16>, lds>::set()), "scatter_rows(attr)");
+  const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
+  MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, total_pad, 0, (k_scatter_roles<NT, F16>),
+             dim3((unsigned)n_ranges, (unsigned)(D / 32)), dim3(512), lds, st, rp, n_rows, nst, D, total_pad, x, slab);
+  return MMG_OK;
+}
+
+#endif   // MMG_SR_ABL
+
 // strip plan: instance (padded tile count) and number of row ranges; ok = false -> k_scatter_units / fp32 kernels
 struct StripPlan { bool ok; int nt; int n_ranges; int total_pad; };
 StripPlan plan_strip(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
@@ -1808,6 +2182,10 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     if (rc3) return rc3;
     if (sp.nt == 4) rc2 = launch_scatter_strip<4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     else if (sp.nt == 8) rc2 = launch_scatter_strip<8>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+#ifdef MMG_SR_ABL
+    else if (sp.nt == 9 && !(MMG_SR_ABL & 16) && (MMG_SR_ABL & 16384)) rc2 = launch_scatter_roles<9, true>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else if (sp.nt == 9 && !(MMG_SR_ABL & 16)) rc2 = launch_scatter_roles<9, false>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+#endif
     else if (sp.nt == 9) rc2 = launch_scatter_strip2<5, 4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     else rc2 = launch_scatter_strip<10>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     if (rc2) return rc2;
