@@ -364,6 +364,34 @@ __device__ inline void split8(const float* v, bf16x8& p0, bf16x8& p1, bf16x8& p2
   }
 }
 
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+// the three bf16 pieces of 8 values by TRUNCATION (upper 16 bits of a, of a - hi, of a - hi - mid: each exactly a bf16,
+// their sum is a): v_perm / v_and / v_sub only.  Element j of a piece sits in half j & 1 of dword j / 2 = the MFMA
+// operand order.
+__device__ __forceinline__ void split8_tr(const float* v, u32x4s& p0, u32x4s& p1, u32x4s& p2) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * j]), a1 = __builtin_bit_cast(unsigned, v[2 * j + 1]);
+    p0[j] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    const float r0 = v[2 * j] - __builtin_bit_cast(float, a0 & 0xFFFF0000u);
+    const float r1 = v[2 * j + 1] - __builtin_bit_cast(float, a1 & 0xFFFF0000u);
+    const unsigned b0 = __builtin_bit_cast(unsigned, r0), b1 = __builtin_bit_cast(unsigned, r1);
+    p1[j] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    const float s0 = r0 - __builtin_bit_cast(float, b0 & 0xFFFF0000u);
+    const float s1 = r1 - __builtin_bit_cast(float, b1 & 0xFFFF0000u);
+    p2[j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
+  }
+}
+
+// (the scatter kernels' split since round 3: 44 plain vector instructions per 8 values instead of 56 with conversions;
+//  same-box A/B 44.9 -> 44.4 us without, 55.7 -> 54.4 us with a rowscale)
+__device__ inline void split8x(const float* v, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
+  u32x4s q0, q1, q2;
+  split8_tr(v, q0, q1, q2);
+  p0 = __builtin_bit_cast(bf16x8, q0); p1 = __builtin_bit_cast(bf16x8, q1); p2 = __builtin_bit_cast(bf16x8, q2);
+}
+
 // k_scatter_strip: the workgroup owns a 32-column STRIP of x for a range of rows; its four waves (one per SIMD: the
 // accumulators of ALL item tiles stay in one wave's registers, so x is split into its bf16 pieces exactly once) take a
 // quarter of those rows each and their partial accumulators are summed through LDS in fixed order at the end, so ONE
@@ -479,7 +507,7 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
     bf16x8 afc[NT], bc[3];
     make_af(mc, 0, afc);
-    split8(xq[0], bc[0], bc[1], bc[2]);
+    split8x(xq[0], bc[0], bc[1], bc[2]);
     MMG_STAMP(2);
 
     const int n2 = (ns + 1) / 2;
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
         __builtin_amdgcn_sched_barrier(0);             // keep the run-ahead: the scheduler would sink these loads
         bf16x8 afn[NT], bn[3];
         make_af((ks & 3) == 3 ? mn : mc, (ks + 1) & 3, afn);
-        split8(xq[(ks + 1) & (RING - 1)], bn[0], bn[1], bn[2]);
+        split8x(xq[(ks + 1) & (RING - 1)], bn[0], bn[1], bn[2]);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -619,7 +647,7 @@ __device__ __forceinline__ void strip_main(const RelPack& rp, int64_t n_rows, in
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the loop is entered with no load in flight
   bf16x8 afc[NT], bc[3];
   make_af(mc, 0, afc);
-  split8(xq[0], bc[0], bc[1], bc[2]);
+  split8x(xq[0], bc[0], bc[1], bc[2]);
   const int n2 = (ns + 1) / 2;
   for (int u = 0; u < n2; ++u) {
 #pragma unroll
@@ -629,7 +657,7 @@ __device__ __forceinline__ void strip_main(const RelPack& rp, int64_t n_rows, in
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 afn[NT], bn[3];
       make_af((ks & 3) == 3 ? mn : mc, (ks + 1) & 3, afn);
-      split8(xq[(ks + 1) & (RING - 1)], bn[0], bn[1], bn[2]);
+      split8x(xq[(ks + 1) & (RING - 1)], bn[0], bn[1], bn[2]);
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -765,26 +793,6 @@ template <int NT> struct SrLds {
   static constexpr int RED = 4 * ST_TP * 16 * 64 * 4;     // the final cross-wave sum (aliases the pair buffers)
   static constexpr int TOTAL = 4 * PAIR > RED ? 4 * PAIR : RED;
 };
-
-typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
-// the three bf16 pieces of 8 values by TRUNCATION (upper 16 bits of a, of a - hi, of a - hi - mid: each exactly a bf16,
-// their sum is a): v_perm / v_and / v_sub only.  Element j of a piece sits in half j & 1 of dword j / 2 = the MFMA
-// operand order.
-__device__ __forceinline__ void split8_tr(const float* v, u32x4s& p0, u32x4s& p1, u32x4s& p2) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const unsigned a0 = __builtin_bit_cast(unsigned, v[2 * j]), a1 = __builtin_bit_cast(unsigned, v[2 * j + 1]);
-    p0[j] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-    const float r0 = v[2 * j] - __builtin_bit_cast(float, a0 & 0xFFFF0000u);
-    const float r1 = v[2 * j + 1] - __builtin_bit_cast(float, a1 & 0xFFFF0000u);
-    const unsigned b0 = __builtin_bit_cast(unsigned, r0), b1 = __builtin_bit_cast(unsigned, r1);
-    p1[j] = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-    const float s0 = r0 - __builtin_bit_cast(float, b0 & 0xFFFF0000u);
-    const float s1 = r1 - __builtin_bit_cast(float, b1 & 0xFFFF0000u);
-    p2[j] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, s1), __builtin_bit_cast(unsigned, s0), 0x07060302u);
-  }
-}
 
 // TWO f16 pieces of 8 scaled values (hi = f16(X), lo = f16(X - hi): 22 significant bits, relative error <= 2^-22 while
 // 2^-3 <= |X| < 65504; below that the residual is an f16 denormal, absolute error 2^-25)
@@ -1234,9 +1242,9 @@ __device__ __forceinline__ void scatter_unit_body(const ScUnits& su, const RelPa
         float v[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = xq[kq][j] * s0[j]; v[4 + j] = xq[kq][4 + j] * s1[j]; }
-        split8(v, b0, b1, b2);
+        split8x(v, b0, b1, b2);
       } else {
-        split8(xq[kq], b0, b1, b2);
+        split8x(xq[kq], b0, b1, b2);
       }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
