@@ -1176,9 +1176,6 @@ __global__ __launch_bounds__(64 * WNN * WNK) void k_linear_wgrad_x6(const float*
   }
 }
 
-__device__ __forceinline__ float plain_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float plain_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-
 // Role-specialised variant for the plain (no prologue) 128 x 128 tile.  Waves 0..3 only multiply (a 64 x 64 quadrant
 // each, one wave per SIMD), waves 4..7 only stage (loads -> 3-way split -> LDS for stage s+1 while the multipliers work on
 // stage s).  The stagers transpose in registers: a stager thread owns an 8-row x 4-column block (8 coalesced 16-B loads),
@@ -1234,20 +1231,6 @@ __global__ __launch_bounds__(512) void k_linear_wgrad_ws(const float* __restrict
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const f32x4 v = f[j];                      // rows past the end arrive as zeros
-#ifdef MMG_WS_PLAIN
-        // plain (one-lane) subtractions and sums: the compiler pairs them into v_pk_add_f32, and a stager's PACKED fp32
-        // instructions do not overlap with the matrix instructions of the multiplier wave on its SIMD (DESIGN section 5,
-        // "Round 3, third session")
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bsum[e] = plain_add(bsum[e], v[e]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const __bf16 a = (__bf16)v[e];
-          const float r1 = plain_sub(v[e], (float)a);
-          const __bf16 b = (__bf16)r1;
-          q[0][e][j] = a; q[1][e][j] = b; q[2][e][j] = (__bf16)plain_sub(r1, (float)b);
-        }
-#else
         bsum += v;                                 // column sums of dY (the bias gradient); ignored by the X waves
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1256,7 +1239,6 @@ __global__ __launch_bounds__(512) void k_linear_wgrad_ws(const float* __restrict
           const __bf16 b = (__bf16)r1;
           q[0][e][j] = a; q[1][e][j] = b; q[2][e][j] = (__bf16)(r1 - (float)b);
         }
-#endif
       }
       // column c of a group sits at entry (c & ~15) | ((c / 4 + 4 (c % 4)) & 15): 16 consecutive lanes then touch 16
       // distinct 16-B bank groups both here (lane = column quad, fixed e) and in the fragment reads (lane = column)
