@@ -198,6 +198,14 @@ def load():
         raise MmgError(
             f"{LIB_PATH} not found: the HIP library is mandatory (no CPU fallback). Build it with "
             f"`make -C {os.path.join(_HERE, 'csrc')}` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # PyTorch (the package's device-memory plumbing) bundles its own HIP runtime.  It has to be in the process BEFORE this
+    # library is mapped: libmmgnn.so then binds to it; mapped first, the library pulls in /opt/rocm's runtime, PyTorch adds
+    # its own later, and the second runtime of a process sees no device ("no ROCm-capable device is detected" from the
+    # first library call -- `python __graft_entry__.py smoke`, where build() loaded the library before anything imported torch).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)     # AttributeError here = header/library mismatch
