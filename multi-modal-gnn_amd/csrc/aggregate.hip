@@ -1129,10 +1129,10 @@ StripPlan plan_strip(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
   }
   const int tiles = (items + 31) / 32;
   // (one wave holds every tile's accumulators + a double-buffered operand set: 10 tiles fill the 512 registers)
-  if (tiles == 0 || tiles > 10 || n_rows < SB_SR) return sp;
+  if (tiles == 0 || tiles > 11 || n_rows < SB_SR) return sp;
   if (has_rs) return sp;
-  const int inst[] = {4, 8, 9, 10};
-  for (int i = 0; i < 4; ++i)
+  const int inst[] = {4, 8, 9, 10, 11};                // 9 and 11 (the eICU and the MIMIC-III vocabularies): two waves per SIMD
+  for (int i = 0; i < 5; ++i)
     if (tiles <= inst[i]) { sp.nt = inst[i]; break; }
   sp.total_pad = sp.nt * 32;
   const int strips = D / 32;
@@ -2195,6 +2195,7 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     else if (sp.nt == 9 && !(MMG_SR_ABL & 16)) rc2 = launch_scatter_roles<9, false>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
 #endif
     else if (sp.nt == 9) rc2 = launch_scatter_strip2<5, 4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else if (sp.nt == 11) rc2 = launch_scatter_strip2<6, 5>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     else rc2 = launch_scatter_strip<10>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     if (rc2) return rc2;
     const int64_t n = (int64_t)sp.total_pad * D;

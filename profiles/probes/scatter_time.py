@@ -1,5 +1,5 @@
 """Stand-alone timing of mmg_scatter_rows (kernel + slab sum) on the x100 eICU-shape graph, with and without a rowscale,
-next to an fp64 index_add_ check of the same call.  Usage: python profiles/probes/scatter_time.py [scale] [D] [iters]"""
+next to an fp64 index_add_ check of the same call.  Usage: python profiles/probes/scatter_time.py [scale] [D] [iters] [eicu|mimic]"""
 import os, sys, torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
@@ -9,13 +9,14 @@ if os.environ.get("MMG_AB_LIB"):                       # an ablation build (prof
     _lib.LIB_PATH = os.path.join(REPO, os.environ["MMG_AB_LIB"])
 from mmgnn import ops
 from mmgnn.data import build_plan
-from mmgnn.synth import make_graph
+from mmgnn.synth import make_graph, EICU, MIMIC_LIKE
 
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 dev = torch.device("cuda:0")
-g = make_graph(scale, seed=0, device=dev)
+shape = MIMIC_LIKE if (len(sys.argv) > 4 and sys.argv[4] == "mimic") else EICU
+g = make_graph(scale, seed=0, device=dev, shape=shape)
 plan = build_plan(g, dev)
 P = plan.n_rows
 x = torch.randn(P, D, device=dev) * 1.5 + 0.25

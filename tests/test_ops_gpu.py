@@ -216,6 +216,31 @@ def test_aggregates_simple_graph_paths(ops, dev, D, n_rows):
         assert rel(r.out, ref) <= 1e-6
 
 
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("n_rows", [64, 1000, 5000])
+def test_scatter_rows_eleven_tiles(ops, dev, D, n_rows):
+    """The 50 / 200 / 100 vocabulary of config 5 packs into 11 item tiles: the two-wave strip kernel's <6, 5> instance
+    (forward scatter, no rowscale), against scatter_mean in fp64."""
+    gen = torch.Generator().manual_seed(11 * D + n_rows)
+    sizes, degs = [50, 200, 100], [50, 9, 25]
+    x = torch.randn(n_rows, D, generator=gen) * 2 - 0.4
+    rels, refs = [], []
+    for nc, md in zip(sizes, degs):
+        ei = simple_edges(gen, n_rows, nc, md)
+        rp, col = _csr(ops, dev, ei, n_rows)
+        cnt, cinv = ops.col_degree(col, nc)
+        mask, _ = ops.rel_mask_build(rp, col, nc)
+        rels.append(ops.Rel(rp, col, nc, colscale=cinv, out=torch.full((nc, D), 5.0, device=dev), simple=True, mask_t=mask))
+        refs.append(scatter_mean(x.double(), ei, nc))
+    ops.scatter_rows(rels, n_rows, D, x.to(dev))
+    first = [r.out.clone() for r in rels]
+    for r, ref in zip(rels, refs):
+        assert rel(r.out, ref) <= 1e-6
+    ops.scatter_rows(rels, n_rows, D, x.to(dev))
+    for r, f in zip(rels, first):
+        assert torch.equal(r.out, f)                      # fixed-order sums: bit-reproducible
+
+
 # ------------------------------------------------------------------------------------------ dense
 @pytest.mark.parametrize("M,N,K", [(1, 64, 64), (50, 128, 128), (1834, 128, 128), (1834, 64, 128), (1000, 128, 64),
                                    (777, 256, 256), (333, 64, 256), (114, 128, 128), (5000, 256, 128)])
