@@ -344,7 +344,7 @@ def agg_extra(w, D):
                 extra[("gather_rows", kg, acc)] = rel_bytes(rels, True, False) + 4 * D * P * (2 if acc else 1)
             # (the strip kernel packs the relations' items back to back: its padded row count is the instance's)
             tiles = (kg + 31) // 32
-            k_strip = next((i * 32 for i in (4, 8, 9, 10) if tiles <= i), ks)
+            k_strip = next((i * 32 for i in (4, 8, 9, 10, 11) if tiles <= i), ks)
             extra[("scatter_rows", k_strip, 0)] = rel_bytes(rels, False, True) + 4 * D * P
             extra[("scatter_rows", ks, 0)] = rel_bytes(rels, False, True) + 4 * D * P
             extra[("scatter_rows", ks, 8)] = rel_bytes(rels, True, False) + 4 * D * P
