@@ -15,6 +15,7 @@ tables and all weights are replicated.  Exchanges per step (all SUM all-reduces,
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -36,6 +37,76 @@ class ShardComm:
         self.n_calls = 0
         self.n_bytes = 0
         self.on_collective = None         # set while a step is being captured piecewise (train.PiecewiseGraphedTrainStep)
+        self._capturable = None           # capturable(): decided once, by a probe capture
+
+    # ---- recording collectives into a hipGraph
+    def backend(self) -> str:
+        return str(dist.get_backend(self.group))
+
+    def capturable(self) -> bool:
+        """True when the all-reduces of this group can be RECORDED into a hipGraph together with the kernels around them
+        (train.PiecewiseGraphedTrainStep then replays a sharded step as one launch instead of a chain of segments with
+        the collectives issued from Python between them): the RCCL backend on a HIP device, and a probe capture + replay
+        of one tiny all-reduce that went through.  Decided ONCE per ShardComm, outside any other capture;
+        MMG_CAPTURE_COLLECTIVES=0 / 1 overrides the probe's verdict."""
+        if self._capturable is None:
+            self._capturable = self._probe_capture()
+        return self._capturable
+
+    def _probe_capture(self) -> bool:
+        env = os.environ.get("MMG_CAPTURE_COLLECTIVES")
+        if env is not None and env.strip() in ("0", "1"):
+            return env.strip() == "1"
+        if self.backend() != "nccl" or not torch.cuda.is_available():
+            return False
+        try:
+            t = torch.zeros(64, device=torch.device("cuda", torch.cuda.current_device()))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.raw_all_reduce(t)                 # the communicator exists before anything is recorded
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    self.raw_all_reduce(t)
+                g.replay()
+                torch.cuda.synchronize()
+            torch.cuda.current_stream().wait_stream(side)
+            del g
+            return True
+        except Exception as e:                         # a backend that cannot record: the segment chain stays
+            import sys
+            print(f"[mmgnn.dist] collectives are not capturable here ({type(e).__name__}: {e}); using the segment chain",
+                  file=sys.stderr)
+            return False
+
+    # ---- teardown
+    def close(self, *holders, destroy: bool = True):
+        """The ONE teardown order of a sharded run (bench.py, the RCCL test, user code):
+          1. `holders` (captured steps: anything with release()) drop their hipGraphs, the all-reduce tensors of their
+             segment chain and their side-stream events -- what a step keeps alive that references the communicator;
+          2. collect garbage, synchronise the device: no replay or collective of this process is in flight;
+          3. barrier + synchronise: no OTHER rank is still inside a collective that needs this one;
+          4. destroy the process group (destroy=False: the caller keeps the group for its next measurement).
+        An abort inside destroy_process_group was seen once (world_size 1, message lost: DESIGN.md section 6, cause not
+        established); every teardown of the repo goes through here so that a recurrence has one place to be read from."""
+        for h in holders:
+            rel = getattr(h, "release", None)
+            if rel is not None:
+                rel()
+        self.on_collective = None
+        import gc
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist.is_initialized():
+            if self.world > 1:
+                dist.barrier(group=self.group)
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            if destroy:
+                g, self.group = self.group, None
+                dist.destroy_process_group(g)
 
     def raw_all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

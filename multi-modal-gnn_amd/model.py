@@ -236,6 +236,8 @@ class HeteroRGCN(nn.Module):
         cache holds the tensors, so their storage cannot be recycled under a stale entry).  head lists = the
         positions served by tabular_mlp / edge_predictor (deg[pi] < thr or not; static per pair set):
         (sel_low, sel_high, counts_dev, n_low, n_high)."""
+        if pair_ids is not None and pair_ids.numel() != pi.numel():
+            pair_ids = None     # ids of ANOTHER pair set (a shard's train-pair ids while its validation pairs are scored)
         key = (id(pi), id(li), pi._version, li._version, n_rows, id(pair_ids), id(deg), int(thr))
         hit = self._pair_cache.get(key)
         if hit is not None:

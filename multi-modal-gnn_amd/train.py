@@ -37,6 +37,21 @@ LAB_EDGE = ("patient", "has_lab", "lab")
 CAPTURE_ERROR_MODE = "thread_local"
 
 
+def capture_error_mode() -> str:
+    """Mode of the next stream capture.  `thread_local` only while a torch.distributed process group is alive -- its
+    watchdog thread is the one known source of HIP calls from another thread during a capture window; without a group
+    the default ("global") stays, so that a capture-invalidating call from ANY thread is still reported instead of
+    silently corrupting the recording.  (The SIGABRT that led here left no log -- DESIGN.md section 6 -- so the mode is
+    confined to the situation it was seen in rather than applied everywhere.)"""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return CAPTURE_ERROR_MODE
+    except Exception:
+        pass
+    return "global"
+
+
 class EdgeMasker:
     """train.py:37-176 -- edge-level 70/15/15 split (seed 42) + per-epoch supervision mask."""
 
@@ -83,12 +98,44 @@ class EdgeMasker:
         self._cache = {}
         return self
 
+    def shard(self, shard_data, keep: torch.Tensor) -> "EdgeMasker":
+        """This masker restricted to ONE patient shard of the graph it was built on (dist.shard_graph): the same 70/15/15
+        split -- every has_lab edge stays in the split the global permutation gave it -- and the same per-epoch
+        supervision subsets (the shard draws the GLOBAL mask from its equally seeded generator and keeps its own
+        positions), so that N sharded Trainers train exactly what one unsharded Trainer trains.
+        keep: bool [num_edges], the has_lab edges of the shard in their original order.  `train_pair_ids` = positions of
+        the shard's train pairs in the unsharded train-pair list (the keys of the per-pair dropout / in-step draw)."""
+        m = object.__new__(EdgeMasker)
+        m.__dict__.update(self.__dict__)
+        keep = keep.to(self.train_mask.device)
+        m.data = shard_data
+        m.edge_index = shard_data[self.edge_type].edge_index
+        m.edge_attr = shard_data[self.edge_type].edge_attr
+        m.num_edges = int(keep.sum())
+        if m.edge_index.shape[1] != m.num_edges:
+            raise ValueError("EdgeMasker.shard: `keep` does not select the shard's has_lab edges")
+        m.train_mask, m.val_mask, m.test_mask = self.train_mask[keep], self.val_mask[keep], self.test_mask[keep]
+        pos = torch.cumsum(self.train_mask.to(torch.int64), 0) - 1
+        m.train_pair_ids = pos[keep & self.train_mask].contiguous()
+        m._draw_from = (int(self.train_mask.sum()), m.train_pair_ids)
+        m._cache = {}
+        return m
+
     def draw_supervision_mask(self, n: int, device=None) -> torch.Tensor:
         """The per-epoch supervision subset of the n train edges (train.py:150-166): torch.rand(n) < mask_fraction.
         mask_generator on the CPU (or none: wall-clock seed, train.py:156) draws on the host exactly like the reference;
         a device generator draws on its device, nothing crosses PCIe."""
         if self.mask_fraction <= 0:
             return torch.ones(n, dtype=torch.bool, device=device)
+        frm = getattr(self, "_draw_from", None)
+        if frm is not None and n == frm[1].numel():        # a shard: the global draw, this shard's positions of it
+            n_all, pos = frm
+            self._draw_from = None
+            try:
+                m = self.draw_supervision_mask(n_all, device)
+            finally:
+                self._draw_from = frm
+            return m[pos.to(m.device)]
         gen = self.mask_generator
         if gen is None:
             torch.manual_seed(int(time.time()))                              # train.py:156
@@ -146,6 +193,11 @@ class Trainer:
         self.best_val_loss = float("inf")
         self.patience_counter = 0
         self.train_losses, self.val_losses = [], []
+        # patient-sharded model (dist.shard_model): this Trainer holds ONE shard of the graph; losses, lab weights and the
+        # supervision normaliser are global (summed over the group), everything else is local
+        self.comm = getattr(self.model, "_comm", None)
+        if self.comm is not None and getattr(self.comm, "pair_ids", None) is None and hasattr(masker, "train_pair_ids"):
+            self.comm.pair_ids = masker.train_pair_ids.to(device)     # per-pair dropout / in-step draw: global pair ids
         self.lab_weights = self._compute_lab_weights()
         self._pairs = {}
         # the captured device step (built at the first epoch) and the captured validation passes
@@ -186,8 +238,13 @@ class Trainer:
         v = edge_values.double()
         cnt = torch.zeros(L, dtype=torch.float64, device=v.device).index_add_(0, lab, torch.ones_like(v))
         s1 = torch.zeros(L, dtype=torch.float64, device=v.device).index_add_(0, lab, v)
+        if self.comm is not None:              # the statistics are over ALL shards' train edges
+            self.comm.raw_all_reduce(cnt)
+            self.comm.raw_all_reduce(s1)
         mean = s1 / cnt.clamp(min=1)
         s2 = torch.zeros(L, dtype=torch.float64, device=v.device).index_add_(0, lab, (v - mean[lab]) ** 2)
+        if self.comm is not None:
+            self.comm.raw_all_reduce(s2)
         var = torch.where(cnt > 1, s2 / (cnt - 1).clamp(min=1), torch.ones_like(s2))
         w = 1.0 / (var + 1e-6)
         w = w * L / w.sum()
@@ -204,14 +261,26 @@ class Trainer:
     def _device_step_ok(self) -> bool:
         from .optim import Adam
         return (self.device_step and torch.device(self.device).type == "cuda" and isinstance(self.optimizer, Adam)
-                and self.loss_fn in ("mae", "mse", "huber") and getattr(self.model, "_comm", None) is None)
+                and self.loss_fn in ("mae", "mse", "huber"))
 
     def _graph_plan(self):
         """ONE plan (CSR, bit planes, degrees) of the static graph for the captured training step and every captured
         validation pass (held here: the module-level plan cache is bounded and may decline a very large graph)."""
         if getattr(self, "_plan", None) is None:
             from .data import build_plan
-            self._plan = build_plan(self.data, self.device)
+            if self.comm is None:
+                self._plan = build_plan(self.data, self.device)
+            else:
+                # this shard of the global graph: contiguous patient ranges in rank order (dist.shard_graph records its
+                # range; otherwise the shards are taken back to back), vocab in-degrees summed over the group
+                from . import dist as mdist
+                plan = build_plan(self.data, self.device, use_cache=False)
+                sizes = torch.zeros(int(self.comm.world), dtype=torch.float64, device=self.device)
+                sizes[int(self.comm.rank)] = float(plan.n_rows)
+                self.comm.raw_all_reduce(sizes)
+                rr = getattr(self.data, "row_range", None)
+                lo = int(rr[0]) if rr is not None else int(sizes[:int(self.comm.rank)].sum().item())
+                self._plan = mdist.shard_plan(plan, self.comm, lo, int(sizes.sum().item()))
         return self._plan
 
     def _loss_slots(self):
@@ -232,9 +301,10 @@ class Trainer:
         plan = self._graph_plan()
         if len(self.model.embeddings) == 0:
             self.model._init_embeddings(self.data)
-        self._dstep = PiecewiseGraphedTrainStep(self.model, plan, pi, li, y, self.lab_weights, self.optimizer, sup0, None,
-                                                loss_fn=self.loss_fn, mask_fraction=frac if in_graph else None,
-                                                loss_out=self._loss_slots()[0])
+        self._dstep = PiecewiseGraphedTrainStep(self.model, plan, pi, li, y, self.lab_weights, self.optimizer, sup0,
+                                                self.comm, loss_fn=self.loss_fn,
+                                                mask_fraction=frac if in_graph else None, loss_out=self._loss_slots()[0],
+                                                reduce_loss=self.comm is not None)
         self._dstep_injects = frac > 0 and not in_graph
 
     def _train_epoch_device(self) -> torch.Tensor:
@@ -252,7 +322,8 @@ class Trainer:
         if ev is None:
             from .data import build_plan
             pi, li, y, _ = self._split_pairs(split, want_mask=False)
-            ev = GraphedEval(self.model, self._graph_plan(), pi, li, y, self.loss_fn, loss_out=self._loss_slots()[slot])
+            ev = GraphedEval(self.model, self._graph_plan(), pi, li, y, self.loss_fn, loss_out=self._loss_slots()[slot],
+                             comm=self.comm)
             self._deval[split] = ev
         return ev.step()
 
@@ -268,6 +339,8 @@ class Trainer:
         self.model.train()
         pi, li, y, sup = self._split_pairs("train")
         self.optimizer.zero_grad()
+        if self.comm is not None:
+            return self._train_epoch_eager_sharded(pi, li, y, sup)
         pred = self.model.predict_lab_values(self.data, pi, li)
         sp, st, sl = pred[sup], y[sup], li[sup]
         if self.loss_fn == "mae":
@@ -284,6 +357,23 @@ class Trainer:
         self.optimizer.step()
         return loss.item()
 
+    def _train_epoch_eager_sharded(self, pi, li, y, sup) -> float:
+        """The eager epoch of ONE shard: the mean over predictions[supervision_mask] (train.py:366-386) is a global mean --
+        the local weighted sum over the global subset size; gradients are exchanged inside the model's backward."""
+        from . import ops
+        if self.loss_fn not in ("mae", "mse", "huber"):
+            raise ValueError(f"Unknown loss type: {self.loss_fn}")
+        n = sup.sum(dtype=torch.float64).reshape(1)
+        self.comm.raw_all_reduce(n)
+        pred = self.model.predict_lab_values(self._graph_plan(), pi, li)
+        wl = self.lab_weights[li].contiguous() if self.loss_fn in ("mae", "mse") else None
+        loss = ops.weighted_pair_loss(pred, y, wl, sup.float(), 1.0 / max(float(n), 1.0), self.loss_fn)
+        loss.backward()
+        self.optimizer.step()
+        tot = loss.detach().double().reshape(1).clone()
+        self.comm.raw_all_reduce(tot)
+        return float(tot)
+
     @torch.no_grad()
     def validate(self, split: str = "val") -> float:
         """train.py:394-431."""
@@ -297,6 +387,15 @@ class Trainer:
     def _validate_eager(self, split: str = "val") -> float:
         self.model.eval()
         pi, li, y, _ = self._split_pairs(split)
+        if self.comm is not None:              # global mean: local sums over the global pair count
+            from . import ops
+            pred = self.model.predict_lab_values(self._graph_plan(), pi, li)
+            n = torch.tensor([float(pi.numel())], dtype=torch.float64, device=pi.device)
+            self.comm.raw_all_reduce(n)
+            loss, _ = ops.pair_loss(pred, y, None, None, 1.0 / max(float(n), 1.0), self.loss_fn, want_dpred=False)
+            tot = loss.detach().double().reshape(1).clone()
+            self.comm.raw_all_reduce(tot)
+            return float(tot)
         pred = self.model.predict_lab_values(self.data, pi, li)
         return compute_regression_loss(pred, y, loss_type=self.loss_fn).item()
 
@@ -481,7 +580,7 @@ class GraphedTrainStep:
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode()):
             self._body()
         torch.cuda.synchronize()
         _restore_training_state(model, optimizer, snap)
@@ -524,8 +623,14 @@ class PiecewiseGraphedTrainStep:
 
     def __init__(self, model, plan, pi, li, y, lab_weights, optimizer, sup_mask, comm, loss_fn: str = "mae",
                  n_sup_global: Optional[float] = None, warmup: int = 2, mask_fraction: Optional[float] = None,
-                 loss_out: Optional[torch.Tensor] = None, supervised_heads_only: bool = True):
-        """mask_fraction: draw a NEW supervision subset of that fraction inside every step (device RNG; the reference
+                 loss_out: Optional[torch.Tensor] = None, supervised_heads_only: bool = True,
+                 capture_collectives: Optional[bool] = None, reduce_loss: bool = False):
+        """capture_collectives: record the all-reduces of a sharded step INTO the hipGraph (one launch per step) instead
+        of cutting the recording at each of them; None = ask the communicator (`ShardComm.capturable()`: RCCL backend and
+        a probe capture that went through).  Chosen here, once -- never by retrying a failed recording.
+        reduce_loss: a sharded step's `loss` is this shard's share of the global mean; True sums it over the group (one
+        more fp64 all-reduce of 8 bytes per step) so that every rank reads the reference's number (Trainer's history).
+        mask_fraction: draw a NEW supervision subset of that fraction inside every step (device RNG; the reference
         redraws it every epoch, train.py:150-176) -- `sup_mask` may then be None; otherwise the subset is `sup_mask`
         until set_mask.  loss_out: fp64 device scalar the step writes its loss to.
         supervised_heads_only: the two edge heads are evaluated on the supervised pairs alone (the loss of train.py:366-386
@@ -543,6 +648,7 @@ class PiecewiseGraphedTrainStep:
         self.wl = lab_weights[li].contiguous() if loss_fn in ("mae", "mse") else None
         self.mask_fraction = None if mask_fraction is None else float(mask_fraction)
         self.supervised_heads_only = bool(supervised_heads_only)
+        self.reduce_loss = bool(reduce_loss) and comm is not None
         self.pred = None
         self._sel_ready = None
         dev = pi.device
@@ -579,6 +685,14 @@ class PiecewiseGraphedTrainStep:
         model.train()
         self.items = []
         self._cur = None
+        if comm is None:
+            self.capture_collectives = False
+        elif capture_collectives is None:
+            cap = getattr(comm, "capturable", None)
+            self.capture_collectives = bool(cap()) if cap is not None else False
+        else:
+            self.capture_collectives = bool(capture_collectives)
+        self.n_collectives = 0
         snap = _snapshot_training_state(model, optimizer)           # warm-up and capture run REAL steps: undone below
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -603,7 +717,7 @@ class PiecewiseGraphedTrainStep:
     # ---- recording
     def _begin(self):
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self._pool, capture_error_mode=CAPTURE_ERROR_MODE)
+        g.capture_begin(pool=self._pool, capture_error_mode=capture_error_mode())
         self._cur = g
 
     def _end(self):
@@ -612,10 +726,25 @@ class PiecewiseGraphedTrainStep:
         self._cur = None
 
     def _collective(self, t):
+        self.n_collectives += 1
+        if self.capture_collectives:       # recorded like any kernel of the step (RCCL on the capturing stream)
+            self.comm.raw_all_reduce(t)
+            return
         self._end()
         self.comm.raw_all_reduce(t)
         self.items.append(("all_reduce", t))
         self._begin()
+
+    def release(self):
+        """Drop what this step keeps alive that references the communicator or its streams -- the hipGraphs (with
+        captured collectives their nodes ARE RCCL kernels), the all-reduce tensors of the chain, the side-stream event --
+        so that `ShardComm.close` tears the group down with nothing of the step left.  The step cannot run afterwards."""
+        self.items = []
+        self._cur = None
+        self._sel_ready = None
+        self._pool = None
+        self.comm = None
+        self._sv.comm = None
 
     def _body(self):
         ops, model = self._ops, self.model
@@ -638,6 +767,8 @@ class PiecewiseGraphedTrainStep:
             self.pred = pred
             loss, dpred = ops.pair_loss(pred, self.y, self.wl, self.sup, 1.0, self.loss_fn, self._sv.inv_den,
                                         loss_out=self._loss_out)
+            if self.reduce_loss:
+                self.comm.all_reduce(loss)           # reporting only: the gradient came out of the same pass already
             grads = run.run_backward((dpred,))
             for p, g in zip(self.params, grads):
                 if g is not None:
@@ -701,7 +832,10 @@ class GraphedEval:
     loss stays on the device (``loss_out``, or a scalar of the graph's pool); the predictions are ``self.pred``."""
 
     def __init__(self, model, plan, pi, li, y, loss_fn: str = "mae", loss_out: Optional[torch.Tensor] = None,
-                 warmup: int = 1):
+                 warmup: int = 1, comm=None):
+        """comm: the model is patient-sharded -- pi / li / y are this shard's pairs, the loss is the mean over ALL shards'
+        pairs (local sum over the global count, then one fp64 all-reduce of the scalar: recorded inside the graph when the
+        communicator allows, issued right after the replay otherwise)."""
         from . import ops
         from .model import _Run
         if loss_fn not in ops.LOSS_TYPES:
@@ -711,6 +845,17 @@ class GraphedEval:
         self.loss_fn, self._loss_out = loss_fn, loss_out
         self._ops, self._Run = ops, _Run
         self.loss = self.pred = None
+        self.comm = comm
+        self._n_global = max(int(pi.numel()), 1)
+        self._loss_in_graph = False
+        if comm is not None:
+            n = torch.tensor([float(pi.numel())], dtype=torch.float64, device=pi.device)
+            comm.raw_all_reduce(n)
+            self._n_global = max(int(n.item()), 1)
+            cap = getattr(comm, "capturable", None)
+            self._loss_in_graph = bool(cap()) if cap is not None else False
+            if self._loss_out is None:         # the all-reduce acts in place on a tensor the caller can read
+                self._loss_out = torch.zeros((), dtype=torch.float64, device=pi.device)
         was_training = model.training
         model.eval()
         side = torch.cuda.Stream()
@@ -720,7 +865,7 @@ class GraphedEval:
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_ERROR_MODE):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode()):
             self._body()
         torch.cuda.synchronize()
         model.train(was_training)
@@ -734,11 +879,18 @@ class GraphedEval:
             run.n_pairs = self.pi.numel()
             run.need_grad = False
             (pred,) = run.run_forward("predict")
-            n = max(int(self.pi.numel()), 1)
-            self.loss, _ = ops.pair_loss(pred, self.y, None, None, 1.0 / n, self.loss_fn, loss_out=self._loss_out,
-                                         want_dpred=False)
+            self.loss, _ = ops.pair_loss(pred, self.y, None, None, 1.0 / self._n_global, self.loss_fn,
+                                         loss_out=self._loss_out, want_dpred=False)
+            if self.comm is not None and self._loss_in_graph:
+                self.comm.raw_all_reduce(self.loss)
             self.pred = pred
+
+    def release(self):
+        self.graph = None
+        self.comm = None
 
     def step(self) -> torch.Tensor:
         self.graph.replay()
+        if self.comm is not None and not self._loss_in_graph:
+            self.comm.raw_all_reduce(self.loss)
         return self.loss

@@ -145,3 +145,38 @@ def test_partition_rows_properties():
     sizes = [b[i + 1] - b[i] for i in range(8)]
     assert max(sizes) - min(sizes) <= 1
     assert md.partition_rows(torch.zeros(0, dtype=torch.long), 2) == [0, 0, 0]
+
+
+def test_edge_masker_shards_keep_the_global_split_and_supervision_draws():
+    """EdgeMasker.shard (what a patient-sharded Trainer is given): every has_lab edge stays in the split the global
+    permutation gave it, the shards' train-pair ids tile the unsharded train-pair list, and the per-epoch supervision
+    subsets of the shards are the global draw (train.py:150-166) cut at the shard boundaries."""
+    import mmgnn  # noqa: F401
+    from mmgnn import dist as md
+    from mmgnn.train import EdgeMasker
+    g = fx.graph_from_frames(fx.det_frames(*SHAPE))
+    lab = ("patient", "has_lab", "lab")
+    src = g[lab].edge_index[0]
+    whole = EdgeMasker(g, 0.7, 0.15, 0.15, 0.2, 42, mask_generator=torch.Generator().manual_seed(5))
+    b = md.partition_rows(md.patient_weights(g), 3)
+    parts = []
+    for r in range(3):
+        lo, hi = b[r], b[r + 1]
+        keep = (src >= lo) & (src < hi)
+        m = EdgeMasker(g, 0.7, 0.15, 0.15, 0.2, 42, mask_generator=torch.Generator().manual_seed(5)).shard(
+            md.shard_graph(g, lo, hi), keep)
+        assert torch.equal(m.train_mask, whole.train_mask[keep]) and torch.equal(m.val_mask, whole.val_mask[keep])
+        assert m.num_edges == int(keep.sum()) == m.edge_index.shape[1]
+        ei, ev, _, sup = m.get_masked_data("train")
+        assert ei.shape[1] == m.train_pair_ids.numel() == sup.numel()
+        assert torch.equal(ei[0] + lo, g[lab].edge_index[0][keep & whole.train_mask])
+        parts.append((m, sup))
+    ids = torch.cat([m.train_pair_ids for m, _ in parts]).sort().values
+    assert torch.equal(ids, torch.arange(int(whole.train_mask.sum())))
+    _, _, _, sup_all = whole.get_masked_data("train")
+    for m, sup in parts:                                     # first epoch's draw; the generators advance alike afterwards
+        assert torch.equal(sup, sup_all[m.train_pair_ids])
+    _, _, _, sup_all2 = whole.get_masked_data("train")
+    for m, _ in parts:
+        assert torch.equal(m.get_masked_data("train")[3], sup_all2[m.train_pair_ids])
+    assert not torch.equal(sup_all, sup_all2)

@@ -412,15 +412,28 @@ def test_rccl_backend_carries_the_sharded_step(capfd):
             opt1.step()
             losses1.append(float(loss))
         m2, plan2, comm2, opt2 = make(True)
-        step = PiecewiseGraphedTrainStep(m2, plan2, pi, li, y, wlab, opt2, sup, comm2, warmup=1)   # n_sup all-reduced inside
+        # (a) the segment chain: the recording is cut at every collective, RCCL is called between the replays
+        step = PiecewiseGraphedTrainStep(m2, plan2, pi, li, y, wlab, opt2, sup, comm2, warmup=1,    # n_sup all-reduced inside
+                                         capture_collectives=False)
         n_coll = sum(1 for k, _ in step.items if k == "all_reduce")
-        assert n_coll >= 10 and comm2.n_bytes > 0
+        assert n_coll >= 10 and comm2.n_bytes > 0 and step.n_collectives == n_coll
         losses2 = [float(step.step()) for _ in range(3)]
         for a, b in zip(losses1, losses2):
             assert abs(a - b) <= 2e-5 * abs(a), (losses1, losses2)
         for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
             if not n.startswith("embeddings."):
                 assert float((p1 - p2).detach().abs().max()) <= 1e-4 * float(p1.detach().abs().max()) + 1e-6, n
+        # (b) the collectives INSIDE the recording: one hipGraph per step, RCCL's kernels are nodes of it.  Same
+        # arithmetic in the same order as (a): the three steps must give the chain's losses and parameters bit for bit
+        assert comm2.capturable(), "RCCL all-reduce could not be recorded into a hipGraph on this box"
+        m4, plan4, comm4, opt4 = make(True)
+        step_c = PiecewiseGraphedTrainStep(m4, plan4, pi, li, y, wlab, opt4, sup, comm4, warmup=1, capture_collectives=True)
+        assert [k for k, _ in step_c.items] == ["graph"] and step_c.n_collectives == n_coll
+        losses4 = [float(step_c.step()) for _ in range(3)]
+        assert losses4 == losses2, (losses2, losses4)
+        for (n, p2), (_, p4) in zip(m2.named_parameters(), m4.named_parameters()):
+            if not n.startswith("embeddings."):
+                assert torch.equal(p2, p4), n
         # a new supervision subset of another size: the normaliser follows it (device scalar, all-reduced over the group)
         sup2 = (torch.arange(sel.numel(), device=dev) % 3 == 0)
         step.set_mask(sup2)
@@ -430,7 +443,7 @@ def test_rccl_backend_carries_the_sharded_step(capfd):
         # rank itself (no collective added: the chain has as many all-reduces as with an injected mask)
         m3, plan3, comm3, opt3 = make(True)
         step3 = PiecewiseGraphedTrainStep(m3, plan3, pi, li, y, wlab, opt3, None, comm3, warmup=1, mask_fraction=0.2)
-        assert sum(1 for k, _ in step3.items if k == "all_reduce") == n_coll
+        assert step3.capture_collectives and step3.n_collectives == n_coll          # default: what the probe allows
         assert step3.n_pairs_global == pi.numel() and torch.equal(step3._draw_ids, torch.arange(pi.numel(), device=dev))
         seen = []
         for _ in range(3):
@@ -445,9 +458,111 @@ def test_rccl_backend_carries_the_sharded_step(capfd):
         # process group's watchdog thread polls) go first, the device is idle.  Once -- in several hundred runs of this
         # suite -- the teardown aborted inside destroy_process_group with its C++ message swallowed by pytest's capture:
         # the capture is off around it so that a recurrence names its cause.
-        step = step3 = m1 = m2 = m3 = opt1 = opt2 = opt3 = comm2 = comm3 = None
-        import gc
-        gc.collect()
-        torch.cuda.synchronize()
+        # ShardComm.close is the one teardown order of the repo (release the steps -> collect -> synchronise -> barrier ->
+        # destroy); pytest's capture is off around it so that an abort in there prints its C++ message.
+        closer = md.ShardComm()
+        holders = [h for h in (locals().get("step"), locals().get("step_c"), locals().get("step3")) if h is not None]
+        step = step_c = step3 = m1 = m2 = m3 = m4 = opt1 = opt2 = opt3 = opt4 = comm2 = comm3 = comm4 = None
         with capfd.disabled():
-            dist.destroy_process_group()
+            closer.close(*holders)
+        assert not dist.is_initialized()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Trainer.train() -- the reference's entry point (src/train.py:433-544) -- on a patient-sharded model: two ranks (gloo; both
+# on the one GPU of the box) against ONE unsharded Trainer on the same graph, split and per-epoch supervision masks.
+TR_SHAPE = (320, 12, 15, 10)
+
+
+def _trainer_cfg():
+    return {"model": {"architecture": "RGCN", "hidden_dim": 64, "num_layers": 2, "dropout": 0.2, "use_batch_norm": True,
+                      "activation": "relu"},
+            "train": {"optimizer": {"type": "adam", "lr": 2e-3, "weight_decay": 1e-5},
+                      "lr_scheduler": {"enabled": True, "type": "step", "step_size": 2, "gamma": 0.5},
+                      "loss": "mae", "epochs": 4, "early_stopping_patience": 20, "train_split": 0.7, "val_split": 0.15,
+                      "test_split": 0.15, "mask_fraction": 0.2, "seed": 42},
+            "logging": {"save_checkpoints": False, "log_interval": 0}}
+
+
+def _trainer_history(dev, out_dir, comm_world=None, rank=0):
+    """One Trainer.train() run from the deterministic state; comm_world = N: this process is rank `rank` of N shards."""
+    import mmgnn  # noqa: F401
+    from mmgnn import dist as md
+    from mmgnn.model import build_model
+    from mmgnn.train import EdgeMasker, Trainer
+    from oracle import model as om
+    cfg = _trainer_cfg()
+    tc = cfg["train"]
+    g_all = fx.graph_from_frames(fx.det_frames(*TR_SHAPE))
+    sd = fx.det_state(om.GraphView(g_all).num_nodes, 64)
+    masker = EdgeMasker(g_all, tc["train_split"], tc["val_split"], tc["test_split"], tc["mask_fraction"], tc["seed"],
+                        mask_generator=torch.Generator().manual_seed(11))
+    g = g_all
+    if comm_world is not None:
+        b = md.partition_rows(md.patient_weights(g_all), comm_world)
+        lo, hi = b[rank], b[rank + 1]
+        g = md.shard_graph(g_all, lo, hi)
+        src = g_all["patient", "has_lab", "lab"].edge_index[0]
+        masker = masker.shard(g, (src >= lo) & (src < hi))
+        sd = md.shard_state(sd, lo, hi)
+    model = build_model(cfg, (g.node_types, g.edge_types), None)
+    model._init_embeddings(g)
+    model.load_state_dict(sd)
+    if comm_world is not None:
+        md.shard_model(model, md.ShardComm())
+    torch.manual_seed(123)                     # the dropout seed stream of the captured step starts from the host generator
+    trainer = Trainer(model, g, masker, cfg, dev)
+    hist = trainer.train(out_dir)
+    extra = {"device_step": trainer._dstep is not None, "n_coll": getattr(trainer._dstep, "n_collectives", None),
+             "test_loss": trainer.validate("test"),
+             "weights": {k: v.detach().cpu() for k, v in model.state_dict().items()
+                         if v.is_floating_point() and not k.startswith("embeddings.")}}
+    return hist, extra, trainer
+
+
+def _trainer_worker(rank, world, port, out_dir, q):
+    try:
+        import os
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from mmgnn import dist as md
+        hist, extra, trainer = _trainer_history(torch.device("cuda:0"), os.path.join(out_dir, f"r{rank}"), world, rank)
+        q.put((rank, hist, extra, None))
+        md.ShardComm().close(trainer._dstep, *trainer._deval.values())
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, None, None, traceback.format_exc()))
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_trainer_trains_like_one_unsharded_trainer(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import socket
+    import torch.multiprocessing as mp
+    dev = torch.device("cuda:0")
+    h1, e1, _ = _trainer_history(dev, tmp_path / "one")
+    assert e1["device_step"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=480) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for rank, hist, extra, tb in res:
+        assert tb is None, f"rank {rank} failed:\n{tb}"
+        assert extra["device_step"] and extra["n_coll"] >= 11          # the sharded CAPTURED step ran (chain: gloo)
+        assert hist["learning_rates"] == h1["learning_rates"]
+        for k in ("train_loss", "val_loss"):
+            assert len(hist[k]) == len(h1[k]) == 4
+            for a, b in zip(hist[k], h1[k]):
+                assert abs(a - b) <= 2e-4 * abs(b), (rank, k, hist[k], h1[k])     # every rank reads the GLOBAL loss
+        assert abs(extra["test_loss"] - e1["test_loss"]) <= 2e-4 * abs(e1["test_loss"])
+        for k, v in extra["weights"].items():                                       # four chained Adam steps
+            assert float((v - e1["weights"][k]).abs().max()) <= 2e-3 * float(e1["weights"][k].abs().max()) + 1e-6, k
