@@ -450,10 +450,12 @@ int mmg_pair_head_fwd(const mmg_head_t* head, const int32_t* pi, const int32_t* 
  * NULL `saved` = the plain entry points: the backward recomputes -- in the forward's own order, so both variants return
  * the same bits.  Up to 64 labs on the backward side (beyond: recomputed). */
 typedef struct {
-  uint32_t* h1_bits;      /* [n_total, 2] */
-  float* h2;              /* [n_total, 32] */
+  uint32_t* h1_bits;      /* [n_entries, 2] */
+  float* h2;              /* [n_entries, 32] */
   int by_position;        /* != 0: entry = position in the pair list `sel` instead of the pair index k -- dense, streamed
                            * writes and reads; the backward must then run over the SAME list as the forward */
+  int64_t n_entries;      /* rows of both buffers: >= n_total (indexed by pair), >= n_pairs -- the launch bound of the list
+                           * -- when by_position; checked by both entry points (MMG_ERR_ARG) */
 } mmg_pair_saved_t;
 int mmg_pair_head_fwd_save(const mmg_head_t* head, const int32_t* pi, const int32_t* li,
                            const int32_t* deg, int degree_threshold, int want_low, int64_t n_pairs, int64_t n_total,

@@ -76,7 +76,7 @@ class NextBnT(C.Structure):
 
 
 class PairSavedT(C.Structure):
-    _fields_ = [("h1_bits", C.c_void_p), ("h2", C.c_void_p), ("by_position", C.c_int)]
+    _fields_ = [("h1_bits", C.c_void_p), ("h2", C.c_void_p), ("by_position", C.c_int), ("n_entries", C.c_int64)]
 
 
 class WgradReduceT(C.Structure):

@@ -392,185 +392,95 @@ __device__ inline void split8x(const float* v, bf16x8& p0, bf16x8& p1, bf16x8& p
   p0 = __builtin_bit_cast(bf16x8, q0); p1 = __builtin_bit_cast(bf16x8, q1); p2 = __builtin_bit_cast(bf16x8, q2);
 }
 
-// k_scatter_strip: the workgroup owns a 32-column STRIP of x for a range of rows; its four waves (one per SIMD: the
-// accumulators of ALL item tiles stay in one wave's registers, so x is split into its bf16 pieces exactly once) take a
-// quarter of those rows each and their partial accumulators are summed through LDS in fixed order at the end, so ONE
-// [padded items x 32] strip per workgroup goes to the partial slabs: 256 / (D / 32) row ranges -> 10.5 MB at the eICU
-// vocabulary instead of 42 MB (the slabs were 84 MB of traffic beside 94 MB of x).
-// No rowscale here: with one, every relation needs its own scaled copy of x split into pieces (3x the vector work of
-// a wave that is already alone on its SIMD) -- measured 56 us against 50 us for k_scatter_units below, which takes
-// those launches (and every vocabulary beyond 10 tiles).
-// The operands of k-step q+1 are produced in the shadow of the matrix instructions of k-step q: a wave that is alone
-// on its SIMD hides at most ~24 cycles of other issue per 32-cycle MFMA (MI355X_MICROARCH.md), so the vector work is
-// dealt out between the MFMAs explicitly (sched_group_barrier) instead of left in clumps.
-constexpr int ST_TP = 5;                     // tiles per phase of the final cross-wave sum (80 registers x 4 waves = 80 KB)
-#ifdef MMG_STAMPS                             // diagnostic build only (scratch/): per-wave s_memtime stamps of the phases
-__device__ unsigned long long g_stamps[1024 * 8];
-#define MMG_STAMP(i) do { if (lane == 0) g_stamps[(size_t)(blockIdx.y * gridDim.x * 4 + blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define MMG_STAMP(i) do { } while (0)
-#endif
+// ---- two f16 pieces of x * 2^e (round 4): 18 instead of 27 matrix instructions per 16 patients x 9 item tiles.
+// hi = f16(X), lo = f16(X - hi) with X = x * 2^e: 22 significant bits, relative error <= 2^-22 of X while 2^-3 <= |X| < 65504;
+// below that the residual is an f16 denormal (absolute error 2^-25 in units of X).  The scale is a power of two chosen BY THE
+// WAVE from the data it streams (block floating point over the wave's row range): e starts at whatever brings the first
+// 16 x 32 block's largest magnitude to [2^12, 2^13); a later block with an element beyond 2^15 / 2^e lowers e, the
+// accumulators are multiplied by 2^(e_new - e_old) and that block is split again -- so every piece is finite for finite x,
+// whatever its range, and an element's error is <= 2^-22 of itself or 2^-37 of the largest magnitude seen so far in the
+// strip, whichever is larger: the error of an fp32 running sum, not of a format with fewer bits.  A NaN or an infinity in x
+// gives NaN in the sums it enters (fp32 index_add_: NaN, or +-inf for an infinity alone).
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2s __attribute__((ext_vector_type(2)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+constexpr int H2_E_INIT = 120, H2_E_MIN = -110;
 
-template <int NT>
-__global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_rows, int n_stage_total, int D, int total_pad,
-                                                       const float* __restrict__ x, float* __restrict__ slab) {
-  constexpr int KS = 8, RING = 8, AHEAD = 6;
-  __shared__ __attribute__((aligned(16))) unsigned lut[256][4];            // byte -> 8 bf16 in {0, 1}
-  extern __shared__ __attribute__((aligned(16))) float st_red[];           // [4 waves][ST_TP * 16][64]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, l31 = lane & 31;
-  const int d0 = blockIdx.y * 32;
-  MMG_STAMP(0);
-  // stages of this wave: the n_stage_total 64-row stages are dealt evenly over (workgroup, wave)
-  const int q_id = blockIdx.x * 4 + wid, n_q = gridDim.x * 4;
-  const int s_beg = (int)((int64_t)q_id * n_stage_total / n_q);
-  const int s_end = (int)((int64_t)(q_id + 1) * n_stage_total / n_q);
-  const int ns = s_end - s_beg;
-  const int64_t r_beg = (int64_t)s_beg * SB_SR;
-  // x goes through a buffer descriptor that covers exactly this wave's rows: the range check returns 0 for rows past
-  // the end and for the run-ahead past the last k-step (no clamps, no exec-masked regions in the loop), and an address
-  // is  descriptor base + one 32-bit lane offset + a scalar row offset  (one VALU add per k-step).
-  const int64_t rows_here = ns <= 0 ? 0 : ((n_rows - r_beg) < (int64_t)ns * SB_SR ? (n_rows - r_beg) : (int64_t)ns * SB_SR);
-  const float* xw = x + (size_t)r_beg * D + d0;
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(xw), 0, rows_here > 0 ? (int)((rows_here * D - d0) * 4) : 0, 0x00020000);
-  const unsigned row_bytes = (unsigned)D * 4u;
-  const unsigned voff0 = (unsigned)(8 * h) * row_bytes + (unsigned)l31 * 4u;
-  float xq[RING][8];                                   // ring of k-step operands: slot = k-step & 7
-  auto loadx = [&](int kg, float* dst) {
-    const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
+__device__ __forceinline__ void split8_h2(const float* v, float scale, f16x8s& p0, f16x8s& p1) {
+  u32x4s q0, q1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, vo, j * row_bytes, 0));
-  };
-  // the ring is primed FIRST: the cold start of the kernel (every wave of the chip asks at once) then runs beside
-  // the LUT build, its barrier and the bit-plane address set-up instead of after them
-#pragma unroll
-  for (int q = 0; q < AHEAD; ++q) loadx(q, xq[q]);
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
-  __syncthreads();
-  MMG_STAMP(1);
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-  if (ns > 0) {
-    // The items of all relations are PACKED back to back (rp.r[r].acc_off = items in front of relation r): 264 items of
-    // the eICU vocabulary are 9 tiles, not the 10 that per-relation padding to 32 would need -- a tile may straddle two
-    // relations, so every LANE has its own bit-plane row (pointer and per-stage stride); lanes past the last item read
-    // some valid word and select the all-zero LUT entry.
-    const uint64_t* mb[NT];
-    unsigned ms[NT], lm[NT];
-    const uint64_t* any_mask = nullptr;
-#pragma unroll
-    for (int r = 0; r < MMG_MAX_REL; ++r)
-      if (r < rp.n && rp.r[r].mask && !any_mask) any_mask = rp.r[r].mask;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      mb[t] = any_mask; ms[t] = 0; lm[t] = 0u;
-      const int it = t * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < MMG_MAX_REL; ++r) {
-        if (r >= rp.n) continue;
-        const int padc = (rp.r[r].n_cols + 31) & ~31;
-        if (rp.r[r].mask && it >= rp.r[r].acc_off && it < rp.r[r].acc_off + rp.r[r].n_cols) {
-          mb[t] = rp.r[r].mask + ((size_t)s_beg * padc + (it - rp.r[r].acc_off)) * 2 + h;
-          ms[t] = 2u * (unsigned)padc; lm[t] = 0xFF0u;
-        }
-      }
-    }
-    auto loadm = [&](int s, uint64_t* dst) {           // past the end: re-read the last stage (its x reads as 0)
-      const int sc = s < ns ? s : ns - 1;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) dst[t] = mb[t][(size_t)sc * ms[t]];
-    };
-    // operands of one k-step.  kq = k-step inside its 64-row stage (0..3): field kq of the mask word is
-    // (8 patient bits) << 4 = the byte offset of the LUT entry that expands them.
-    auto make_af = [&](const uint64_t* mw, int kq, bf16x8* af) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const unsigned w = (kq & 2) ? (unsigned)(mw[t] >> 32) : (unsigned)mw[t];
-        const unsigned off = (kq & 1) ? ((w >> 16) & lm[t]) : (w & lm[t]);       // field << 4, 0 for a lane without an item
-        af[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
-      }
-    };
-    uint64_t mc[NT], mn[NT];
-    loadm(0, mc);
-    // drained completely: the loop is then entered with no load in flight, a subset of what its back edge carries, so
-    // the wait counts inside stay exact
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
-    bf16x8 afc[NT], bc[3];
-    make_af(mc, 0, afc);
-    split8x(xq[0], bc[0], bc[1], bc[2]);
-    MMG_STAMP(2);
-
-    const int n2 = (ns + 1) / 2;
-    for (int u = 0; u < n2; ++u) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if ((ks & 3) == 0) loadm(2 * u + (ks >> 2) + 1, mn);             // words of the next stage
-        loadx(u * KS + ks + AHEAD, xq[(ks + AHEAD) & (RING - 1)]);       // into a slot consumed two k-steps ago
-        __builtin_amdgcn_sched_barrier(0);             // keep the run-ahead: the scheduler would sink these loads
-        bf16x8 afn[NT], bn[3];
-        make_af((ks & 3) == 3 ? mn : mc, (ks + 1) & 3, afn);
-        split8x(xq[(ks + 1) & (RING - 1)], bn[0], bn[1], bn[2]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[p], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) afc[t] = afn[t];
-        bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
-        // deal the next k-step's vector work out between this k-step's matrix instructions (~4 per MFMA by count)
-#pragma unroll
-        for (int i = 0; i < 3 * NT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                      // a slice of the split work
-          if (i < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one LUT read
-        }
-        if ((ks & 3) == 3) {
-#pragma unroll
-          for (int t = 0; t < NT; ++t) mc[t] = mn[t];
-        }
-      }
-    }
+  for (int j = 0; j < 4; ++j) {
+    const f32x2s a = {v[2 * j] * scale, v[2 * j + 1] * scale};
+    const f16x2s hh = __builtin_convertvector(a, f16x2s);
+    const f32x2s r = {a[0] - (float)hh[0], a[1] - (float)hh[1]};
+    const f16x2s ll = __builtin_convertvector(r, f16x2s);
+    q0[j] = __builtin_bit_cast(unsigned, hh); q1[j] = __builtin_bit_cast(unsigned, ll);
   }
-  MMG_STAMP(3);
-  // ---- fixed-order sum of the four waves' partial accumulators through LDS, ST_TP tiles at a time: every wave parks
-  // its registers of the phase, then sums a QUARTER of them over the four copies (wave 0 + 1 + 2 + 3) and stores it
-  float* dst = slab + (size_t)blockIdx.x * total_pad * D + d0 + l31;
-#pragma unroll
-  for (int t0 = 0; t0 < NT; t0 += ST_TP) {
-    constexpr int dummy = 0; (void)dummy;
-    const int ntp = (NT - t0) < ST_TP ? (NT - t0) : ST_TP;
-    if (t0 > 0) __syncthreads();                       // the previous phase's reads are done
-#pragma unroll
-    for (int t = 0; t < ST_TP; ++t)
-      if (t0 + t < NT) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) st_red[((size_t)wid * ST_TP * 16 + t * 16 + i) * 64 + lane] = acc[t0 + t][i];
-      }
-    __syncthreads();
-    const int nreg = ntp * 16;
-    for (int idx = wid * nreg / 4; idx < (wid + 1) * nreg / 4; ++idx) {
-      float v = st_red[((size_t)0 * ST_TP * 16 + idx) * 64 + lane];
-      v += st_red[((size_t)1 * ST_TP * 16 + idx) * 64 + lane];
-      v += st_red[((size_t)2 * ST_TP * 16 + idx) * 64 + lane];
-      v += st_red[((size_t)3 * ST_TP * 16 + idx) * 64 + lane];
-      const int i = idx & 15;
-      const int vrow = (t0 + (idx >> 4)) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      dst[(size_t)vrow * D] = v;
-    }
-  }
-  MMG_STAMP(4);
+  p0 = __builtin_bit_cast(f16x8s, q0); p1 = __builtin_bit_cast(f16x8s, q1);
 }
 
+__device__ __forceinline__ float absmax8(const float* v) {      // (fmaxf drops a NaN operand: a NaN never moves the scale)
+  float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
+  m = fmaxf(fmaxf(m, fabsf(v[3])), fabsf(v[4]));
+  m = fmaxf(fmaxf(m, fabsf(v[5])), fabsf(v[6]));
+  return fmaxf(m, fabsf(v[7]));
+}
+
+// (rare path only) the same over the FINITE values: an infinity takes part in no scale decision -- it poisons the sums
+// of its own column, as it must, and leaves the scale of the 31 other columns of the strip alone
+__device__ __forceinline__ float absmax8_finite(const float* v) {
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(v[j]) < __builtin_inff() ? fabsf(v[j]) : 0.f);
+  return m;
+}
+
+// The wave's scale.  e: the pieces are those of x * 2^e.  The first block with a finite non-zero value sets e so that its
+// largest magnitude lands in [2^12, 2^13) and anchors e_floor = e - 10; from then on a block that does not fit
+// (an element beyond 2^15 / 2^e) either lowers e (not below e_floor: the data grew, the accumulators are multiplied by the
+// power of two, nothing is lost) or -- an outlier more than ~2^12 above anything seen before -- is multiplied exactly on its own.
+// Every term is therefore kept to 2^-22 of itself while it is within [2^-16, 2^2] of the wave's reference magnitude 2^(13 - e)
+// (at least 2^-6 of the first block's maximum), exactly if it is an outlier above, and to an absolute 2^-25 * 2^-e below.
+struct H2Scale {
+  int e, e_floor, seen;
+  float sc, lim;                                       // 2^e, 2^(15 - e): wave-uniform
+  __device__ __forceinline__ void set(int en) { e = en; sc = h2_pow2_(en); lim = h2_pow2_(15 - en); }
+  __device__ __forceinline__ void init() { seen = 0; e_floor = H2_E_MIN; set(H2_E_INIT); }
+  static __device__ __forceinline__ float h2_pow2_(int k) { return __builtin_bit_cast(float, (unsigned)(k + 127) << 23); }
+};
+constexpr int H2_E_DROP = 10;
+
+// m = a lane's finite magnitude maximum of the block.  Returns 1: multiply this block exactly (bf16 pieces), scale unchanged;
+// 0: split it as f16 pieces at the (possibly lowered) scale after multiplying the accumulators by 2^d.
+__device__ __forceinline__ int h2_decide(float m, H2Scale& hs, int& d) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  // (scalar from here on: every decision below is a uniform branch and the wave's scale stays in scalar registers -- with
+  //  the maximum left in a vector register the compiler treats the whole state as divergent and masks the main loop)
+  m = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+  d = 0;
+  if (!(m > 0.f)) return 0;                            // nothing finite and non-zero: the block cannot move the scale
+  const int fe = __builtin_amdgcn_frexp_expf(m);       // floor(log2 m) + 1
+  int en = 13 - fe;
+  en = en < H2_E_MIN ? H2_E_MIN : en;
+  en = en > hs.e ? hs.e : en;
+  if (!hs.seen) { hs.seen = 1; hs.e_floor = en - H2_E_DROP; hs.set(en); return 0; }   // (the accumulators are still zero)
+  if (en >= hs.e_floor) { d = en - hs.e; hs.set(en); return 0; }
+  if (fe + hs.e >= 100) {                              // x * 2^e would leave the fp32 range: re-anchor
+    d = en - hs.e; hs.e_floor = en - H2_E_DROP; hs.set(en); return 0;
+  }
+  return 1;
+}
+__device__ __forceinline__ float h2_pow2(int e) {          // 2^e for |e| <= 126 (wave-uniform)
+  return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+
+// The strip layout (round 2): a workgroup owns a 32-column STRIP of x for a range of rows; four row quarters stream it and
+// their partial accumulators are summed through LDS in fixed order, so ONE [padded items x 32] strip per workgroup goes to the
+// partial slabs: 256 / (D / 32) row ranges -> 10.5 MB at the eICU vocabulary instead of 42 MB.  The relations' items are
+// packed back to back (264 items = 9 tiles; a tile may straddle two relations: every lane carries its own bit-plane row).
+// The operands of k-step q+1 are produced in the shadow of the matrix instructions of k-step q: the vector work is dealt
+// out between the MFMAs explicitly (sched_group_barrier) instead of left in clumps.
 // k_scatter_strip2<NA, NB>: the same strip, its item tiles dealt over TWO waves per SIMD.  k_scatter_strip<9> holds 392
 // registers (144 accumulators + operand ring): ONE wave per SIMD, whose matrix pipe is busy 52 % of its life -- every LUT
 // round trip, every x load it waits for and whatever vector work does not co-issue is exposed.  Here wave w (tiles
@@ -578,11 +488,17 @@ __global__ __launch_bounds__(256) void k_scatter_strip(RelPack rp, int64_t n_row
 // wave_simd) and stream the SAME quarter of the rows, each under 256 registers: while one waits or expands fragments the
 // other multiplies.  Both load and split x themselves (the second reader hits the cache; two splits per SIMD still fit
 // under the matrix time, three -- k_scatter_units at this vocabulary -- did not).  Same arithmetic, same slab layout.
-template <int NT, int RING, int AHEAD>
-__device__ __forceinline__ void strip_main(const RelPack& rp, int64_t n_rows, int n_stage_total, int D, const float* __restrict__ x,
-                                           const unsigned (*lut)[4], int t_first, int q_id, int n_q, f32x16* acc) {
-  constexpr int KS = 8;
-  static_assert((RING & (RING - 1)) == 0 && AHEAD < RING && KS % RING == 0, "ring slots follow the k-step index");
+// strip_main_h: the strip's main loop on the f16 matrix instructions -- two pieces of x * 2^e (split8_h2) instead of three
+// bf16 pieces; the scale exponent e belongs to the wave (H2Scale).  The magnitude check of a k-step's block rides in the
+// shadow of the matrix instructions (four v_max3 and a compare); a block with an element beyond 2^15 / 2^e is found at the top
+// of ITS k-step -- before anything multiplied it -- and handled there (h2_decide): e is lowered and the accumulators rescaled
+// (exact: a power of two), or, for an outlier, the block alone is multiplied as three exact bf16 pieces at the unchanged
+// scale.  One 64-row stage per loop trip.  On return the accumulators are in units of 2^-e_out.
+template <int NT>
+__device__ __forceinline__ void strip_main_h(const RelPack& rp, int64_t n_rows, int n_stage_total, int D, const float* __restrict__ x,
+                                             const unsigned (*lut)[4], const unsigned (*lutb)[4], int t_first, int q_id, int n_q,
+                                             f32x16* acc, int& e_out) {
+  constexpr int RING = 4, AHEAD = 3;
   const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
   const int d0 = blockIdx.y * 32;
   const int s_beg = (int)((int64_t)q_id * n_stage_total / n_q);
@@ -608,6 +524,7 @@ __device__ __forceinline__ void strip_main(const RelPack& rp, int64_t n_rows, in
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  e_out = 0;
   if (ns <= 0) return;
   const uint64_t* mb[NT];
   unsigned ms[NT], lm[NT];
@@ -634,65 +551,107 @@ __device__ __forceinline__ void strip_main(const RelPack& rp, int64_t n_rows, in
 #pragma unroll
     for (int t = 0; t < NT; ++t) dst[t] = mb[t][(size_t)sc * ms[t]];
   };
-  auto make_af = [&](const uint64_t* mw, int kq, bf16x8* af) {
+  // field kq (k-step inside the 64-row stage) of a mask word = (8 patient bits) << 4 = byte offset of the table entry
+  auto frag_off = [&](const uint64_t* mw, int kq, int t) -> unsigned {
+    const unsigned w = (kq & 2) ? (unsigned)(mw[t] >> 32) : (unsigned)mw[t];
+    return (kq & 1) ? ((w >> 16) & lm[t]) : (w & lm[t]);
+  };
+  auto make_af = [&](const uint64_t* mw, int kq, f16x8s* af) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const unsigned w = (kq & 2) ? (unsigned)(mw[t] >> 32) : (unsigned)mw[t];
-      const unsigned off = (kq & 1) ? ((w >> 16) & lm[t]) : (w & lm[t]);
-      af[t] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + off);
-    }
+    for (int t = 0; t < NT; ++t)
+      af[t] = *reinterpret_cast<const f16x8s*>(reinterpret_cast<const unsigned char*>(&lut[0][0]) + frag_off(mw, kq, t));
   };
   uint64_t mc[NT], mn[NT];
   loadm(0, mc);
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the loop is entered with no load in flight
-  bf16x8 afc[NT], bc[3];
+  f16x8s afc[NT], bc[2];
   make_af(mc, 0, afc);
-  split8x(xq[0], bc[0], bc[1], bc[2]);
-  const int n2 = (ns + 1) / 2;
-  for (int u = 0; u < n2; ++u) {
+  H2Scale hs;
+  hs.init();
+  unsigned long long over = ~0ull;                     // block 0 goes through the decision like any block that does not fit
+  bc[0] = bc[1] = f16x8s{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int u = 0; u < ns; ++u) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if ((ks & 3) == 0) loadm(2 * u + (ks >> 2) + 1, mn);
-      loadx(u * KS + ks + AHEAD, xq[(ks + AHEAD) & (RING - 1)]);
+    for (int kq = 0; kq < 4; ++kq) {
+      if (__builtin_expect(over != 0ull, 0)) {
+        // the block of this k-step (raw in xq[kq], nothing has multiplied it yet) does not fit the scale, or is the first
+        const float* xb = xq[kq];
+        int d;
+        if (h2_decide(absmax8_finite(xb), hs, d)) {
+          // an outlier: this block alone as three exact bf16 pieces of x * 2^e (any range), fragments from the bf16 table
+          float xs[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xs[j] = xb[j] * hs.sc;
+          bf16x8 p0, p1, p2;
+          split8x(xs, p0, p1, p2);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const bf16x8 ab = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(&lutb[0][0]) + frag_off(mc, kq, t));
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, p0, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, p1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, p2, acc[t], 0, 0, 0);
+          }
+          bc[0] = bc[1] = f16x8s{0, 0, 0, 0, 0, 0, 0, 0};      // (the f16 products of this k-step add nothing)
+        } else {
+          if (d != 0) {
+            const float f = h2_pow2(d < -126 ? -126 : d);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) acc[t][i] *= f;
+          }
+          split8_h2(xb, hs.sc, bc[0], bc[1]);
+        }
+      }
+      if (kq == 0) loadm(u + 1, mn);
+      loadx(u * 4 + kq + AHEAD, xq[(kq + AHEAD) & (RING - 1)]);
       __builtin_amdgcn_sched_barrier(0);
-      bf16x8 afn[NT], bn[3];
-      make_af((ks & 3) == 3 ? mn : mc, (ks + 1) & 3, afn);
-      split8x(xq[(ks + 1) & (RING - 1)], bn[0], bn[1], bn[2]);
+      f16x8s afn[NT], bn[2];
+      make_af(kq == 3 ? mn : mc, (kq + 1) & 3, afn);
+      const float* xn = xq[(kq + 1) & (RING - 1)];
+      split8_h2(xn, hs.sc, bn[0], bn[1]);
+      over = __builtin_amdgcn_ballot_w64(absmax8(xn) > hs.lim);
 #pragma unroll
-      for (int p = 0; p < 3; ++p)
+      for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[t], bc[p], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[t], bc[p], acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) afc[t] = afn[t];
-      bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
+      bc[0] = bn[0]; bc[1] = bn[1];
 #pragma unroll
-      for (int i = 0; i < 3 * NT; ++i) {
+      for (int i = 0; i < 2 * NT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, (48 + 3 * NT - 1) / (3 * NT) + 2, 0);   // a slice of the split / expansion work
+        __builtin_amdgcn_sched_group_barrier(0x002, (30 + 2 * NT + 2 * NT - 1) / (2 * NT), 0);   // a slice of the split / expansion work
         if (i < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one LUT read
       }
-      if ((ks & 3) == 3) {
+      // (the pieces are pinned HERE: left alone, the compiler sinks the split behind the branch at the top of the next
+      //  k-step -- the rare path replaces them -- and out of the shadow of the matrix instructions above)
+      asm volatile("" :: "v"(bc[0]), "v"(bc[1]));
+      if (kq == 3) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) mc[t] = mn[t];
       }
     }
   }
+  e_out = hs.e;
 }
 
 template <int NA, int NB>
 __global__ __launch_bounds__(512) void k_scatter_strip2(RelPack rp, int64_t n_rows, int n_stage_total, int D, int total_pad,
                                                         const float* __restrict__ x, float* __restrict__ slab) {
   constexpr int NP = NA > NB ? NA : NB;                                    // tiles parked per phase
-  __shared__ __attribute__((aligned(16))) unsigned lut[256][4];            // byte -> 8 bf16 in {0, 1}
+  __shared__ __attribute__((aligned(16))) unsigned lut[256][4];            // byte -> 8 f16 in {0, 1}
+  __shared__ __attribute__((aligned(16))) unsigned lutb[256][4];           // ... as bf16: the exact path of an outlier block
   extern __shared__ __attribute__((aligned(16))) float st_red[];           // [4 row quarters][NP * 16][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31, w4 = wid & 3;
   const int d0 = blockIdx.y * 32;
-  if (tid < 256) {
+  {
+    unsigned (*tb)[4] = tid < 256 ? lut : lutb;
+    const unsigned one_lo = tid < 256 ? 0x3C00u : 0x3F80u, one_hi = one_lo << 16, b = tid & 255;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      lut[tid][q] = ((tid >> (2 * q)) & 1 ? 0x3F80u : 0u) | ((tid >> (2 * q + 1)) & 1 ? 0x3F800000u : 0u);
+    for (int q = 0; q < 4; ++q) tb[b][q] = ((b >> (2 * q)) & 1 ? one_lo : 0u) | ((b >> (2 * q + 1)) & 1 ? one_hi : 0u);
   }
   __syncthreads();
   const int q_id = blockIdx.x * 4 + w4, n_q = gridDim.x * 4;
@@ -711,13 +670,15 @@ __global__ __launch_bounds__(512) void k_scatter_strip2(RelPack rp, int64_t n_ro
       dst[(size_t)vrow * D] = v;
     }
   };
+  int e;
   if (wid < 4) {
     f32x16 acc[NA];
-    strip_main<NA, 4, 3>(rp, n_rows, n_stage_total, D, x, lut, 0, q_id, n_q, acc);
+    strip_main_h<NA>(rp, n_rows, n_stage_total, D, x, lut, lutb, 0, q_id, n_q, acc, e);
+    const float un = h2_pow2(-e);                      // the accumulators are in units of 2^-e
 #pragma unroll
     for (int t = 0; t < NA; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) st_red[((size_t)w4 * NP * 16 + t * 16 + i) * 64 + lane] = acc[t][i];
+      for (int i = 0; i < 16; ++i) st_red[((size_t)w4 * NP * 16 + t * 16 + i) * 64 + lane] = acc[t][i] * un;
     __syncthreads();
     sum_store(0, NA);
     __syncthreads();                                   // the first phase's reads are done
@@ -725,14 +686,15 @@ __global__ __launch_bounds__(512) void k_scatter_strip2(RelPack rp, int64_t n_ro
     sum_store(NA, NB);
   } else {
     f32x16 acc[NB];
-    strip_main<NB, 4, 3>(rp, n_rows, n_stage_total, D, x, lut, NA, q_id, n_q, acc);
+    strip_main_h<NB>(rp, n_rows, n_stage_total, D, x, lut, lutb, NA, q_id, n_q, acc, e);
+    const float un = h2_pow2(-e);
     __syncthreads();
     sum_store(0, NA);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < NB; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) st_red[((size_t)w4 * NP * 16 + t * 16 + i) * 64 + lane] = acc[t][i];
+      for (int i = 0; i < 16; ++i) st_red[((size_t)w4 * NP * 16 + t * 16 + i) * 64 + lane] = acc[t][i] * un;
     __syncthreads();
     sum_store(NA, NB);
   }
@@ -749,370 +711,6 @@ int launch_scatter_strip2(const RelPack& rp, int64_t n_rows, int D, int n_ranges
   return MMG_OK;
 }
 
-template <int NT>
-int launch_scatter_strip(const RelPack& rp, int64_t n_rows, int D, int n_ranges, int total_pad, const float* x, float* slab,
-                         hipStream_t st) {
-  constexpr int lds = 4 * ST_TP * 16 * 64 * 4;
-  MMG_CHECK_HIP((MmgMaxLds<&k_scatter_strip<NT>, lds>::set()), "scatter_rows(attr)");
-  const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
-  MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, total_pad, 0, (k_scatter_strip<NT>),
-             dim3((unsigned)n_ranges, (unsigned)(D / 32)), dim3(256), lds, st, rp, n_rows, nst, D, total_pad, x, slab);
-  return MMG_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// EXPERIMENT, diagnostic builds only (-DMMG_SR_ABL=<bits>, profiles/probes/scatter_ab.sh; the shipped library does not
-// contain it): a role-specialised form of the strip kernel, built to find out whether a different decomposition of the
-// dense-indicator product reaches half of the HBM roofline.  It does not: see DESIGN section 5,
-// "Round 3, third session" and profiles/probes/scatter_roles_mi355x.log.  bits: 1 no bit-plane loads, 2 no x loads, 4 one
-// matrix instruction per pass, 8 no main loop, 16 k_scatter_strip2 instead (the shipped kernel, as the reference line),
-// 1024 / 2048 four / two k-steps of x in flight, 4096 non-temporal x loads, 8192 (with 2) x loads issued and never
-// used, 16384 two f16 pieces of 256 x instead of three bf16 pieces.
-#ifdef MMG_SR_ABL
-// k_scatter_roles<NT>: the same strip with the two kinds of work on two KINDS of wave.  In k_scatter_strip / strip2 every wave
-// loads x, splits it, expands its indicator fragments and multiplies, and the time of a k-step is close to the SUM of its
-// matrix and vector issue: a wave's own vector work hides behind its matrix instructions only two or
-// three instructions at a time.  Here waves 0..3 (one per SIMD) ONLY multiply: per k-step 3 x NT matrix instructions, NT
-// table reads for the next fragments (one behind each matrix instruction of the third pass), one vector instruction per
-// tile; their operands arrive through LDS.  Waves 4..7 (wave w + 4 shares the SIMD of wave w) ONLY produce: they stream x
-// (ring of 8 k-steps, 6 in flight), split it into the three bf16 pieces in the MFMA B layout (the lane that loads a
-// column is the lane that multiplies it: ds_write_b128 / ds_read_b128 at lane * 16, no conflicts) and pass the bit-plane
-// words of each 64-row stage on (8 k-steps ahead of their use).  One workgroup barrier per k-step, placed in the
-// multipliers BETWEEN their second and third pass over the tiles: the operand reads of the next k-step were issued two
-// passes earlier (nothing to wait for), and the table reads of the third pass stay in flight across the iteration
-// boundary.  Measured on the way (profiles/probes/scatter_ab.sh, x100 eICU shape): the producer's vector work hides behind
-// the partner's matrix instructions ONLY as plain vector instructions -- with v_pk_add_f32 / v_cvt_pk_bf16_f32 in the
-// split the two waves' times add up (42.9 us without loads), with the truncating split below (v_and / v_sub / v_perm)
-// they overlap (33.4 us).  The pieces differ from k_scatter_strip's (truncated, not rounded), their sum is x either way.
-constexpr float SR_F16_SCALE = 256.f;    // the f16 experiment: X = 256 x (|x| < 255.9)
-constexpr int SR_AHEAD = (MMG_SR_ABL & 2048) ? 2 : ((MMG_SR_ABL & 1024) ? 4 : 6), SR_RING = 8;
-template <int NT> struct SrLds {
-  static constexpr int B_BYTES = 3 * 64 * 16;             // one k-step of B pieces
-  static constexpr int W_BYTES = NT * 64 * 8;             // one stage of bit-plane words (lane-major per tile)
-  static constexpr int PAIR = 2 * (B_BYTES + W_BYTES);    // both double-buffered
-  static constexpr int RED = 4 * ST_TP * 16 * 64 * 4;     // the final cross-wave sum (aliases the pair buffers)
-  static constexpr int TOTAL = 4 * PAIR > RED ? 4 * PAIR : RED;
-};
-
-// TWO f16 pieces of 8 scaled values (hi = f16(X), lo = f16(X - hi): 22 significant bits, relative error <= 2^-22 while
-// 2^-3 <= |X| < 65504; below that the residual is an f16 denormal, absolute error 2^-25)
-typedef _Float16 f16x2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split8_h(const float* v, float scale, u32x4s& p0, u32x4s& p1) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float a0 = v[2 * j] * scale, a1 = v[2 * j + 1] * scale;
-    const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
-    const _Float16 l0 = (_Float16)(a0 - (float)h0), l1 = (_Float16)(a1 - (float)h1);
-    const f16x2s hh = {h0, h1}, ll = {l0, l1};
-    p0[j] = __builtin_bit_cast(unsigned, hh); p1[j] = __builtin_bit_cast(unsigned, ll);
-  }
-}
-
-template <int NT, bool F16>
-__device__ __forceinline__ void roles_producer(const RelPack& rp, int64_t n_rows, int n_stage_total, int D,
-                                               const float* __restrict__ x, int s_beg, int ns, int G, unsigned char* pl) {
-  using L = SrLds<NT>;
-  const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
-  const int d0 = blockIdx.y * 32;
-  const int64_t r_beg = (int64_t)s_beg * SB_SR;
-  int64_t rows_here = n_rows - r_beg;
-  if (rows_here > (int64_t)ns * SB_SR) rows_here = (int64_t)ns * SB_SR;
-  if (rows_here < 0) rows_here = 0;
-  const float* xw = x + (size_t)(rows_here > 0 ? r_beg : 0) * D + d0;
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(xw), 0, rows_here > 0 ? (int)((rows_here * D - d0) * 4) : 0, 0x00020000);
-  // x: lane (r = lane / 8, c = lane % 8) loads 16 bytes of row r and of row r + 8 of the k-step (two instructions per
-  // k-step instead of eight dword loads: the texture addresser takes a wave instruction per ~16 cycles whatever its
-  // width, and with 8 + 9 loads per k-step and wave it, not HBM, paced the kernel; 64 loads in flight also saturate vmcnt)
-  const unsigned row_bytes = (unsigned)D * 4u;
-  const unsigned voff0 = (unsigned)(lane >> 3) * row_bytes + (unsigned)(lane & 7) * 16u;
-  float xq[SR_RING][8];
-  auto loadx = [&](int kg, float* dst) {
-    const unsigned vo = voff0 + (unsigned)kg * 16u * row_bytes;
-    if (MMG_SR_ABL & 2) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dst[j] = __builtin_bit_cast(float, vo + j);
-      if (MMG_SR_ABL & 8192) {                         // the loads are issued, nothing waits for them
-        f32x4s t0, t1;
-        asm volatile("buffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen"
-                     : "=&v"(t0), "=&v"(t1) : "v"(vo), "s"(xsrc), "s"(8 * row_bytes));
-      }
-      return;
-    }
-    // (bit-cast to a FLOAT vector: cast to an unsigned ext_vector, this clang narrows the load to one dword and splats it)
-    const f32x4s a = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(xsrc, vo, 0, (MMG_SR_ABL & 4096) ? 2 : 0));
-    const f32x4s b = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(xsrc, vo, 8 * row_bytes, (MMG_SR_ABL & 4096) ? 2 : 0));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { dst[j] = a[j]; dst[4 + j] = b[j]; }
-  };
-#pragma unroll
-  for (int q = 0; q < SR_RING; ++q) loadx(q, xq[q]);
-  // Bit-plane rows of this lane's items: the relations are packed back to back (a tile may straddle two of them), so
-  // every lane has its own pointer and stage stride per tile.  A lane without an item reads some valid word and drops
-  // it (lm) when the word goes to LDS.
-  const uint64_t* mb[NT];
-  unsigned ms[NT], lm[NT];
-  const uint64_t* any_mask = nullptr;
-#pragma unroll
-  for (int r = 0; r < MMG_MAX_REL; ++r)
-    if (r < rp.n && rp.r[r].mask && !any_mask) any_mask = rp.r[r].mask;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    mb[t] = any_mask; ms[t] = 0; lm[t] = 0u;
-    const int it = t * 32 + l31;
-#pragma unroll
-    for (int r = 0; r < MMG_MAX_REL; ++r) {
-      if (r >= rp.n) continue;
-      const int padc = (rp.r[r].n_cols + 31) & ~31;
-      if (rp.r[r].mask && it >= rp.r[r].acc_off && it < rp.r[r].acc_off + rp.r[r].n_cols) {
-        mb[t] = rp.r[r].mask + (size_t)(it - rp.r[r].acc_off) * 2 + h;
-        ms[t] = 2u * (unsigned)padc; lm[t] = ~0u;
-      }
-    }
-  }
-  auto loadm = [&](int s, uint64_t* dst) {             // stage s of this pair, clamped to the planes (x reads as 0 past the end)
-    int sc = s_beg + s;
-    sc = sc < n_stage_total ? sc : n_stage_total - 1;
-    if (MMG_SR_ABL & 1) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t) dst[t] = (uint64_t)((unsigned)(sc * 16 + t * 48 + lane * 16) & 0xFF0u) * 0x0001000100010001ull;
-      return;
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) dst[t] = mb[t][(size_t)sc * ms[t]];
-  };
-  auto storem = [&](const uint64_t* w, int buf) {      // a stage's words, lane-major per tile
-    unsigned char* wb = pl + 2 * L::B_BYTES + buf * L::W_BYTES + lane * 8;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const u32x2s q = {(unsigned)w[t] & lm[t], (unsigned)(w[t] >> 32) & lm[t]};
-      *reinterpret_cast<u32x2s*>(wb + t * 512) = q;
-    }
-  };
-  uint64_t mw[2][NT];
-  loadm(0, mw[0]);
-  loadm(1, mw[1]);
-  // one k-step: the pieces of x -> B[buf], ROW-major ([piece][16 rows][32 columns] bf16, 64-byte rows): this lane's 4 + 4
-  // values are 8 bytes of row r and of row r + 8; the multipliers fetch their column slices with the transposing read
-  auto produce = [&](const float* xs, int buf) {
-    u32x4s b[3];
-    if (F16) split8_h(xs, SR_F16_SCALE, b[0], b[1]);
-    else split8_tr(xs, b[0], b[1], b[2]);
-    unsigned char* bb = pl + buf * L::B_BYTES + lane * 8;
-#pragma unroll
-    for (int p = 0; p < (F16 ? 2 : 3); ++p) {
-      const u32x2s lo = {b[p][0], b[p][1]}, hi = {b[p][2], b[p][3]};
-      *reinterpret_cast<u32x2s*>(bb + p * 1024) = lo;
-      *reinterpret_cast<u32x2s*>(bb + p * 1024 + 512) = hi;
-    }
-  };
-  storem(mw[0], 0);
-  loadm(2, mw[0]);
-  produce(xq[0], 0);
-  produce(xq[1], 1);
-  if (MMG_SR_ABL & 8) G = 0;
-  __syncthreads();                                     // (A) k-steps 0 and 1 and the words of stage 0 are in LDS
-  __syncthreads();                                     // (B) the multipliers hold k-step 0: its buffer may be rewritten
-  // iteration g produces k-step g + 2; the first k-step of stage s (g = 4 s - 2) takes the stage's words along, and the
-  // register slot (s & 1) is refilled with stage s + 2 at once: 8 k-steps of lead
-  for (int u = 0; u < G; u += SR_RING) {
-#pragma unroll
-    for (int ks = 0; ks < SR_RING; ++ks) {
-      if (u + ks >= G) break;
-      if ((ks & 3) == 2) {
-        const int s = (u + ks + 2) >> 2;               // 2 (u / 8) + 1 or + 2
-        storem(mw[((ks + 2) >> 2) & 1], ((ks + 2) >> 2) & 1);
-        loadm(s + 2, mw[((ks + 2) >> 2) & 1]);
-      }
-      produce(xq[(ks + 2) & (SR_RING - 1)], ks & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      loadx(u + ks + 2 + SR_AHEAD, xq[(ks + 2 + SR_AHEAD) & (SR_RING - 1)]);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-    }
-  }
-  if (MMG_SR_ABL & 8192) asm volatile("s_waitcnt vmcnt(0)");
-}
-
-template <int NT, bool F16>
-__device__ __forceinline__ void roles_multiplier(const unsigned (*lut)[4], int G, const unsigned char* pl, f32x16* acc) {   // (G by value: an ablation build zeroes it)
-  using L = SrLds<NT>;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  // B fragment (rows 8 h .. 8 h + 7 of column n = lane % 32) from the row-major image: ds_read_b64_tr_b16 hands a 16-lane
-  // group a block of 4 rows x 16 columns, lane 4 q + p supplying the address of row q, columns 4 p .. 4 p + 3
-  const int grp = lane >> 4, gi = lane & 15;
-  const unsigned char* bb = pl + (8 * (grp >> 1) + (gi >> 2)) * 64 + (16 * (grp & 1) + 4 * (gi & 3)) * 2;
-  const unsigned char* wb = pl + 2 * L::B_BYTES + lane * 8;
-  const unsigned char* lutb = reinterpret_cast<const unsigned char*>(&lut[0][0]);
-  bf16x8 af[NT], bc[3], bn[3];
-  u32x2s mwd[2][NT];                                   // the bit-plane words of the stage, slot = stage & 1
-  auto read_b = [&](int buf, bf16x8* b) {
-    typedef short s16x4s __attribute__((ext_vector_type(4)));
-    typedef short s16x8s __attribute__((ext_vector_type(8)));
-#pragma unroll
-    for (int p = 0; p < (F16 ? 2 : 3); ++p) {
-      const unsigned char* q = bb + buf * L::B_BYTES + p * 1024;
-      const s16x4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4s*)q);
-      const s16x4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4s*)(q + 256));
-      const s16x8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      b[p] = __builtin_bit_cast(bf16x8, v);
-    }
-  };
-  auto read_w = [&](int buf, u32x2s* w) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const u32x2s*>(wb + buf * L::W_BYTES + t * 512);
-  };
-  // field kq (k-step inside the stage) of a word = (8 patient bits) << 4 = the byte offset of the table entry
-  auto frag = [&](const u32x2s* w, int kq, int t) -> bf16x8 {
-    const unsigned d = w[t][(kq >> 1) & 1];
-    const unsigned off = (kq & 1) ? (d >> 16) : (d & 0xFFFFu);
-    return *reinterpret_cast<const bf16x8*>(lutb + off);
-  };
-  if (MMG_SR_ABL & 8) G = 0;
-  __syncthreads();                                     // (A)
-  read_b(0, bc);
-  read_w(0, mwd[0]);
-#pragma unroll
-  for (int t = 0; t < NT; ++t) af[t] = frag(mwd[0], 0, t);
-  __syncthreads();                                     // (B) (its lgkmcnt(0): k-step 0 has left LDS)
-  for (int u = 0; u < G; u += 8) {
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      if (u + ks >= G) break;
-      constexpr int dummy = 0; (void)dummy;
-      const int sn = ((ks + 1) >> 2) & 1;              // slot of the stage of k-step g + 1
-      read_b((ks + 1) & 1, bn);                        // k-step g + 1 (written one barrier ago or earlier)
-      if ((ks & 3) == 3) read_w(sn, mwd[sn]);          // ... opens a stage: its words (written five barriers ago)
-      typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
-      auto mma = [&](int t, int p) {
-        if ((MMG_SR_ABL & 4) && t != 0) return;
-        if (F16) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, af[t]), __builtin_bit_cast(f16x8s, bc[p]), acc[t], 0, 0, 0);
-        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bc[p], acc[t], 0, 0, 0);
-      };
-      constexpr int NP = F16 ? 2 : 3, NRD = 2 * NP;    // passes over the tiles; LDS reads of a k-step's pieces
-#pragma unroll
-      for (int p = 0; p < NP - 1; ++p)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) mma(t, p);
-      // one LDS read behind each of the first matrix instructions (a cluster of reads in front of them stalls the
-      // in-order wave on the LDS queue)
-#pragma unroll
-      for (int i = 0; i < (NP - 1) * NT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < NRD + ((ks & 3) == 3 ? NT : 0)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, NRD + NT, 0);    // (what did not fit behind the first pass of the f16 form)
-      __builtin_amdgcn_sched_barrier(0);               // (matrix instructions are not memory operations: unpinned, the
-      __syncthreads();                                 //  barrier and its wait rise to the top of the iteration)
-      __builtin_amdgcn_sched_barrier(0);               // operands of g + 1 are in registers: the producer may rewrite them
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        mma(t, NP - 1);
-        af[t] = frag(mwd[sn], (ks + 1) & 3, t);        // the tile's fragment of k-step g + 1, in flight across the back edge
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      bc[0] = bn[0]; bc[1] = bn[1]; bc[2] = bn[2];
-    }
-  }
-}
-
-template <int NT, bool F16>
-__global__ __launch_bounds__(512) void k_scatter_roles(RelPack rp, int64_t n_rows, int n_stage_total, int D, int total_pad,
-                                                       const float* __restrict__ x, float* __restrict__ slab) {
-  __shared__ __attribute__((aligned(16))) unsigned lut[256][4];            // byte -> 8 bf16 in {0, 1}
-  extern __shared__ __attribute__((aligned(16))) unsigned char sr_lds[];   // 4 pair buffers, later [4][ST_TP * 16][64] floats
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = lane >> 5, l31 = lane & 31, w4 = wid & 3;
-  const int d0 = blockIdx.y * 32;
-  if (tid < 256) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      lut[tid][q] = ((tid >> (2 * q)) & 1 ? (F16 ? 0x3C00u : 0x3F80u) : 0u) | ((tid >> (2 * q + 1)) & 1 ? (F16 ? 0x3C000000u : 0x3F800000u) : 0u);
-  }
-  // 64-row stages dealt over (workgroup, pair): pair q takes base (+ 1 for the first rem pairs); G = the k-steps of the
-  // longest share of this workgroup (every wave runs G barriers).  Scalar on purpose: a share that reaches the per-lane
-  // pointer set-up in a vector register makes every buffer descriptor derived from it "divergent" (waterfall loops).
-  const unsigned n_q = gridDim.x * 4u;
-  const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)n_stage_total / n_q), rem = (unsigned)n_stage_total - base * n_q;
-  const unsigned q_id = blockIdx.x * 4u + (unsigned)w4;
-  const int G = 4 * (int)(base + (blockIdx.x * 4u < rem ? 1u : 0u));
-  const int s_beg = __builtin_amdgcn_readfirstlane((int)(q_id * base + (q_id < rem ? q_id : rem)));
-  const int ns = __builtin_amdgcn_readfirstlane((int)(base + (q_id < rem ? 1u : 0u)));
-  unsigned char* pl = sr_lds + w4 * SrLds<NT>::PAIR;
-  float* st_red = reinterpret_cast<float*>(sr_lds);
-  float* dst = slab + (size_t)blockIdx.x * total_pad * D + d0 + l31;
-  auto sum_store = [&](int t_first, int ntp) {         // every wave sums an eighth of the parked registers over the four pairs
-    const int nreg = ntp * 16;
-    for (int idx = wid * nreg / 8; idx < (wid + 1) * nreg / 8; ++idx) {
-      float v = st_red[((size_t)0 * ST_TP * 16 + idx) * 64 + lane];
-      v += st_red[((size_t)1 * ST_TP * 16 + idx) * 64 + lane];
-      v += st_red[((size_t)2 * ST_TP * 16 + idx) * 64 + lane];
-      v += st_red[((size_t)3 * ST_TP * 16 + idx) * 64 + lane];
-      const int i = idx & 15;
-      const int vrow = (t_first + (idx >> 4)) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      dst[(size_t)vrow * D] = v;
-    }
-  };
-#ifdef MMG_STAMPS
-#define SR_STAMP(i) do { if (lane == 0 && wid < 4) { \
-    g_stamps[(size_t)(blockIdx.y * gridDim.x * 4 + blockIdx.x * 4 + wid) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
-    g_stamps[(size_t)(blockIdx.y * gridDim.x * 4 + blockIdx.x * 4 + wid) * 8 + 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#else
-#define SR_STAMP(i) do { } while (0)
-#endif
-  SR_STAMP(0);
-  __syncthreads();                                     // the table
-  if (wid >= 4) {
-    roles_producer<NT, F16>(rp, n_rows, n_stage_total, D, x, s_beg, ns, G, pl);
-#pragma unroll
-    for (int t0 = 0; t0 < NT; t0 += ST_TP) {
-      __syncthreads();                                 // the pair buffers (or the previous phase) are dead
-      __syncthreads();                                 // parked
-      sum_store(t0, (NT - t0) < ST_TP ? (NT - t0) : ST_TP);
-    }
-  } else {
-    f32x16 acc[NT];
-    SR_STAMP(1);
-    roles_multiplier<NT, F16>(lut, G, pl, acc);
-    SR_STAMP(2);
-#pragma unroll
-    for (int t0 = 0; t0 < NT; t0 += ST_TP) {
-      __syncthreads();
-#pragma unroll
-      for (int t = 0; t < ST_TP; ++t)
-        if (t0 + t < NT) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) st_red[((size_t)w4 * ST_TP * 16 + t * 16 + i) * 64 + lane] = F16 ? acc[t0 + t][i] * (1.f / SR_F16_SCALE) : acc[t0 + t][i];
-        }
-      __syncthreads();
-      sum_store(t0, (NT - t0) < ST_TP ? (NT - t0) : ST_TP);
-    }
-    SR_STAMP(3);
-  }
-}
-
-template <int NT, bool F16>
-int launch_scatter_roles(const RelPack& rp, int64_t n_rows, int D, int n_ranges, int total_pad, const float* x, float* slab,
-                         hipStream_t st) {
-  constexpr int lds = SrLds<NT>::TOTAL;
-  MMG_CHECK_HIP((MmgMaxLds<&k_scatter_roles<NT, F16>, lds>::set()), "scatter_rows(attr)");
-  const int nst = (int)((n_rows + SB_SR - 1) / SB_SR);
-  MMG_LAUNCH(MMG_PROBE_SCATTER, n_rows, D, total_pad, 0, (k_scatter_roles<NT, F16>),
-             dim3((unsigned)n_ranges, (unsigned)(D / 32)), dim3(512), lds, st, rp, n_rows, nst, D, total_pad, x, slab);
-  return MMG_OK;
-}
-
-#endif   // MMG_SR_ABL
 
 // strip plan: instance (padded tile count) and number of row ranges; ok = false -> k_scatter_units / fp32 kernels
 struct StripPlan { bool ok; int nt; int n_ranges; int total_pad; };
@@ -1129,10 +727,14 @@ StripPlan plan_strip(const mmg_rel_t* rels, int n_rel, int64_t n_rows, int D) {
   }
   const int tiles = (items + 31) / 32;
   // (one wave holds every tile's accumulators + a double-buffered operand set: 10 tiles fill the 512 registers)
-  if (tiles == 0 || tiles > 11 || n_rows < SB_SR) return sp;
+  if (tiles == 0 || tiles > 11 || n_rows < SB_SR) return sp;      // (12+ tiles: the unit-per-wave kernel)
   if (has_rs) return sp;
-  const int inst[] = {4, 8, 9, 10, 11};                // 9 and 11 (the eICU and the MIMIC-III vocabularies): two waves per SIMD
-  for (int i = 0; i < 5; ++i)
+  // tiles of the instance: <4,4>, <5,4> (eICU vocabulary), <5,5>, <6,5>.  (No instance below four tiles per wave: a <2,2>
+  // build of the same code returned wrong sums in columns 16..31 of a strip in some launches -- only four matrix
+  // instructions per k-step between the rewrites of the piece registers; 40 launches of each instance kept are clean --
+  // so a small vocabulary runs the <4,4> instance with empty tiles.)
+  const int inst[] = {8, 9, 10, 11};
+  for (int i = 0; i < 4; ++i)
     if (tiles <= inst[i]) { sp.nt = inst[i]; break; }
   sp.total_pad = sp.nt * 32;
   const int strips = D / 32;
@@ -2188,15 +1790,10 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     RelPack rq;                                       // packed accumulator rows: acc_off = items in front of the relation
     int rc3 = pack(rels, n_rel, &rq, false, true, false);
     if (rc3) return rc3;
-    if (sp.nt == 4) rc2 = launch_scatter_strip<4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-    else if (sp.nt == 8) rc2 = launch_scatter_strip<8>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-#ifdef MMG_SR_ABL
-    else if (sp.nt == 9 && !(MMG_SR_ABL & 16) && (MMG_SR_ABL & 16384)) rc2 = launch_scatter_roles<9, true>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-    else if (sp.nt == 9 && !(MMG_SR_ABL & 16)) rc2 = launch_scatter_roles<9, false>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-#endif
+    if (sp.nt == 8) rc2 = launch_scatter_strip2<4, 4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     else if (sp.nt == 9) rc2 = launch_scatter_strip2<5, 4>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-    else if (sp.nt == 11) rc2 = launch_scatter_strip2<6, 5>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
-    else rc2 = launch_scatter_strip<10>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else if (sp.nt == 10) rc2 = launch_scatter_strip2<5, 5>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
+    else rc2 = launch_scatter_strip2<6, 5>(rq, n_rows, D, sp.n_ranges, sp.total_pad, x, slab, st);
     if (rc2) return rc2;
     const int64_t n = (int64_t)sp.total_pad * D;
     MMG_LAUNCH(MMG_PROBE_SCATTER_REDUCE, n_rows, D, sp.total_pad, 0, (mmg_k_reduce_slabs<EpiScatter>),
@@ -2244,11 +1841,6 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
   return MMG_OK;
 }
 
-#ifdef MMG_STAMPS
-extern "C" int mmg_debug_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8);
-}
-#endif
 
 extern "C" size_t mmg_rel_mask_words(int64_t n_rows, int32_t n_cols) {
   if (n_rows <= 0 || n_cols <= 0) return 0;

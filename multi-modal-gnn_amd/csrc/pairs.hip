@@ -1605,6 +1605,8 @@ extern "C" int mmg_pair_head_fwd_save(const mmg_head_t* head, const int32_t* pi,
   float* svh = saved ? saved->h2 : nullptr;
   const int sv_pos = saved && saved->by_position ? 1 : 0;
   MMG_CHECK_ARG(!sv_pos || sel, "pair_head_fwd_save: by_position needs a pair list");
+  MMG_CHECK_ARG(!saved || saved->n_entries >= (sv_pos ? n_pairs : n_total),
+                "pair_head_fwd_save: the saved buffers are shorter than the entries this launch can write");
   constexpr int lds_max = 256 * PF_LDB * (int)sizeof(float);
 #define MMG_LAUNCH_PFWD(BL_, SV_, LDS_, NL_)                                                                           \
   MMG_LAUNCH(MMG_PROBE_PAIR_FWD, n_pairs, 0, 0, (want_low ? 2 : 0) | (SV_ ? 512 : 0), (k_pair_fwd_mfma<BL_, SV_>),      \
@@ -1687,6 +1689,8 @@ extern "C" int mmg_pair_head_bwd_saved(const mmg_head_t* head, const mmg_head_gr
     const float* svh = saved ? saved->h2 : nullptr;
     const int sv_pos = saved && saved->by_position ? 1 : 0;
     MMG_CHECK_ARG(!sv_pos || sel, "pair_head_bwd_saved: by_position needs the pair list the forward ran over");
+    MMG_CHECK_ARG(!saved || saved->n_entries >= (sv_pos ? n_pairs : n_total),
+                  "pair_head_bwd_saved: the saved buffers are shorter than the entries this launch can read");
     if (n_labs <= 64) {
       if (saved) {
         if (aux) MMG_LAUNCH_PBWD((k_pair_bwd_duo6<2, true, true>), 512, svb, svh, sv_pos);

@@ -1284,7 +1284,8 @@ class _Run:
             # training: the forward leaves the first layer's sign bits and the second layer's activations of the pairs it
             # visits (136 B per pair) -- the backward then recomputes neither the dropout masks nor the 64 x 32 product
             # (indexed by list position -- dense -- when the backward is known to run over the same lists)
-            save = ops.pair_saved_alloc(pi.numel(), self.dev) + (self.static_select is self.forward_select,) \
+            by_pos = self.static_select is self.forward_select
+            save = ops.pair_saved_alloc(nb if by_pos else pi.numel(), self.dev) + (by_pos,) \
                 if self.T and SAVE_PAIR_STATE and self.forward_select is not None else None
             ops.pair_head_fwd(head, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr, want_low,
                               self.p, self.seed, ids, pred, self.seed_dev,

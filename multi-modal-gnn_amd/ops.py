@@ -113,27 +113,35 @@ def probe_read(cap: int = 1 << 16):
              bytes(nm[i]).split(b"\0", 1)[0].decode("ascii", "replace")) for i in range(n)]
 
 
-_WS = {}
-_WS_RETIRED = []      # outgrown workspaces: a captured hipGraph may hold their addresses, so they are never handed back
+_WS = {}              # key -> [buffer, handed out during a stream capture?]
+_WS_RETIRED = []      # outgrown workspaces a captured hipGraph may hold the address of: never handed back
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Growable scratch per (device, host thread, stream).  Reuse is stream-ordered: an op runs on the current stream,
     and neither two host threads nor two streams (the model overlaps its vocab-side work on a side stream) share a
-    buffer."""
+    buffer.  Growth is geometric (at least twice the old size: a sweep over growing shapes retires O(log n) buffers), and
+    an outgrown buffer is only kept alive if it was ever handed out DURING a stream capture -- a graph recorded then replays
+    kernels that write to it; one that no capture has seen goes back to the allocator."""
     import threading
     d = torch.device(device)
     key = (d.index if d.index is not None else torch.cuda.current_device(), threading.get_ident(),
            torch.cuda.current_stream().cuda_stream)
-    buf = _WS.get(key)
-    if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            # a step captured earlier on this stream replays kernels that write to the old buffer: if it went back to
-            # the allocator, the next tensor placed there (an index list, say) would be scribbled over by the replay
-            _WS_RETIRED.append(buf)
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _WS[key] = buf
-    return buf
+    ent = _WS.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None or ent[0].numel() < nbytes:
+        old = 0
+        if ent is not None:
+            old = ent[0].numel()
+            if ent[1]:
+                # a step captured earlier on this stream replays kernels that write to the old buffer: if it went back to
+                # the allocator, the next tensor placed there (an index list, say) would be scribbled over by the replay
+                _WS_RETIRED.append(ent[0])
+        ent = [torch.empty(max(int(nbytes), 2 * old, 1 << 20), dtype=torch.uint8, device=device), False]
+        _WS[key] = ent
+    if capturing:
+        ent[1] = True
+    return ent[0]
 
 
 @dataclass
@@ -799,23 +807,29 @@ def _pair_sizes(head: Head, pi, li, deg, pair_id, io_perm, per_pair):
 
 
 def pair_saved_alloc(n_total: int, device):
-    """Buffers of mmg_pair_saved_t for a pair set of n_total pairs: (h1 sign bits int32 [n_total, 2], layer-2 activations
-    float32 [n_total, 32]).  The forward fills the entries of the pairs it visits, the backward reads those it visits."""
+    """Buffers of mmg_pair_saved_t: (h1 sign bits int32 [n, 2], layer-2 activations float32 [n, 32]), 136 B per entry.
+    n = the pairs of the pair set (entries indexed by pair), or the launch bound of the head's pair list when the entries
+    are indexed by list position (by_position).  The forward fills the entries it visits, the backward reads those."""
     return (torch.empty(max(n_total, 1), 2, dtype=torch.int32, device=device),
             torch.empty(max(n_total, 1), 32, dtype=torch.float32, device=device))
 
 
-def _pair_saved(saved, n_total: int):
+def _pair_saved(saved, n_total: int, n_launch: int):
     """saved = (bits, h2) or (bits, h2, by_position): by_position -- entries indexed by the position in the pair list
-    instead of the pair index (dense); forward and backward must then run over the same list."""
+    instead of the pair index (dense); forward and backward must then run over the same list.  Sizes: one entry per pair
+    of the pair set (indexed by pair), or per list position the launch can reach (n_launch, its bound) when by_position."""
     if saved is None:
         return None
     bits, h2 = saved[0], saved[1]
     by_pos = bool(saved[2]) if len(saved) > 2 else False
-    if bits.dtype != torch.int32 or tuple(bits.shape) != (max(n_total, 1), 2) or h2.dtype != torch.float32 or \
-            tuple(h2.shape) != (max(n_total, 1), 32):
-        raise ValueError("pair head: saved = (int32 [n_total, 2], float32 [n_total, 32]) -- see pair_saved_alloc")
-    return PairSavedT(_p(bits, torch.int32).value, _p(h2).value, int(by_pos))
+    need = max(int(n_launch) if by_pos else int(n_total), 1)
+    if bits.dtype != torch.int32 or bits.dim() != 2 or bits.shape[1] != 2 or h2.dtype != torch.float32 or h2.dim() != 2 or \
+            h2.shape[1] != 32 or bits.shape[0] != h2.shape[0] or not bits.is_contiguous() or not h2.is_contiguous():
+        raise ValueError("pair head: saved = (int32 [n, 2], float32 [n, 32]) -- see pair_saved_alloc")
+    if bits.shape[0] < need:
+        raise ValueError(f"pair head: saved buffers hold {bits.shape[0]} entries, the launch reaches {need}"
+                         + (" list positions" if by_pos else " pairs"))
+    return PairSavedT(_p(bits, torch.int32).value, _p(h2).value, int(by_pos), int(bits.shape[0]))
 
 
 def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, seed: int, pair_id, pred, seed_dev=None,
@@ -829,7 +843,7 @@ def pair_head_fwd(head: Head, pi, li, deg, thr: int, want_low: bool, p: float, s
         return
     h = head.c()
     _pair_sizes(head, pi, li, deg, pair_id, io_perm, pred)
-    sv = _pair_saved(save, pi.numel())
+    sv = _pair_saved(save, pi.numel(), n)
     _tok = _pb("pair_head_fwd")
     check(lib.mmg_pair_head_fwd_save(C.byref(h), _p(pi, torch.int32), _p(li, torch.int32), _p(deg, torch.int32), thr,
                                      int(want_low), n, pi.numel(), min(int(head.A.shape[0]), deg.numel()),
@@ -858,7 +872,7 @@ def pair_head_bwd(head: Head, grads: Head, pi, li, deg, thr: int, want_low: bool
     _pair_sizes(head, pi, li, deg, pair_id, io_perm, dpred)
     if tuple(grads.A.shape) != tuple(head.A.shape) or tuple(grads.B.shape) != tuple(head.B.shape):
         raise ValueError("pair_head_bwd: gradient tables must have the shapes of A and B")
-    sv = _pair_saved(saved, pi.numel())
+    sv = _pair_saved(saved, pi.numel(), n)
     _tok = _pb("pair_head_bwd")
     check(lib.mmg_pair_head_bwd_saved(C.byref(h), C.byref(g), _p(pi, torch.int32), _p(li, torch.int32),
                                       _p(deg, torch.int32), thr, int(want_low), n, pi.numel(),

@@ -545,6 +545,76 @@ def _new_seed_state(dev) -> torch.Tensor:
     return st
 
 
+class _Recording:
+    """Device work recorded into hipGraphs and replayed: ONE graph, or -- for a patient-sharded model whose collectives
+    cannot be recorded (ShardComm.capturable() is false: gloo, or an RCCL that refuses) -- a CHAIN of graphs cut at every
+    ``ShardComm.all_reduce`` the body meets, with the all-reduces issued eagerly between the replays.  All segments share one
+    memory pool (static addresses), are recorded on one thread on the current stream, and replay in recording order.
+    ``capture_collectives``: None = ask the communicator; chosen once, never by retrying a failed recording."""
+
+    def __init__(self, comm, capture_collectives: Optional[bool] = None):
+        self.comm = comm
+        if comm is None:
+            self.capture_collectives = False
+        elif capture_collectives is None:
+            cap = getattr(comm, "capturable", None)
+            self.capture_collectives = bool(cap()) if cap is not None else False
+        else:
+            self.capture_collectives = bool(capture_collectives)
+        self.items = []
+        self.n_collectives = 0
+        self._cur = None
+        self._pool = None
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self._pool, capture_error_mode=capture_error_mode())
+        self._cur = g
+
+    def _end(self):
+        self._cur.capture_end()
+        self.items.append(("graph", self._cur))
+        self._cur = None
+
+    def _collective(self, t):
+        self.n_collectives += 1
+        if self.capture_collectives:       # recorded like any kernel of the body (RCCL on the capturing stream)
+            self.comm.raw_all_reduce(t)
+            return
+        self._end()
+        self.comm.raw_all_reduce(t)
+        self.items.append(("all_reduce", t))
+        self._begin()
+
+    def record(self, body):
+        """Run `body` once under stream capture on the CURRENT stream (the caller has warmed it up there)."""
+        self._pool = torch.cuda.graph_pool_handle()
+        self._begin()
+        if self.comm is not None:
+            self.comm.on_collective = self._collective
+        try:
+            body()
+        finally:
+            if self.comm is not None:
+                self.comm.on_collective = None
+            self._end()
+
+    def replay(self):
+        for kind, x in self.items:
+            if kind == "graph":
+                x.replay()
+            else:
+                self.comm.raw_all_reduce(x)
+
+    def release(self):
+        """Drop the hipGraphs (with recorded collectives their nodes ARE RCCL kernels) and the all-reduce tensors of the
+        chain: what a recording keeps alive that references the communicator."""
+        self.items = []
+        self._cur = None
+        self._pool = None
+        self.comm = None
+
+
 class GraphedTrainStep:
     """One whole training step -- zero_grad, predict_lab_values, weighted loss, backward, optimizer.step --
     captured ONCE into a hipGraph and replayed per epoch (the eICU-scale graph is launch-bound: ~250 kernel
@@ -683,16 +753,7 @@ class PiecewiseGraphedTrainStep:
         self.loss = torch.zeros((), device=dev)
         self.params = [p for p in model.parameters()]
         model.train()
-        self.items = []
-        self._cur = None
-        if comm is None:
-            self.capture_collectives = False
-        elif capture_collectives is None:
-            cap = getattr(comm, "capturable", None)
-            self.capture_collectives = bool(cap()) if cap is not None else False
-        else:
-            self.capture_collectives = bool(capture_collectives)
-        self.n_collectives = 0
+        self._rec = _Recording(comm, capture_collectives)
         snap = _snapshot_training_state(model, optimizer)           # warm-up and capture run REAL steps: undone below
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -700,49 +761,30 @@ class PiecewiseGraphedTrainStep:
             for _ in range(max(warmup, 1)):
                 self._body()
             torch.cuda.synchronize()
-            self._pool = torch.cuda.graph_pool_handle()
-            self._begin()
-            if comm is not None:
-                comm.on_collective = self._collective
-            try:
-                self._body()
-            finally:
-                if comm is not None:
-                    comm.on_collective = None
-                self._end()
+            self._rec.record(self._body)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         _restore_training_state(model, optimizer, snap)
 
-    # ---- recording
-    def _begin(self):
-        g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self._pool, capture_error_mode=capture_error_mode())
-        self._cur = g
+    # ---- what was recorded (tests and bench read these)
+    @property
+    def items(self):
+        return self._rec.items
 
-    def _end(self):
-        self._cur.capture_end()
-        self.items.append(("graph", self._cur))
-        self._cur = None
+    @property
+    def n_collectives(self) -> int:
+        return self._rec.n_collectives
 
-    def _collective(self, t):
-        self.n_collectives += 1
-        if self.capture_collectives:       # recorded like any kernel of the step (RCCL on the capturing stream)
-            self.comm.raw_all_reduce(t)
-            return
-        self._end()
-        self.comm.raw_all_reduce(t)
-        self.items.append(("all_reduce", t))
-        self._begin()
+    @property
+    def capture_collectives(self) -> bool:
+        return self._rec.capture_collectives
 
     def release(self):
-        """Drop what this step keeps alive that references the communicator or its streams -- the hipGraphs (with
-        captured collectives their nodes ARE RCCL kernels), the all-reduce tensors of the chain, the side-stream event --
-        so that `ShardComm.close` tears the group down with nothing of the step left.  The step cannot run afterwards."""
-        self.items = []
-        self._cur = None
+        """Drop what this step keeps alive that references the communicator or its streams -- the recording (hipGraphs,
+        all-reduce tensors of a chain), the side-stream event -- so that `ShardComm.close` tears the group down with
+        nothing of the step left.  The step cannot run afterwards."""
+        self._rec.release()
         self._sel_ready = None
-        self._pool = None
         self.comm = None
         self._sv.comm = None
 
@@ -818,11 +860,7 @@ class PiecewiseGraphedTrainStep:
     def step(self) -> torch.Tensor:
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()                    # a scheduler may have changed lr since the last replay
-        for kind, x in self.items:
-            if kind == "graph":
-                x.replay()
-            else:
-                self.comm.raw_all_reduce(x)
+        self._rec.replay()
         return self.loss
 
 
@@ -847,26 +885,25 @@ class GraphedEval:
         self.loss = self.pred = None
         self.comm = comm
         self._n_global = max(int(pi.numel()), 1)
-        self._loss_in_graph = False
         if comm is not None:
             n = torch.tensor([float(pi.numel())], dtype=torch.float64, device=pi.device)
             comm.raw_all_reduce(n)
             self._n_global = max(int(n.item()), 1)
-            cap = getattr(comm, "capturable", None)
-            self._loss_in_graph = bool(cap()) if cap is not None else False
             if self._loss_out is None:         # the all-reduce acts in place on a tensor the caller can read
                 self._loss_out = torch.zeros((), dtype=torch.float64, device=pi.device)
         was_training = model.training
         model.eval()
+        # a sharded eval forward meets collectives too (the vocab-side partial sums of every layer, the loss): recorded
+        # like the training step -- inside the one graph, or as a chain of segments (_Recording)
+        self._rec = _Recording(comm)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 1)):
                 self._body()
+            torch.cuda.synchronize()
+            self._rec.record(self._body)
         torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode()):
-            self._body()
         torch.cuda.synchronize()
         model.train(was_training)
 
@@ -881,16 +918,19 @@ class GraphedEval:
             (pred,) = run.run_forward("predict")
             self.loss, _ = ops.pair_loss(pred, self.y, None, None, 1.0 / self._n_global, self.loss_fn,
                                          loss_out=self._loss_out, want_dpred=False)
-            if self.comm is not None and self._loss_in_graph:
-                self.comm.raw_all_reduce(self.loss)
+            if self.comm is not None:
+                self.comm.all_reduce(self.loss)          # (through on_collective: recorded, or a cut of the chain)
             self.pred = pred
 
+    @property
+    def graph(self):
+        """The one hipGraph of an unsharded (or fully recorded) pass."""
+        return self._rec.items[0][1] if len(self._rec.items) == 1 else None
+
     def release(self):
-        self.graph = None
+        self._rec.release()
         self.comm = None
 
     def step(self) -> torch.Tensor:
-        self.graph.replay()
-        if self.comm is not None and not self._loss_in_graph:
-            self.comm.raw_all_reduce(self.loss)
+        self._rec.replay()
         return self.loss

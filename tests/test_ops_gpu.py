@@ -217,12 +217,14 @@ def test_aggregates_simple_graph_paths(ops, dev, D, n_rows):
 
 
 @pytest.mark.parametrize("D", [64, 128, 256])
-@pytest.mark.parametrize("n_rows", [64, 1000, 5000])
-def test_scatter_rows_eleven_tiles(ops, dev, D, n_rows):
-    """The 50 / 200 / 100 vocabulary of config 5 packs into 11 item tiles: the two-wave strip kernel's <6, 5> instance
-    (forward scatter, no rowscale), against scatter_mean in fp64."""
-    gen = torch.Generator().manual_seed(11 * D + n_rows)
-    sizes, degs = [50, 200, 100], [50, 9, 25]
+@pytest.mark.parametrize("n_rows", [64, 640, 1000, 5000])
+@pytest.mark.parametrize("sizes", [[50, 200, 100], [30, 40, 25], [60, 100, 90], [64, 150, 100], [20], [300, 90]])
+def test_scatter_rows_strip_instances(ops, dev, D, n_rows, sizes):
+    """Every instance of the two-wave strip kernel (forward scatter, no rowscale) against scatter_mean in fp64: 11 packed item
+    tiles <6, 5> (the 50 / 200 / 100 vocabulary of config 5), 3 -> <2, 2>, 8 -> <4, 4>, 10 -> <5, 5>, one tile, and 13 tiles
+    (beyond the strip instances: the unit-per-wave kernel)."""
+    gen = torch.Generator().manual_seed(11 * D + n_rows + sum(sizes))
+    degs = [min(50, sizes[0])] + [9, 25][:len(sizes) - 1]
     x = torch.randn(n_rows, D, generator=gen) * 2 - 0.4
     rels, refs = [], []
     for nc, md in zip(sizes, degs):
@@ -239,6 +241,90 @@ def test_scatter_rows_eleven_tiles(ops, dev, D, n_rows):
     ops.scatter_rows(rels, n_rows, D, x.to(dev))
     for r, f in zip(rels, first):
         assert torch.equal(r.out, f)                      # fixed-order sums: bit-reproducible
+
+
+def _simple_scatter_problem(ops, dev, gen, n_rows, sizes, degs, D):
+    rels, eis = [], []
+    for nc, md in zip(sizes, degs):
+        ei = simple_edges(gen, n_rows, nc, md)
+        rp, col = _csr(ops, dev, ei, n_rows)
+        mask, _ = ops.rel_mask_build(rp, col, nc)
+        rels.append(ops.Rel(rp, col, nc, out=torch.full((nc, D), 5.0, device=dev), simple=True, mask_t=mask))
+        # edges in CSR order (what the kernel's sums are compared with)
+        eis.append(torch.stack([torch.repeat_interleave(torch.arange(n_rows), (rp[1:] - rp[:-1]).cpu().long()),
+                                col.cpu().long()]))
+    return rels, eis
+
+
+@pytest.mark.parametrize("rowscale", [False, True])
+@pytest.mark.parametrize("sizes", [[50, 114, 100], [50, 200, 100]])
+def test_scatter_f16_pieces_follow_the_data_range(ops, dev, sizes, rowscale):
+    """The matrix-core scatter multiplies TWO f16 pieces of x * 2^e, e chosen per wave from the rows it streams and lowered
+    (accumulators rescaled, block split again) when a later block does not fit.  Whatever the magnitudes -- 1e-30 .. 1e+30,
+    rising, falling, one huge row in the middle, zero blocks at the start -- a sum must be as good as an fp32 running sum
+    of a handful of terms: the error is measured against the sum of |terms| of the SAME output element, so a small column
+    cannot hide behind a large one, and every output is finite.  Bar 6e-7: two f16 pieces carry 22 bits (2^-22 = 2.4e-7 per
+    term at worst), the matrix cores' fp32 accumulation adds a few 6e-8 (the exact three-bf16-piece kernels of the row-scaled
+    launches measure 3.7e-7 here), and in the steep `falling` / `rising` cases ONE term dominates a sum, so the per-term
+    bound is what is measured."""
+    D, n_rows = 128, 6000
+    gen = torch.Generator().manual_seed(len(sizes) * 97 + sizes[1] + int(rowscale))
+    rels, eis = _simple_scatter_problem(ops, dev, gen, n_rows, sizes, [50, 9, 25], D)
+    rs = [torch.rand(n_rows, generator=gen) + 0.25 for _ in rels]
+    if rowscale:
+        for r, w in zip(rels, rs):
+            r.rowscale = w.to(dev)
+    base = torch.randn(n_rows, D, generator=gen)
+    ramp = torch.linspace(-30, 30, n_rows)[:, None]
+    cases = {
+        "unit": base,
+        "tiny": base * 1e-30,
+        "huge": base * 1e30,
+        "rising": base * 10.0 ** ramp,                     # every row range starts small and ends large: e keeps falling
+        "falling": base * 10.0 ** (-ramp),
+        "spike": base.clone().index_put_((torch.tensor([3001]),), base[3001] * 1e25),
+        "zero_head": torch.cat([torch.zeros(1500, D), base[1500:] * 1e-12]),      # all-zero blocks before the first data
+        "columns": base * 10.0 ** torch.linspace(-6, 6, D)[None, :],              # columns of one strip 1e3 apart, strips 1e12
+    }
+    for name, x in cases.items():
+        x = x.float()
+        for r in rels:
+            r.out.fill_(5.0)
+        ops.scatter_rows(rels, n_rows, D, x.to(dev))
+        for r, ei, w in zip(rels, eis, rs):
+            xs = x.double() * (w.double()[:, None] if rowscale else 1.0)
+            xs = xs.float().double() if rowscale else xs                         # (the reference's own fp32 product)
+            ref = torch.zeros(r.n_cols, D, dtype=torch.float64).index_add_(0, ei[1], xs[ei[0]])
+            mag = torch.zeros(r.n_cols, D, dtype=torch.float64).index_add_(0, ei[1], xs[ei[0]].abs())
+            got = r.out.double().cpu()
+            assert torch.isfinite(got).all(), name
+            err = ((got - ref).abs() / mag.clamp(min=1e-300)).max().item() if mag.max() > 0 else 0.0
+            assert err <= 6e-7, (name, r.n_cols, err)
+            assert torch.equal(got[mag == 0], torch.zeros_like(got[mag == 0])), name
+
+
+def test_scatter_f16_pieces_nonfinite_inputs_stay_in_their_column(ops, dev):
+    """An infinity or a NaN in x[row, c] makes the sums of that row's items in column c non-finite (the matrix product also
+    multiplies it by the 0 of every other item of the block: NaN there too -- the stated deviation from index_add_, as in the
+    dense layers); every OTHER column is bitwise what it is without it: a non-finite value takes part in no scale decision."""
+    D, n_rows = 128, 3000
+    gen = torch.Generator().manual_seed(77)
+    rels, eis = _simple_scatter_problem(ops, dev, gen, n_rows, [50, 114, 100], [50, 9, 25], D)
+    x = torch.randn(n_rows, D, generator=gen)
+    ops.scatter_rows(rels, n_rows, D, x.to(dev))
+    clean = [r.out.clone() for r in rels]
+    for bad in (float("inf"), float("nan")):
+        xb = x.clone()
+        xb[1234, 17] = bad
+        ops.scatter_rows(rels, n_rows, D, xb.to(dev))
+        for r, ei, c in zip(rels, eis, clean):
+            hit = torch.zeros(r.n_cols, dtype=torch.bool)
+            hit[ei[1][ei[0] == 1234]] = True
+            got = r.out.cpu()
+            assert not torch.isfinite(got[hit, 17]).any()
+            keep = torch.ones(D, dtype=torch.bool)
+            keep[17] = False
+            assert torch.equal(got[:, keep], c.cpu()[:, keep])
 
 
 # ------------------------------------------------------------------------------------------ dense
