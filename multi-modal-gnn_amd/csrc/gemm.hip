@@ -361,29 +361,69 @@ __global__ __launch_bounds__(64 * WN, (WN == 4 && K <= 128) ? 2 : 1) void k_line
   }
 }
 
-// K = 256 with 256 output columns per workgroup: the [M, 256] x [256, 256] layers of the 256-d model (BASELINE config 4).
-// At this shape the six-term product is MATRIX-bound (384 matrix FLOP per byte against a machine balance of ~310), and
-// k_linear_fwd_x6<256, 4> spent half of its time outside the matrix pipe: two workgroups (one per 128-column slice, on
-// different CUs) each staged -- loaded, split, wrote to LDS -- the same X tile and read every A fragment for ONE 32-column
-// tile.  Here one workgroup owns all 256 columns: a wave holds the W pieces of TWO column tiles (384 registers; one wave
-// per SIMD has 512), so an X tile is staged once per CU, a fragment read feeds two products, and the staging of tile t+1
-// is woven between the products of tile t (one pass per two k-steps; its input register is refilled at once with tile
-// t+2, so ONE tile of X in registers keeps a full tile time of load latency).
-// PRO: 0 = none, 1 = any prologue (run-time tests), 2 = scale + shift and dropout both present: no branch inside a
-// staging pass, so a pass stays in the basic block of the products it is woven between.
-template <int PRO, bool ACC>
-__global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
+// ---------------------------------------------------------------------------------------------------------------------
+// k_linear_fwd_h3_k256 (round 4): the same layer on THREE f16 products instead of six bf16 ones -- half the matrix
+// instructions of a shape that is matrix-bound.  Every row of X and every row of W (an output column) gets its own power
+// of two: X = x * 2^ex with the row's largest magnitude in [2^13, 2^14), likewise W = w * 2^ew; each is split into
+//   hi = f16(V),  lo = f16((V - hi) * 2^11)          (22 significant bits; the low piece is scaled up by 2^11 so that it
+// is a NORMAL f16 wherever hi is: |V| >= 2^-14, i.e. within 2^-27 of the row's largest magnitude), and
+//   x . w * 2^(ex + ew) = Xh Wh + 2^-11 (Xh Wl + Xl Wh) + O(2^-22 |X||W|):
+// the first product goes to one fp32 accumulator, the two cross terms to a second one, combined and unscaled in the
+// epilogue.  The dropped Xl Wl is 2^-22 of a product, as are the two roundings of the low pieces: ~3 * 2^-22 = 7e-7 per
+// product against 2^-24 for the six-term bf16 split -- tests/test_ops_gpu.py holds the layer to 2e-6 of an fp64 reference
+// like the other kernels.  A row's scale comes from the row itself (wave = row while a tile is staged: one DPP reduction),
+// so the operand range is the fp32 range; an element more than 2^27 below its row's maximum loses relative precision, but
+// what it can add to a dot product with that row is below the rounding of the fp32 sum.  inf / NaN in a row of X: NaN in that
+// row of Y (as the bf16 kernels).  One workgroup of eight waves owns all 256 output columns (a wave: one 32-column tile, its W
+// pieces -- 128 registers -- resident; two waves per SIMD) and persists over 32-row tiles of X dealt round-robin: a tile is
+// staged ONCE per CU (prologue, row scale, split, two f16 planes in LDS, double-buffered), the staging of tile t+1 is woven
+// between the products of tile t, two tiles of X are in flight in registers.  Round 3's six-term kernel for this shape (four
+// waves, two column tiles and 384 registers of W pieces per wave) measured 147 us per [183400, 256] x [256, 256] call, this
+// one 102-112 (179 -> 122 with BatchNorm fold + ReLU + dropout in the prologue); its parts add up -- staging and epilogue
+// alone 48 us, + matrix instructions 32, + memory 29 -- the two waves of a SIMD run the same phase between the per-tile barriers.
+typedef _Float16 xf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 xf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 xf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float wave_max_dpp(float x) {      // -> the maximum over the 64 lanes, in a scalar register
+#define MMG_DPP_MAX(ctrl, rmask)                                                                                             \
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),   \
+                                                                     ctrl, rmask, 0xF, false)))
+  MMG_DPP_MAX(0xB1, 0xF);        // quad_perm [1,0,3,2]
+  MMG_DPP_MAX(0x4E, 0xF);        // quad_perm [2,3,0,1]
+  MMG_DPP_MAX(0x141, 0xF);       // row_half_mirror
+  MMG_DPP_MAX(0x140, 0xF);       // row_mirror
+  MMG_DPP_MAX(0x142, 0xA);       // row_bcast:15 -> rows 1, 3
+  MMG_DPP_MAX(0x143, 0xC);       // row_bcast:31 -> rows 2, 3
+#undef MMG_DPP_MAX
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+// exponent e with  m * 2^e in [2^13, 2^14)  for a normal m (0 for zero / denormal / inf / NaN), from the exponent field of m:
+// integer arithmetic only, so that a wave-uniform m (wave_max_dpp) keeps all of it on the scalar unit
+__device__ __forceinline__ int h3_exponent(float m) {
+  const int E = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xFFu);     // m = 1.f * 2^(E - 127)
+  const int e = 140 - E;
+  return (E == 0 || E == 255) ? 0 : (e > 126 ? 126 : e);
+}
+__device__ __forceinline__ float h3_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
+template <int PRO, bool ACC, bool STATS, int WN>      // WN = 4: two column tiles per wave; 8: one (two waves per SIMD)
+__global__ __launch_bounds__(64 * WN, 1) void k_linear_fwd_h3_k256(
     const float* __restrict__ X, ProDev pr, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, int64_t M, int N, int flags, double* __restrict__ stat_partial) {
-  constexpr int K = 256, CT = 2, LDP = K + 8, BN = 256, NK = K / 16, NTHR = 256, BM = 32;
+  constexpr int K = 256, CT = 8 / WN, LDP = K + 8, BN = 256, NK = K / 16, NTHR = 64 * WN, BM = 32;
+  constexpr int PLANE = BM * LDP;            // one piece of one buffer, in f16 elements
   if (PRO) pr.resolve();
-  extern __shared__ __attribute__((aligned(16))) __bf16 planes[];     // [2 buffers][3 pieces][BM][LDP]
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) _Float16 hplanes[];     // [2 buffers][2 pieces][BM][LDP], then float ex2[2][BM]
+  float* rowf = reinterpret_cast<float*>(hplanes + 2 * 2 * PLANE);       // 2^-ex of the staged rows, per buffer
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
   const int bx = blockIdx.x, by = blockIdx.y;
   const int c0 = bx * BN;
-  xbf16x8 wb[CT][NK][3];
-  float bv[CT];
+  xf16x8 wh[CT][NK], wl[CT][NK];
+  float bv[CT], cf[CT];                      // bias and 2^-ew of this lane's two columns
   {
     const bool wkn = (flags & MMG_LIN_W_KN) != 0;
 #pragma unroll
@@ -391,30 +431,43 @@ __global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
       const int col = c0 + (wn * CT + ct) * 32 + l31;
       bv[ct] = bias ? bias[col] : 0.f;
       const float* wp = wkn ? W + (size_t)(8 * h) * N + col : W + (size_t)col * K + 8 * h;
+      float wv[NK][8];
+      float m = 0.f;
 #pragma unroll
       for (int ks = 0; ks < NK; ++ks) {
-        f32x4 w0, w1;
         if (wkn) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { w0[j] = wp[(size_t)(ks * 16 + j) * N]; w1[j] = wp[(size_t)(ks * 16 + 4 + j) * N]; }
+          for (int j = 0; j < 8; ++j) wv[ks][j] = wp[(size_t)(ks * 16 + j) * N];
         } else {
-          w0 = *reinterpret_cast<const f32x4*>(wp + ks * 16); w1 = *reinterpret_cast<const f32x4*>(wp + ks * 16 + 4);
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + ks * 16), w1 = *reinterpret_cast<const f32x4*>(wp + ks * 16 + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wv[ks][j] = w0[j]; wv[ks][4 + j] = w1[j]; }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float v = j < 4 ? w0[j] : w1[j - 4];
-          const __bf16 a = (__bf16)v;
-          const float r1 = v - (float)a;
-          const __bf16 b = (__bf16)r1;
-          wb[ct][ks][0][j] = a; wb[ct][ks][1][j] = b; wb[ct][ks][2][j] = (__bf16)(r1 - (float)b);
+          const float a = fabsf(wv[ks][j]);
+          m = fmaxf(m, a < __builtin_inff() ? a : 0.f);
         }
       }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));             // the other half of the column's K (lane ^ 32)
+      const int ew = h3_exponent(m);
+      const float sw = h3_pow2(ew > 126 ? 126 : ew);
+      cf[ct] = h3_pow2(-(ew > 126 ? 126 : ew));
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = wv[ks][j] * sw;
+          const _Float16 a = (_Float16)v;
+          wh[ct][ks][j] = a;
+          wl[ct][ks][j] = (_Float16)((v - (float)a) * 2048.f);
+        }
     }
   }
   constexpr int K4 = K / 4, ROWS_PER_PASS = NTHR / K4, NP = BM / ROWS_PER_PASS;      // 64 quads, 4 rows per pass, 8 passes
-  static_assert(NK == 2 * NP, "one staging pass per two k-steps");
-  const int kc4 = tid % K4, prow = tid / K4;
-  // (the prologue's scale / shift quads are re-read from L1 in every pass: eight registers the wave does not have)
+  constexpr int KPP = NK / NP;               // k-steps per staging pass (2 | 4)
+  static_assert(NK % NP == 0 && K4 == 64, "a staging pass every KPP k-steps; a wave stages one row per pass");
+  const int kc4 = lane, prow = wn;           // (tid % K4, tid / K4)
   float floor_v = -__builtin_inff();
   bool drop = false;
   if (PRO) {
@@ -435,15 +488,17 @@ __global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
                                              0x00020000);
   };
   const int xvo = (prow * K + kc4 * 4) * 4;
-  f32x4 nx[NP];                              // ONE tile of X in registers (see the header)
-  auto fetch_pass = [&](__amdgpu_buffer_rsrc_t rs, int p) __attribute__((always_inline)) {
-    nx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
+  // TWO tiles of X in registers (the six-term kernel had room for one): a workgroup per CU with one 32 KB tile in flight
+  // is 8 MB on the chip -- at ~2 us of loaded HBM latency a ceiling of ~4 TB/s; the freed W-piece registers hold the second
+  f32x4 nx[2][NP];
+  auto fetch_pass = [&](__amdgpu_buffer_rsrc_t rs, int slot, int p) __attribute__((always_inline)) {
+    nx[slot][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, xvo, p * ROWS_PER_PASS * K * 4, MMG_NT_LD));
   };
-  auto stage_pass = [&](int64_t tile, int buf, int p) __attribute__((always_inline)) {
+  auto stage_pass = [&](int64_t tile, int buf, int slot, int p) __attribute__((always_inline)) {
     const int64_t row0 = tile * BM;
-    __bf16* pb = planes + (size_t)buf * 3 * BM * LDP;
+    _Float16* pb = hplanes + (size_t)buf * 2 * PLANE;
     const int r = p * ROWS_PER_PASS + prow;
-    f32x4 v = nx[p];
+    f32x4 v = nx[slot][p];
     if (PRO) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (PRO == 2 || pr.scale) {
@@ -455,77 +510,93 @@ __global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
       if (PRO == 2 || drop)
         mmg_drop4(v, pr.key, (uint64_t)(pr.row_offset + row0 + r) * (uint64_t)K + (uint64_t)(kc4 * 4), pr.thr, pr.inv_keep);
     }
-    xbf16x4 q0, q1, q2;
+    // the row's scale: this wave holds the whole row (64 quads)
+    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    m = wave_max_dpp(m);
+    const int ex = h3_exponent(m);
+    const float sx = h3_pow2(ex);
+    xf16x4 qh, ql;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const __bf16 a = (__bf16)v[j];
-      const float r1 = v[j] - (float)a;
-      const __bf16 b = (__bf16)r1;
-      q0[j] = a; q1[j] = b; q2[j] = (__bf16)(r1 - (float)b);
+    for (int j = 0; j < 4; j += 2) {
+      const f32x2 a = {v[j] * sx, v[j + 1] * sx};
+      const xf16x2 hh = __builtin_convertvector(a, xf16x2);
+      const f32x2 rr = {(a[0] - (float)hh[0]) * 2048.f, (a[1] - (float)hh[1]) * 2048.f};
+      const xf16x2 ll = __builtin_convertvector(rr, xf16x2);
+      qh[j] = hh[0]; qh[j + 1] = hh[1]; ql[j] = ll[0]; ql[j + 1] = ll[1];
     }
-    *reinterpret_cast<xbf16x4*>(pb + (0 * BM + r) * LDP + kc4 * 4) = q0;
-    *reinterpret_cast<xbf16x4*>(pb + (1 * BM + r) * LDP + kc4 * 4) = q1;
-    *reinterpret_cast<xbf16x4*>(pb + (2 * BM + r) * LDP + kc4 * 4) = q2;
+    *reinterpret_cast<xf16x4*>(pb + (0 * BM + r) * LDP + kc4 * 4) = qh;
+    *reinterpret_cast<xf16x4*>(pb + (1 * BM + r) * LDP + kc4 * 4) = ql;
+    if (lane == 0) rowf[buf * BM + r] = h3_pow2(-ex);
   };
   {
-    const __amdgpu_buffer_rsrc_t r0 = x_rsrc(t0), r1 = x_rsrc(t0 + G);
+    const __amdgpu_buffer_rsrc_t r0 = x_rsrc(t0), r1 = x_rsrc(t0 + G), r2 = x_rsrc(t0 + 2 * G);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) fetch_pass(r0, p);
+    for (int p = 0; p < NP; ++p) fetch_pass(r0, 0, p);
 #pragma unroll
-    for (int p = 0; p < NP; ++p) { stage_pass(t0, 0, p); fetch_pass(r1, p); }
+    for (int p = 0; p < NP; ++p) fetch_pass(r1, 1, p);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { stage_pass(t0, 0, 0, p); fetch_pass(r2, 0, p); }
   }
   __syncthreads();
-  double cs1[CT] = {0.0, 0.0}, cs2[CT] = {0.0, 0.0};
-  for (int i = 0; i < n_my; ++i) {
+  double cs1[CT] = {}, cs2[CT] = {};
+  // (two tiles per trip: the register slot of a tile is its parity, a compile-time index)
+  for (int i2 = 0; i2 < n_my; i2 += 2) {
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int i = i2 + par;
+    if (i >= n_my) break;
     const int64_t tt = t0 + (int64_t)i * G;
-    const int buf = i & 1;
+    const int buf = par;
     const int rows = rows_of(tt);
     const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(
         Y + (size_t)(rows ? tt : 0) * BM * N + c0, 0, rows ? (rows * N - c0) * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xs2 = x_rsrc(tt + 2 * G);     // refills: the tile after next
-    f32x16 acc[CT];
+    const __amdgpu_buffer_rsrc_t xs3 = x_rsrc(tt + 3 * G);     // refills: three tiles ahead (slot of tile t + 1)
+    f32x16 ah[CT], al[CT];
+    float yold[ACC ? CT : 1][16];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int yvo = ((4 * h) * N + (wn * CT + ct) * 32 + l31) * 4;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        acc[ct][r] = ACC ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, yvo, ((r & 3) + 8 * (r >> 2)) * N * 4, 0))
-                         : 0.f;
+      for (int r = 0; r < 16; ++r) {
+        ah[ct][r] = 0.f; al[ct][r] = 0.f;
+        if (ACC) yold[ct][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ys, yvo, ((r & 3) + 8 * (r >> 2)) * N * 4, 0));
+      }
     }
-    const __bf16* ap = planes + (size_t)buf * 3 * BM * LDP + l31 * LDP + 8 * h;
-    constexpr int NF = PRO ? 1 : 2;          // (with a prologue: no room for the second fragment set)
-    xbf16x8 fr[NF][3];
-    auto ldfrag = [&](int ks, xbf16x8* f) __attribute__((always_inline)) {
-      f[0] = *reinterpret_cast<const xbf16x8*>(ap + ks * 16);
-      f[1] = *reinterpret_cast<const xbf16x8*>(ap + BM * LDP + ks * 16);
-      f[2] = *reinterpret_cast<const xbf16x8*>(ap + 2 * BM * LDP + ks * 16);
+    const _Float16* ap = hplanes + (size_t)buf * 2 * PLANE + l31 * LDP + 8 * h;
+    xf16x8 fr[2][2];
+    auto ldfrag = [&](int ks, xf16x8* f) __attribute__((always_inline)) {
+      f[0] = *reinterpret_cast<const xf16x8*>(ap + ks * 16);
+      f[1] = *reinterpret_cast<const xf16x8*>(ap + PLANE + ks * 16);
     };
-    if (NF == 2) ldfrag(0, fr[0]);
+    ldfrag(0, fr[0]);
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-      const bool pass = (ks & 1) == 1;
-      if (NF == 2) { if (ks + 1 < NK) ldfrag(ks + 1, fr[(ks + 1) & (NF - 1)]); } else ldfrag(ks, fr[0]);
-      const xbf16x8* f = fr[ks & (NF - 1)];
+      const bool pass = (ks % KPP) == KPP - 1;
+      if (ks + 1 < NK) ldfrag(ks + 1, fr[(ks + 1) & 1]);
+      const xf16x8* f = fr[ks & 1];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], wb[ct][ks][0], acc[ct], 0, 0, 0);   // small terms first
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ct][ks][2], acc[ct], 0, 0, 0);
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ct][ks][1], acc[ct], 0, 0, 0);
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], wb[ct][ks][0], acc[ct], 0, 0, 0);
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ct][ks][1], acc[ct], 0, 0, 0);
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], wb[ct][ks][0], acc[ct], 0, 0, 0);
+        al[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], wh[ct][ks], al[ct], 0, 0, 0);   // Xl Wh
+        al[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], wl[ct][ks], al[ct], 0, 0, 0);   // Xh Wl
+        ah[ct] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], wh[ct][ks], ah[ct], 0, 0, 0);   // Xh Wh
+
       }
-      if (pass) { stage_pass(tt + G, buf ^ 1, ks >> 1); fetch_pass(xs2, ks >> 1); }
+      if (pass) { stage_pass(tt + G, buf ^ 1, par ^ 1, ks / KPP); fetch_pass(xs3, par ^ 1, ks / KPP); }
 #pragma unroll
-      for (int q = 0; q < 12; ++q) {
+      for (int q = 0; q < 3 * CT; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                          // one MFMA
-        if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // a fragment read of the next k-step
-        if (pass) __builtin_amdgcn_sched_group_barrier(0x002, PRO ? 6 : 3, 0);      // a slice of the staging pass
-        if (pass && q >= 8 && q < 11) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // its three plane writes
-        if (pass && q == 11) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // the refill load
+        if (q < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // a fragment read of the next k-step
+        if (pass) __builtin_amdgcn_sched_group_barrier(0x002, (PRO ? 72 : 42) / (3 * CT), 0);   // a slice of the staging pass
+        if (pass && q >= 3 * CT - 3 && q < 3 * CT - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // its plane writes
+        if (pass && q == 3 * CT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // the refill load
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    // epilogue: y = (ah + 2^-11 al) * 2^-ex[row] * 2^-ew[col] + bias (+ the old tile)
+    const float* rf = rowf + buf * BM + 4 * h;
+    f32x4 rf4[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) rf4[g4] = *reinterpret_cast<const f32x4*>(rf + 8 * g4);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int yvo = ((4 * h) * N + (wn * CT + ct) * 32 + l31) * 4;
@@ -533,17 +604,21 @@ __global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
 #pragma unroll
       for (int r16 = 0; r16 < 16; ++r16) {
         const int r = (r16 & 3) + 8 * (r16 >> 2);
-        const float v = acc[ct][r16] + bv[ct];
+        float v = fmaf(al[ct][r16], 1.f / 2048.f, ah[ct][r16]) * (rf4[r16 >> 2][r16 & 3] * cf[ct]) + bv[ct];
+        if (ACC) v += yold[ct][r16];
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ys, yvo, r * N * 4, MMG_NT_ST);
-        const float vs = r + 4 * h < rows ? v : 0.f;
-        t1 += vs; t2 = fmaf(vs, vs, t2);
+        if (STATS) {
+          const float vs = r + 4 * h < rows ? v : 0.f;
+          t1 += vs; t2 = fmaf(vs, vs, t2);
+        }
       }
-      if (stat_partial) { cs1[ct] += (double)t1; cs2[ct] += (double)t2; }
+      if (STATS) { cs1[ct] += (double)t1; cs2[ct] += (double)t2; }
     }
     __syncthreads();                         // buf fully read, buf^1 fully written
   }
-  if (stat_partial) {
-    double* red = reinterpret_cast<double*>(planes);          // the planes are dead: every wave passed the last barrier
+  }
+  if (STATS) {
+    double* red = reinterpret_cast<double*>(hplanes);         // the planes are dead: every wave passed the last barrier
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       red[(h * 2 + 0) * BN + (wn * CT + ct) * 32 + l31] = cs1[ct];
@@ -557,14 +632,22 @@ __global__ __launch_bounds__(256, 1) void k_linear_fwd_x6_k256(
   }
 }
 
-template <int PRO, bool ACC>
-int launch_fwd_x6_k256_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
-                         int flags, hipStream_t st, double* stat_partial, int64_t gy) {
-  constexpr int lds = 2 * 3 * 32 * (256 + 8) * 2;
-  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_x6_k256<PRO, ACC>, lds>::set()), "linear_fwd(attr)");
-  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, 256, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0), (k_linear_fwd_x6_k256<PRO, ACC>),
-             dim3((unsigned)(N / 256), (unsigned)gy), dim3(256), lds, st, X, pr, W, bias, Y, M, N, flags, stat_partial);
+template <int PRO, bool ACC, bool STATS>
+int launch_fwd_h3_k256_vs(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                          int flags, hipStream_t st, double* stat_partial, int64_t gy) {
+  constexpr int lds = 2 * 2 * 32 * (256 + 8) * 2 + 2 * 32 * 4;
+  constexpr int WN = 8;                      // (WN = 4 -- two column tiles per wave, 424+ registers -- measured 122 us against 108)
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_h3_k256<PRO, ACC, STATS, WN>, lds>::set()), "linear_fwd(attr)");
+  MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, 256, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0),
+             (k_linear_fwd_h3_k256<PRO, ACC, STATS, WN>), dim3((unsigned)(N / 256), (unsigned)gy), dim3(64 * WN), lds, st, X, pr,
+             W, bias, Y, M, N, flags, stat_partial);
   return 0;
+}
+template <int PRO, bool ACC>
+int launch_fwd_h3_k256_v(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+                         int flags, hipStream_t st, double* stat_partial, int64_t gy) {
+  return stat_partial ? launch_fwd_h3_k256_vs<PRO, ACC, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+                      : launch_fwd_h3_k256_vs<PRO, ACC, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
 }
 
 // rows of partial statistics = grid.y of the K = 256, 256-column kernel
@@ -575,17 +658,17 @@ inline int64_t fwd_k256_rows(int64_t M, int N) {
   return gy > n_tiles ? n_tiles : gy;
 }
 
-int launch_fwd_x6_k256(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
+int launch_fwd_h3_k256(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                        int flags, hipStream_t st, double* stat_partial) {
   const bool pro = pr.scale || pr.relu || pr.p > 0.f, acc = (flags & MMG_LIN_ACCUMULATE) != 0;
   const int64_t gy = fwd_k256_rows(M, N);
   if (pro && pr.scale && pr.p > 0.f)
-    return acc ? launch_fwd_x6_k256_v<2, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
-               : launch_fwd_x6_k256_v<2, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
-  if (pro) return acc ? launch_fwd_x6_k256_v<1, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
-                      : launch_fwd_x6_k256_v<1, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
-  return acc ? launch_fwd_x6_k256_v<0, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
-             : launch_fwd_x6_k256_v<0, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
+    return acc ? launch_fwd_h3_k256_v<2, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+               : launch_fwd_h3_k256_v<2, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
+  if (pro) return acc ? launch_fwd_h3_k256_v<1, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+                      : launch_fwd_h3_k256_v<1, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
+  return acc ? launch_fwd_h3_k256_v<0, true>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy)
+             : launch_fwd_h3_k256_v<0, false>(X, pr, W, bias, Y, M, N, flags, st, stat_partial, gy);
 }
 
 inline int64_t fwd_x6_rows(int64_t M, int N, int BN, int K = 128) {   // grid.y of the bf16-split forward (= partial stat rows)
@@ -1513,7 +1596,7 @@ static int linear_fwd_stats_impl(const float* X, const mmg_prologue_t* pro, cons
       if (N % 128 == 0) rc = launch_fwd_x6<128, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
       else rc = launch_fwd_x6<128, 2>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
     } else if (N % 256 == 0) {
-      rc = launch_fwd_x6_k256(X, pr, W, bias, Y, M, N, accumulate, st, partial);     // one workgroup spans 256 columns
+      rc = launch_fwd_h3_k256(X, pr, W, bias, Y, M, N, accumulate, st, partial);     // one workgroup spans 256 columns
     } else {
       rc = launch_fwd_x6<256, 4>(X, pr, W, bias, Y, M, N, accumulate, st, partial);
     }

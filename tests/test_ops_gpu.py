@@ -375,6 +375,56 @@ def test_dense_kernels_over_the_fp32_range(ops, dev, M, sx, sw):
         assert rel(dx, dzr @ Wkn.double()) <= 2e-6
 
 
+@pytest.mark.parametrize("case", ["unit", "1e15", "1e-15", "1e30x1e-30", "rows", "cols", "sparse_rows"])
+def test_k256_layer_on_three_f16_products(ops, dev, case):
+    """The [M, 256] x [256, 256] layers of the 256-d model (BASELINE config 4) multiply three f16 products per tile with a
+    power-of-two scale per row of X and per row of W (k_linear_fwd_h3_k256).  Same bar as the six-term bf16 kernels -- 2e-6
+    of an fp64 reference, per ROW of the output here so that a small row cannot hide behind a large one -- at O(1), at
+    1e+-15 / 1e+-30, with rows (and weight rows) whose magnitudes are spread over 40 decades, and with mostly-zero rows;
+    with and without the BatchNorm / ReLU / dropout prologue, accumulating, and with the weight stored [K, N]."""
+    gen = torch.Generator().manual_seed(len(case))
+    M, N, K = 3000, 256, 256
+    x, W = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    if case == "1e15":
+        x, W, b = x * 1e15, W * 1e15, b * 1e30
+    elif case == "1e-15":
+        x, W, b = x * 1e-15, W * 1e-15, b * 1e-30
+    elif case == "1e30x1e-30":
+        x, W = x * 1e30, W * 1e-30
+    elif case == "rows":
+        x = x * 10.0 ** torch.linspace(-20, 20, M)[:, None]
+        b = b * 0
+    elif case == "cols":
+        W = W * 10.0 ** torch.linspace(-18, 18, N)[:, None]
+        b = b * 0
+    elif case == "sparse_rows":                       # ReLU / dropout style inputs: most entries exactly zero
+        x = x * (torch.rand(M, K, generator=gen) < 0.05)
+        x[5] = 0
+    ref = x.double() @ W.double().t() + b.double()
+    rowmax = ref.abs().amax(1, keepdim=True).clamp(min=1e-300)
+    colmax = ref.abs().amax(0, keepdim=True).clamp(min=1e-300)
+
+    def bar(y, r, tol=2e-6):
+        e = (y.double().cpu() - r).abs()
+        return bool(torch.isfinite(y).all()) and float((e / rowmax).max()) <= tol and (case != "cols" or float((e / colmax).max()) <= tol)
+
+    y = ops.linear_fwd(x.to(dev), W.to(dev), b.to(dev))
+    assert bar(y, ref)
+    y3 = ops.linear_fwd(x.to(dev), W.t().contiguous().to(dev), b.to(dev), w_kn=True)
+    assert torch.equal(y3, y)
+    y2 = ops.linear_fwd(x.to(dev), W.to(dev), None, out=y.clone(), accumulate=True)
+    assert bar(y2, 2 * ref - b.double(), 4e-6)
+    if case in ("unit", "sparse_rows"):
+        scale, shift = torch.rand(K, generator=gen) + 0.5, torch.randn(K, generator=gen) * 0.3
+        for p_drop in (0.0, 0.2):
+            pro = ops.Pro(scale.to(dev), shift.to(dev), True, p_drop, 77, 5)
+            yp = ops.linear_fwd(x.to(dev), W.to(dev), b.to(dev), pro=pro)
+            xp = _host_pro(ops, dev, x, scale, shift, True, p_drop, 77, 5)
+            refp = xp @ W.double().t() + b.double()
+            assert rel(yp, refp) <= 2e-6
+
+
 def test_dense_kernels_denormals_and_non_finite_inputs(ops, dev):
     """Edges of the range.  (1) Operands within ~2^8 of the smallest normal fp32 (1.18e-38): the low pieces of the split
     are bf16 denormals, which the matrix cores may flush, so the result degrades towards the first piece alone -- the
