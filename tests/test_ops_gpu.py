@@ -303,6 +303,42 @@ def test_scatter_f16_pieces_follow_the_data_range(ops, dev, sizes, rowscale):
             assert torch.equal(got[mag == 0], torch.zeros_like(got[mag == 0])), name
 
 
+@pytest.mark.parametrize("rowscale", [False, True])
+def test_scatter_on_heavy_tailed_rows_is_reproducible_and_accurate(ops, dev, rowscale):
+    """Gradient-like inputs -- log-normal magnitudes, rows whose scale varies by e^4, isolated spikes of 1e6 -- drive the f16
+    scatter through every rare path (scale lowered with the accumulators rescaled, outlier blocks multiplied exactly) many
+    times per launch: repeats must agree bit for bit and every sum must be fp32-class against the sum of |terms| of its own
+    element.  (A row-scaled strip kernel tried in round 4 failed exactly this; the row-scaled launches keep the exact
+    three-bf16-piece kernel.)"""
+    D, n_rows = 128, 20000
+    gen = torch.Generator().manual_seed(31 + int(rowscale))
+    rels, eis = _simple_scatter_problem(ops, dev, gen, n_rows, [50, 114, 100], [50, 9, 25], D)
+    rs = [torch.rand(n_rows, generator=gen) + 0.25 for _ in rels]
+    if rowscale:
+        for r, w in zip(rels, rs):
+            r.rowscale = w.to(dev)
+    base = torch.randn(n_rows, D, generator=gen)
+    spikes = base.clone()
+    spikes[torch.randint(0, n_rows, (60,), generator=gen), torch.randint(0, D, (60,), generator=gen)] *= 1e6
+    cases = {"lognormal": base * torch.exp(3 * torch.randn(n_rows, D, generator=gen)),
+             "rowscaled": base * torch.exp(4 * torch.randn(n_rows, 1, generator=gen)), "spikes": spikes}
+    for name, x in cases.items():
+        xd = x.float().to(dev)
+        ops.scatter_rows(rels, n_rows, D, xd)
+        first = [r.out.clone() for r in rels]
+        for _ in range(5):
+            ops.scatter_rows(rels, n_rows, D, xd)
+            for r, f in zip(rels, first):
+                assert torch.equal(r.out, f), name
+        for r, ei, w in zip(rels, eis, rs):
+            xs = x.float().double() * (w.double()[:, None] if rowscale else 1.0)
+            xs = xs.float().double() if rowscale else xs
+            ref = torch.zeros(r.n_cols, D, dtype=torch.float64).index_add_(0, ei[1], xs[ei[0]])
+            mag = torch.zeros(r.n_cols, D, dtype=torch.float64).index_add_(0, ei[1], xs[ei[0]].abs())
+            err = ((r.out.double().cpu() - ref).abs() / mag.clamp(min=1e-300)).max().item()
+            assert err <= 1.5e-6, (name, r.n_cols, err)       # (a dozen fp32 additions of terms 1e6 apart)
+
+
 def test_scatter_f16_pieces_nonfinite_inputs_stay_in_their_column(ops, dev):
     """An infinity or a NaN in x[row, c] makes the sums of that row's items in column c non-finite (the matrix product also
     multiplies it by the 0 of every other item of the block: NaN there too -- the stated deviation from index_add_, as in the
