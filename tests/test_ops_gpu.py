@@ -238,9 +238,10 @@ def test_scatter_rows_strip_instances(ops, dev, D, n_rows, sizes):
     first = [r.out.clone() for r in rels]
     for r, ref in zip(rels, refs):
         assert rel(r.out, ref) <= 1e-6
-    ops.scatter_rows(rels, n_rows, D, x.to(dev))
-    for r, f in zip(rels, first):
-        assert torch.equal(r.out, f)                      # fixed-order sums: bit-reproducible
+    for _ in range(12):                                   # fixed-order sums: bit-reproducible, launch after launch
+        ops.scatter_rows(rels, n_rows, D, x.to(dev))      # (a <2, 2> instance of this kernel was dropped for failing exactly this)
+        for r, f in zip(rels, first):
+            assert torch.equal(r.out, f)
 
 
 def _simple_scatter_problem(ops, dev, gen, n_rows, sizes, degs, D):
