@@ -101,8 +101,10 @@ from mmgnn.synth import make_graph  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA
 MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
+MFMA_F16_PEAK_TF = 2500.0    # dense f16 MFMA (same rate: v_mfma_f32_32x32x16_f16 / _bf16 issue once per 32 clocks)
 # the dense layers and the aggregates compute fp32 products as exact bf16 pieces on the bf16 matrix cores: 6 matrix
-# FLOP per algorithmic fp32 FLOP (linear layers, the pair forward's 64 x 32 layer), 3 (0/1-indicator aggregates)
+# FLOP per algorithmic fp32 FLOP (linear layers, the pair forward's 64 x 32 layer; 3 f16 products at K = N = 256: op_summary),
+# 3 (0/1-indicator aggregates on bf16 pieces; the forward scatter: 2 f16 pieces -- they carry no algorithmic FLOPs here)
 MFMA_PEAK_BY_OP = {"linear_fwd": MFMA_BF16_PEAK_TF / 6, "linear_wgrad": MFMA_BF16_PEAK_TF / 6,
                    "gather_rows": MFMA_BF16_PEAK_TF / 3, "scatter_rows": MFMA_BF16_PEAK_TF / 3,
                    "pair_head_fwd": MFMA_BF16_PEAK_TF / 6, "pair_head_bwd": MFMA_F32_PEAK_TF}
@@ -365,7 +367,10 @@ def op_summary(table, op, flags_mask=None, flags_val=None):
     t_ms = out.get("avg_ms_with_follower", out["avg_ms"])
     out["hbm_frac"] = (big["alg_bytes"] / (t_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if big["alg_bytes"] else None
     mf = MFMA_PEAK_BY_OP.get(op)
+    if op == "linear_fwd" and big["K"] == 256 and big["N"] % 256 == 0:
+        mf = MFMA_F16_PEAK_TF / 3            # k_linear_fwd_h3_k256: three f16 products per fp32 product
     out["mfma_frac"] = (big["alg_flops"] / (big["avg_ms"] * 1e-3) / 1e12) / mf if (mf and big["alg_flops"]) else None
+    out["mfma_peak_tf"] = mf
     return out
 
 
@@ -745,7 +750,8 @@ def main():
             mfma_frac = d["mfma_frac"] or 0.0
             if mfma_frac > hbm_frac:
                 roof = {"bound": "mfma", "achieved": d["alg_flops"] / (d["avg_ms"] * 1e-3) / 1e12,
-                        "peak": MFMA_PEAK_BY_OP[dominant], "unit": "TFLOP/s", "frac": mfma_frac, "traffic": None}
+                        "peak": d.get("mfma_peak_tf") or MFMA_PEAK_BY_OP[dominant], "unit": "TFLOP/s", "frac": mfma_frac,
+                        "traffic": None}
             else:
                 roof = {"bound": "hbm", "achieved": d["alg_bytes"] / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": hbm_frac, "traffic": None}
@@ -762,8 +768,8 @@ def main():
                                    "region; slab-sum kernels are added to the op they finish"})
             if d["alg_flops"] and d["mfma_frac"] is not None:     # north_star: matrix-core utilisation of the dense transform
                 roof["mfma_frac"] = d["mfma_frac"]
-                roof["mfma_frac_note"] = ("algorithmic fp32 FLOPs / time / (2.5 PFLOP/s dense bf16 / 6 products of the exact "
-                                          "six-term split)")
+                roof["mfma_frac_note"] = ("algorithmic fp32 FLOPs / time / (2.5 PFLOP/s dense bf16 or f16 / the matrix products "
+                                          "per fp32 product: 6 in the exact six-term bf16 split, 3 in the f16 form of K = 256)")
             pf = pmc_fractions(lookup(pmc, d["symbol"]), psrc, "roofline")
             if "mfma_busy_frac" in pf:
                 roof["mfma_busy_frac"] = pf["mfma_busy_frac"]

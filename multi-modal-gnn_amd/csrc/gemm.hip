@@ -636,10 +636,11 @@ template <int PRO, bool ACC, bool STATS>
 int launch_fwd_h3_k256_vs(const float* X, const ProDev& pr, const float* W, const float* bias, float* Y, int64_t M, int N,
                           int flags, hipStream_t st, double* stat_partial, int64_t gy) {
   constexpr int lds = 2 * 2 * 32 * (256 + 8) * 2 + 2 * 32 * 4;
-  constexpr int WN = 8;                      // (WN = 4 -- two column tiles per wave, 424+ registers -- measured 122 us against 108)
-  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_h3_k256<PRO, ACC, STATS, WN>, lds>::set()), "linear_fwd(attr)");
+  // eight waves (WN = 4 -- two column tiles per wave, 424+ registers -- measured 122 us against 108); the literal is
+  // written out so that the probe records the instantiated symbol
+  MMG_CHECK_HIP((MmgMaxLds<&k_linear_fwd_h3_k256<PRO, ACC, STATS, 8>, lds>::set()), "linear_fwd(attr)");
   MMG_LAUNCH(MMG_PROBE_LINEAR_FWD, M, N, 256, (flags & MMG_LIN_ACCUMULATE) | (PRO ? 4 : 0),
-             (k_linear_fwd_h3_k256<PRO, ACC, STATS, WN>), dim3((unsigned)(N / 256), (unsigned)gy), dim3(64 * WN), lds, st, X, pr,
+             (k_linear_fwd_h3_k256<PRO, ACC, STATS, 8>), dim3((unsigned)(N / 256), (unsigned)gy), dim3(64 * 8), lds, st, X, pr,
              W, bias, Y, M, N, flags, stat_partial);
   return 0;
 }
