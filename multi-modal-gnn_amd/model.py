@@ -229,6 +229,27 @@ class HeteroRGCN(nn.Module):
         run = _Run(self, data)
         return run.apply("predict", patient_indices, lab_indices)
 
+    def configure_execution(self, overlap: Optional[str] = None, next_bn=None, save_pair_state: Optional[bool] = None):
+        """Per-model execution switches (None = keep / fall back to the module-level default): `overlap` 'auto' | 'off' |
+        'on' (vocab-side work of a layer on a side stream), `next_bn` = the BatchNorm-backward statistics taken from
+        producer epilogues (subset of {'heads', 'conv', 'enc2', 'enc1'}), `save_pair_state` = the heads' forward leaves its
+        layer states for the backward.  Results do not depend on any of them; a step captured earlier keeps what it was
+        recorded with."""
+        ex = dict(getattr(self, "_exec", None) or {})
+        if overlap is not None:
+            if overlap not in ("auto", "off", "on"):
+                raise ValueError(f"overlap mode must be 'auto', 'off' or 'on', got {overlap!r}")
+            ex["overlap"] = overlap
+        if next_bn is not None:
+            sites = frozenset(next_bn)
+            if not sites <= {"heads", "conv", "enc2", "enc1"}:
+                raise ValueError(f"unknown next-BatchNorm site(s): {sorted(sites - {'heads', 'conv', 'enc2', 'enc1'})}")
+            ex["next_bn"] = sites
+        if save_pair_state is not None:
+            ex["save_pair_state"] = bool(save_pair_state)
+        self._exec = ex
+        return self
+
     # pairs sorted by patient (cached: the split is static across epochs)
     def _pairs(self, pi: torch.Tensor, li: torch.Tensor, n_rows: int, pair_ids: Optional[torch.Tensor] = None,
                deg: Optional[torch.Tensor] = None, thr: int = 0):
@@ -361,7 +382,13 @@ class _Run:
         # The vocab-side work of a layer (tables of 50..200 rows: ~40 launches of a few microseconds each, a pure
         # dependency chain) runs on a side stream underneath the patient-side kernels of the same layer
         # (OVERLAP_MODE / set_overlap).  Sharded runs keep every collective on the main stream.
-        self.overlap = OVERLAP_MODE == "on" or (OVERLAP_MODE == "auto" and self.plan.n_rows >= 16384)
+        # Execution switches: the MODEL's own setting where it has one (HeteroRGCN.configure_execution: two models of a
+        # process can differ), else the module-level default (set_overlap / set_next_bn / SAVE_PAIR_STATE).
+        ex = getattr(model, "_exec", None) or {}
+        mode = ex.get("overlap") or OVERLAP_MODE
+        self.next_bn_sites = ex["next_bn"] if ex.get("next_bn") is not None else NEXT_BN_SITES
+        self.save_pair_state = ex["save_pair_state"] if ex.get("save_pair_state") is not None else SAVE_PAIR_STATE
+        self.overlap = mode == "on" or (mode == "auto" and self.plan.n_rows >= 16384)
         if self.overlap:
             if getattr(model, "_side_stream", None) is None:
                 model._side_stream = torch.cuda.Stream(device=self.dev)
@@ -738,7 +765,7 @@ class _Run:
         else:
             # the statistics of the second BatchNorm's backward come out of the epilogue of the GEMM that produces its
             # upstream gradient (the separate pass read g and z2 once more)
-            if "enc2" in NEXT_BN_SITES:
+            if "enc2" in self.next_bn_sites:
                 dz3, g, sums = ops.linear_l2bwd(g_x0.contiguous(), enc["x0"], enc["rn"], self.W(f"{pt}.8.weight"),
                                                 next_bn=ops.NextBN(enc["z2"], enc["pro2"], enc["f2"]))
             else:
@@ -755,7 +782,7 @@ class _Run:
         pt = "patient_transform"
         g, sums = state
         y, pro, fold = enc["z2"], enc["pro2"], enc["f2"]
-        nxt = (nstats, enc["pro1"]) if nstats is not None and nstats.fold is not None and "enc1" in NEXT_BN_SITES else None
+        nxt = (nstats, enc["pro1"]) if nstats is not None and nstats.fold is not None and "enc1" in self.next_bn_sites else None
         if enc.get("rows") is not None:
             # an upstream gradient that is zero outside the listed rows (training statistics): the dense apply pass never
             # reads a gradient tensor, the listed rows are patched afterwards
@@ -1185,7 +1212,7 @@ class _Run:
             if rels:
                 nb = None
                 if below is not None and ROW_TYPE in below["y"] and below["folds"].get(ROW_TYPE) is not None and \
-                        "conv" in NEXT_BN_SITES:
+                        "conv" in self.next_bn_sites:
                     nb = ops.NextBN(below["y"][ROW_TYPE], below["pros"][ROW_TYPE], below["folds"][ROW_TYPE])
                 acc_ = g_in[ROW_TYPE] is not None
                 if not acc_:
@@ -1286,7 +1313,7 @@ class _Run:
             # (indexed by list position -- dense -- when the backward is known to run over the same lists)
             by_pos = self.static_select is self.forward_select
             save = ops.pair_saved_alloc(nb if by_pos else pi.numel(), self.dev) + (by_pos,) \
-                if self.T and SAVE_PAIR_STATE and self.forward_select is not None else None
+                if self.T and self.save_pair_state and self.forward_select is not None else None
             ops.pair_head_fwd(head, pi_low if want_low else pi, li, deg_low if want_low else plan.lab_deg, thr, want_low,
                               self.p, self.seed, ids, pred, self.seed_dev,
                               sel=sel, n_sel=n_sel, n_bound=nb, io_perm=perm, save=save)   # written in the caller's pair order
@@ -1375,7 +1402,7 @@ class _Run:
                 else:
                     gP = None                    # single GPU, no such row anywhere: the whole pass contributes exactly 0
                 gsets[which] = {ROW_TYPE: gP, "lab": glab}
-            elif isinstance(xP, _LazyAct) and xP.fold is not None and "heads" in NEXT_BN_SITES:
+            elif isinstance(xP, _LazyAct) and xP.fold is not None and "heads" in self.next_bn_sites:
                 # the final patient activations are BatchNorm outputs: the statistics of that BatchNorm's backward are
                 # summed in the epilogue of the GEMM that produces its upstream gradient
                 gP, bsums = ops.linear_fwd(g.A, w1a, w_kn=True, next_bn=ops.NextBN(xP.y, xP.pro, xP.fold))

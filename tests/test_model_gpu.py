@@ -304,6 +304,36 @@ def test_batchnorm_backward_statistics_from_producer_epilogues(dev, sites, num_l
     _train_step_vs_oracle(dev, (1834, 50, 114, 100), 128, p=0.2, sup_seed=3, num_layers=num_layers)
 
 
+def test_two_models_of_one_process_run_with_their_own_execution_switches(dev):
+    """HeteroRGCN.configure_execution: side stream, next-BatchNorm sites and saved pair state are per MODEL (the module-level
+    switches are defaults) -- two models configured differently give the same predictions and gradients (to summation order:
+    the producer-epilogue statistics are taken in another order than the separate pass) and each run reads ITS settings."""
+    import mmgnn.model as mm
+    n, hidden = (1834, 50, 114, 100), 128
+    outs = []
+    for kw in (dict(overlap="on", next_bn=("heads", "conv", "enc2", "enc1"), save_pair_state=True),
+               dict(overlap="off", next_bn=(), save_pair_state=False)):
+        model, g, gd, gv, sd, ei, ea = make(dev, n, hidden, dropout=0.2)
+        model.configure_execution(**kw)
+        run = mm._Run(model, gd)
+        assert run.overlap == (kw["overlap"] == "on") and run.next_bn_sites == frozenset(kw["next_bn"])
+        assert run.save_pair_state == kw["save_pair_state"]
+        model.train()
+        model._seed_dev = None
+        torch.manual_seed(5)
+        pi, li = ei[0].to(dev), ei[1].to(dev)
+        pred = model.predict_lab_values(gd, pi, li)
+        (pred * torch.linspace(-1, 1, pred.numel(), device=dev)).sum().backward()
+        outs.append((pred.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    with pytest.raises(ValueError):
+        model.configure_execution(overlap="sometimes")
+    (p0, g0), (p1, g1) = outs
+    assert torch.equal(p0, p1)
+    gmax = max(float(v.abs().max()) for v in g1.values())      # (a bias in front of a BatchNorm has gradient 0 + rounding noise)
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * float(g1[k].abs().max()) + 2e-6 * gmax, k
+
+
 @pytest.mark.parametrize("activation", ["elu", "leaky_relu"])
 def test_activation_variants_match_oracle(dev, activation):
     """model.py:145-152 accepts relu / elu / leaky_relu for the conv layers."""
