@@ -642,8 +642,10 @@ def measure_chain(args, dev, scale, dim, steps):
         port = s.getsockname()[1]
         s.close()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
-                                             device_id=dev)
+        # an own store, not init_method="tcp://...": under torch.distributed.run with one rank (TORCHELASTIC_USE_AGENT_STORE
+        # in the environment) the tcp:// handler connects as a CLIENT of the agent's store and waits on this port forever
+        store = torch.distributed.TCPStore("127.0.0.1", port, 1, True)
+        torch.distributed.init_process_group("nccl", store=store, rank=0, world_size=1, device_id=dev)
     try:
         rec = measure(args, 1, 0, dev, scale, False, dim, steps, 3, False, force_comm=True)     # the default scheme
         rec["segments"] = measure(args, 1, 0, dev, scale, False, dim, steps, 3, False, force_comm=True,

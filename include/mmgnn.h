@@ -37,6 +37,14 @@ extern "C" {
 int mmg_version(void);
 const char* mmg_last_error(void);
 
+/* A HIP stream of the library's own (hipStreamNonBlocking, on the current device) -- outside every stream pool of the
+ * host framework, so nothing the host code captures into a hipGraph ever lands on it.  The sharded host side
+ * (mmgnn/dist.py) issues its EAGER RCCL all-reduces there: torch's process-group watchdog polls the end events of eager
+ * collectives with hipEventQuery, and HIP refuses that query -- and invalidates the capture -- while the stream the
+ * event was recorded on is capturing (profiles/probes/rccl_event_cache_abort.py). */
+int mmg_stream_create(void** stream_out);
+int mmg_stream_destroy(void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * CSR construction (consumes the tensors of
  * src/graph_build.py:476-586).  Stable sort of edge ids by edge_index[sort_row]:

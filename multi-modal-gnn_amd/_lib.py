@@ -97,6 +97,8 @@ _P = C.POINTER
 SIGNATURES = {
     "mmg_version": (C.c_int, []),
     "mmg_last_error": (C.c_char_p, []),
+    "mmg_stream_create": (C.c_int, [_P(_vp)]),
+    "mmg_stream_destroy": (C.c_int, [_vp]),
     "mmg_csr_build_ws_bytes": (_sz, [_i64, _i64]),
     "mmg_csr_build": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mmg_row_degree": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),

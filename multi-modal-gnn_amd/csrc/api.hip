@@ -20,6 +20,21 @@ void mmg_set_error(const char* fmt, ...) {
 extern "C" int mmg_version(void) { return 100; }   // 0.1.0
 extern "C" const char* mmg_last_error(void) { return g_err; }
 
+extern "C" int mmg_stream_create(void** stream_out) {
+  MMG_CHECK_ARG(stream_out, "stream_create: null output");
+  hipStream_t st = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  if (e != hipSuccess) { mmg_set_error("stream_create: %s", hipGetErrorString(e)); return MMG_E_LAUNCH; }
+  *stream_out = (void*)st;
+  return MMG_OK;
+}
+extern "C" int mmg_stream_destroy(void* stream) {
+  if (!stream) return MMG_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) { mmg_set_error("stream_destroy: %s", hipGetErrorString(e)); return MMG_E_LAUNCH; }
+  return MMG_OK;
+}
+
 // ---- measurement hook: (event pair, kernel family, shape) of the launches made while armed.  This is the ONE piece of
 // process-wide mutable state in the library (the backward of a step runs on the autograd engine's thread, so a
 // per-thread hook would miss half of the step); it is mutex-guarded, never armed by the product path, and costs the

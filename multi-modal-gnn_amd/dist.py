@@ -24,6 +24,35 @@ import torch.distributed as dist
 from .data import GraphPlan, HeteroGraph, ROW_TYPE
 
 
+_EAGER_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def eager_collective_stream(device_index: int):
+    """The stream every EAGER RCCL collective of this package is issued on: one per device and process, created by the
+    library (mmg_stream_create) and therefore outside torch's stream pools -- no hipGraph capture ever runs on it.
+
+    Why: ProcessGroupNCCL hands every eager collective to its watchdog thread, which polls the collective's end event with
+    hipEventQuery every 100 ms until it has completed.  HIP refuses that query ("operation not permitted on an event last
+    recorded in a capturing stream") while the stream the event was recorded on is capturing -- also when the event itself
+    was recorded BEFORE the capture began -- invalidates the capture, and the watchdog's exception ends the process
+    (profiles/probes/rccl_event_cache_abort.py: eager all-reduces on S, then a capture on S within the watchdog's poll
+    period aborts; the same with the capture on another stream survives).  A step warms up with eager collectives and is
+    recorded right after: on one stream that is exactly the sequence.  With the eager collectives on a stream that never
+    captures, no event the watchdog holds can meet a capturing stream.  Never destroyed: the watchdog may still hold events
+    of it at teardown."""
+    st = _EAGER_STREAMS.get(device_index)
+    if st is None:
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        out = ctypes.c_void_p()
+        with torch.cuda.device(device_index):
+            _lib.check(lib.mmg_stream_create(ctypes.byref(out)), "mmg_stream_create")
+        st = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", device_index))
+        _EAGER_STREAMS[device_index] = st
+    return st
+
+
 class ShardComm:
     """Collectives used by the sharded step.  ``n_calls``/``n_bytes`` are counted for the tests/bench."""
 
@@ -38,6 +67,7 @@ class ShardComm:
         self.n_bytes = 0
         self.on_collective = None         # set while a step is being captured piecewise (train.PiecewiseGraphedTrainStep)
         self._capturable = None           # capturable(): decided once, by a probe capture
+        self._nccl = str(dist.get_backend(group)) == "nccl"
 
     # ---- recording collectives into a hipGraph
     def backend(self) -> str:
@@ -109,6 +139,17 @@ class ShardComm:
                 dist.destroy_process_group(g)
 
     def raw_all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """SUM all-reduce in place.  RCCL on a HIP tensor: recorded on the current stream while that stream is capturing;
+        otherwise issued on the package's eager-collective stream, ordered after the current stream's work and before
+        what it does next (two event waits; see eager_collective_stream for why not on the current stream itself)."""
+        if t.is_cuda and self._nccl and not torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream(t.device)
+            es = eager_collective_stream(t.device.index)
+            es.wait_stream(cur)
+            with torch.cuda.stream(es):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            cur.wait_stream(es)
+            return t
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 

@@ -446,8 +446,28 @@ def test_rccl_backend_carries_the_sharded_step(capfd):
         assert step3.capture_collectives and step3.n_collectives == n_coll          # default: what the probe allows
         assert step3.n_pairs_global == pi.numel() and torch.equal(step3._draw_ids, torch.arange(pi.numel(), device=dev))
         seen = []
-        for _ in range(3):
-            assert torch.isfinite(step3.step())
+        for it in range(3):
+            l3 = step3.step()
+            if not bool(torch.isfinite(l3)):
+                bad = lambda named: [n for n, t in named if t is not None and t.is_floating_point()
+                                     and not bool(torch.isfinite(t).all())]
+                diag = dict(it=it, loss=float(l3), inv_den=float(step3._sv.inv_den), count=float(step3._sv.count),
+                            sup=float(step3.sup.sum()), pred_nonfinite=int((~torch.isfinite(step3.pred)).sum()),
+                            n_pred=step3.pred.numel(), params=bad(m3.named_parameters()),
+                            grads=bad((n, p.grad) for n, p in m3.named_parameters()), buffers=bad(m3.named_buffers()))
+                nf = ~torch.isfinite(step3.pred)
+                diag["nonfinite_outside_sup"] = int((nf & (step3.sup == 0)).sum())
+                diag["pred_sample"] = step3.pred[nf][:6].tolist()
+                with torch.no_grad():
+                    m3.train()
+                    pe = m3.predict_lab_values(plan3, pi, li)
+                diag["eager_pred_nonfinite"] = int((~torch.isfinite(pe)).sum())
+                l3b = step3.step()
+                diag["next_replay"] = (float(l3b), int((~torch.isfinite(step3.pred)).sum()))
+                os.makedirs("gpurun_out", exist_ok=True)
+                with open("gpurun_out/diag_rccl_step3.txt", "w") as f:
+                    f.write(repr(diag) + "\n")
+                raise AssertionError(f"non-finite loss of the sharded step that draws its mask: {diag}")
             k = float(step3.sup.sum())
             assert float(step3._sv.count) == k and abs(float(step3._sv.inv_den) - 1.0 / k) <= 1e-15
             assert 0.1 < k / pi.numel() < 0.3
