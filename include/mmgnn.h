@@ -574,7 +574,8 @@ int mmg_small_bn_bwd_group(const mmg_small_bn_bwd_t* probs, int n_probs, int N, 
  * mmg_counters_add: *counters[i] += incs[i] for <= MMG_SUM_MAX_JOBS * 4 int64 counters (BatchNorm1d.num_batches_tracked
  * of every layer in one launch).  mmg_seed_advance: state[1] += 1 step of a SplitMix64 stream, state[0] = its output
  * (< 2^62) -- the dropout seed the kernels read through mmg_prologue_t.seed_ptr, advanced inside a captured step.
- * mmg_fill_zero: hipMemsetAsync under the library's error handling.
+ * mmg_fill_zero: zero-fill by a kernel on `stream` (bytes of any count / alignment).  Not hipMemsetAsync: recorded into a
+ * hipGraph its node replays a pattern other than the recorded zero on this ROCm (profiles/probes/hipgraph_memset_node.py).
  * ------------------------------------------------------------------------------------- */
 #define MMG_ADAM_MAX_TENSORS 96
 #define MMG_SUM_MAX_JOBS 8

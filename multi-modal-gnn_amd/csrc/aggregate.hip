@@ -1766,7 +1766,7 @@ extern "C" int mmg_scatter_rows(const mmg_rel_t* rels, int n_rel, int64_t n_rows
     if (rc) return rc;
     for (int r = 0; r < n_rel; ++r)
       if (rels[r].n_cols > 0)
-        MMG_CHECK_HIP(hipMemsetAsync(rels[r].out, 0, (size_t)rels[r].n_cols * D * 4, st), "scatter_rows(memset)");
+        MMG_CHECK_HIP(mmg_zero_async(rels[r].out, (size_t)rels[r].n_cols * D * 4, st), "scatter_rows(memset)");
     if (n_rows == 0) return MMG_OK;
     MMG_CHECK_ARG(x, "scatter_rows: x is null");
     const unsigned nb = (unsigned)((n_rows + 3) / 4);
@@ -1856,12 +1856,12 @@ extern "C" int mmg_rel_mask_build(const int32_t* rowptr, const int32_t* col, int
   hipStream_t st = (hipStream_t)stream;
   const int padc = (n_cols + 31) & ~31;
   if (mask_t) {
-    MMG_CHECK_HIP(hipMemsetAsync(mask_t, 0, words * sizeof(uint64_t), st), "rel_mask_build(memset)");
+    MMG_CHECK_HIP(mmg_zero_async(mask_t, words * sizeof(uint64_t), st), "rel_mask_build(memset)");
     hipLaunchKernelGGL(k_mask_build, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rowptr, col, n_rows, padc,
                        reinterpret_cast<unsigned long long*>(mask_t));
   }
   if (mask_r) {
-    MMG_CHECK_HIP(hipMemsetAsync(mask_r, 0, words * sizeof(uint64_t), st), "rel_mask_build(memset)");
+    MMG_CHECK_HIP(mmg_zero_async(mask_r, words * sizeof(uint64_t), st), "rel_mask_build(memset)");
     hipLaunchKernelGGL(k_mask_build_rows, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, rowptr, col, n_rows,
                        padc / 16, reinterpret_cast<unsigned*>(mask_r));
   }

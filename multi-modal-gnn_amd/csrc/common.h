@@ -74,6 +74,31 @@ bool mmg_probe_take(int tag, int64_t M, int N, int K, int flags, const char* ker
 
 static inline int mmg_valid_D(int D) { return D == 64 || D == 128 || D == 256; }
 
+// Zero-fill on a stream, as a KERNEL -- never hipMemsetAsync.  Recorded into a hipGraph by stream capture, the memset node
+// of this ROCm (the HIP runtime PyTorch 2.10 + rocm7.0 ships) replays, in about every second graph of a process, with a
+// fill pattern that is not the recorded zero: 16-byte groups {n_dwords, 1, 0, 0} -- or whatever else lies where the pattern
+// is fetched from -- land in the buffer (profiles/probes/hipgraph_memset_node.py).  As denormal floats they are invisible in
+// a sum; as a large value in a buffer the step assumes zeroed (predictions outside the supervised pair lists, gradient
+// accumulators) they surfaced as a non-finite loss once per few hundred captured steps.
+static __global__ __launch_bounds__(256) void mmg_k_zero(unsigned char* __restrict__ p, size_t bytes) {
+  const size_t mis = (size_t)((16u - (unsigned)((uintptr_t)p & 15u)) & 15u);
+  const size_t head = mis < bytes ? mis : bytes;
+  const size_t n16 = (bytes - head) >> 4, tail0 = head + (n16 << 4);
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+  uint4* q = reinterpret_cast<uint4*>(p + head);
+  for (size_t i = tid; i < n16; i += nth) q[i] = uint4{0u, 0u, 0u, 0u};
+  if (tid < head) p[tid] = 0;
+  if (tid < bytes - tail0) p[tail0 + tid] = 0;          // (fewer than 16 bytes)
+}
+static inline hipError_t mmg_zero_async(void* ptr, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  size_t g = ((bytes >> 4) + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(mmg_k_zero, dim3((unsigned)g), dim3(256), 0, st, (unsigned char*)ptr, bytes);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------
 // Counter-based dropout RNG: keep(seed, site, element) -- stateless, so the backward pass
 // regenerates the forward mask instead of storing it.  Two rounds of a murmur3-style

@@ -245,7 +245,7 @@ extern "C" int mmg_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t
   }
   hipStream_t st = (hipStream_t)stream;
   uint32_t* cnt = (uint32_t*)rowptr;   // histogram is built in place, then scanned into rowptr
-  MMG_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)(n_rows + 1) * 4, st), "csr_build(memset)");
+  MMG_CHECK_HIP(mmg_zero_async(cnt, (size_t)(n_rows + 1) * 4, st), "csr_build(memset)");
   if (n_edges == 0) {
     MMG_CHECK_LAUNCH("csr_build(memset)");
     return MMG_OK;
@@ -302,7 +302,7 @@ extern "C" int mmg_col_degree(const int32_t* col, int64_t n_edges, int64_t n_col
                               void* stream) {
   MMG_CHECK_ARG(n_edges >= 0 && n_cols >= 0 && n_cols < 2147483647LL && cnt, "col_degree: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (n_cols > 0) MMG_CHECK_HIP(hipMemsetAsync(cnt, 0, (size_t)n_cols * 4, st), "col_degree(memset)");
+  if (n_cols > 0) MMG_CHECK_HIP(mmg_zero_async(cnt, (size_t)n_cols * 4, st), "col_degree(memset)");
   if (n_edges > 0 && n_cols > 0) {
     int64_t nb = (n_edges + NTHR * 8 - 1) / (NTHR * 8);      // >= 8 edges per thread: the flush is amortised
     if (nb > 1024) nb = 1024;

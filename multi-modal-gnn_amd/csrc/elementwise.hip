@@ -562,7 +562,7 @@ extern "C" int mmg_col_reduce2(const float* A, const float* B, double* out, int6
                                void* stream) {
   MMG_CHECK_ARG(M >= 0 && out, "col_reduce2: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (M == 0) { MMG_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)2 * N * 8, st), "col_reduce2(memset)"); return MMG_OK; }
+  if (M == 0) { MMG_CHECK_HIP(mmg_zero_async(out, (size_t)2 * N * 8, st), "col_reduce2(memset)"); return MMG_OK; }
   MMG_CHECK_ARG(A && ws, "col_reduce2: null buffer");
   int rc = run_col_reduce<0>(A, B, mmg_pro_dev(nullptr), nullptr, nullptr, out, M, N, ws, ws_bytes, st, "col_reduce2");
   if (rc) return rc;
@@ -610,7 +610,7 @@ extern "C" int mmg_bn_bwd_stats(const float* G, const float* Y, const mmg_prolog
                                 void* stream) {
   MMG_CHECK_ARG(M >= 0 && sums && mean && rstd, "bn_bwd_stats: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (M == 0) { MMG_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st), "bn_bwd_stats(memset)"); return MMG_OK; }
+  if (M == 0) { MMG_CHECK_HIP(mmg_zero_async(sums, (size_t)2 * N * 8, st), "bn_bwd_stats(memset)"); return MMG_OK; }
   MMG_CHECK_ARG(G && Y && ws, "bn_bwd_stats: null buffer");
   int rc = run_col_reduce<1>(G, Y, mmg_pro_dev(pro), mean, rstd, sums, M, N, ws, ws_bytes, st, "bn_bwd_stats");
   if (rc) return rc;
@@ -623,7 +623,7 @@ extern "C" int mmg_bn_bwd_stats2(const float* G, const float* G2, const float* Y
                                  int N, void* ws, size_t ws_bytes, void* stream) {
   MMG_CHECK_ARG(M >= 0 && sums && mean && rstd, "bn_bwd_stats2: bad args");
   hipStream_t st = (hipStream_t)stream;
-  if (M == 0) { MMG_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st), "bn_bwd_stats(memset)"); return MMG_OK; }
+  if (M == 0) { MMG_CHECK_HIP(mmg_zero_async(sums, (size_t)2 * N * 8, st), "bn_bwd_stats(memset)"); return MMG_OK; }
   MMG_CHECK_ARG(G && G2 && Y && ws && pro && pro2, "bn_bwd_stats2: null buffer");
   const ProDev p2 = mmg_pro_dev(pro2);
   int rc = run_col_reduce<1>(G, Y, mmg_pro_dev(pro), mean, rstd, sums, M, N, ws, ws_bytes, st, "bn_bwd_stats2", G2, &p2);
@@ -640,7 +640,7 @@ extern "C" int mmg_bn_bwd_stats_rows(const float* G_rows, const float* Y, const 
   MMG_CHECK_ARG(n_sel >= 0 && sums && mean && rstd, "bn_bwd_stats_rows: bad args");
   MMG_CHECK_ARG(N > 0 && N % 4 == 0 && N <= 256 && 256 % (N / 4) == 0, "bn_bwd_stats_rows: N=%d unsupported", N);
   hipStream_t st = (hipStream_t)stream;
-  if (n_sel == 0) { MMG_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)2 * N * 8, st), "bn_bwd_stats_rows(memset)"); return MMG_OK; }
+  if (n_sel == 0) { MMG_CHECK_HIP(mmg_zero_async(sums, (size_t)2 * N * 8, st), "bn_bwd_stats_rows(memset)"); return MMG_OK; }
   MMG_CHECK_ARG(G_rows && Y && rows && ws, "bn_bwd_stats_rows: null buffer");
   MMG_CHECK_ARG(ws_bytes >= mmg_bn_bwd_stats_rows_ws_bytes(N), "bn_bwd_stats_rows: workspace too small");
   double* partial = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);

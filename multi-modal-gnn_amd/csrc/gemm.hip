@@ -1853,8 +1853,8 @@ static int linear_wgrad_impl(const float* dY, const float* X, const mmg_prologue
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
     if (!accumulate) {
-      MMG_CHECK_HIP(hipMemsetAsync(dW, 0, (size_t)N * K * 4, st), "linear_wgrad(memset)");
-      if (dbias) MMG_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)N * 4, st), "linear_wgrad(memset)");
+      MMG_CHECK_HIP(mmg_zero_async(dW, (size_t)N * K * 4, st), "linear_wgrad(memset)");
+      if (dbias) MMG_CHECK_HIP(mmg_zero_async(dbias, (size_t)N * 4, st), "linear_wgrad(memset)");
     }
     return MMG_OK;
   }

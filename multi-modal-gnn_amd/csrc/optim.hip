@@ -197,6 +197,6 @@ extern "C" int mmg_seed_advance(uint64_t* state, void* stream) {
 extern "C" int mmg_fill_zero(void* ptr, size_t bytes, void* stream) {
   if (bytes == 0) return MMG_OK;
   MMG_CHECK_ARG(ptr, "fill_zero: null buffer");
-  MMG_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream), "fill_zero");
+  MMG_CHECK_HIP(mmg_zero_async(ptr, bytes, (hipStream_t)stream), "fill_zero");
   return MMG_OK;
 }

@@ -1735,7 +1735,7 @@ extern "C" int mmg_pair_select(const int32_t* pi, const int32_t* deg, int degree
   MMG_CHECK_ARG(counts, "pair_select: counts is null");
   hipStream_t st = (hipStream_t)stream;
   if (n_pairs == 0) {
-    MMG_CHECK_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st), "pair_select(memset)");
+    MMG_CHECK_HIP(mmg_zero_async(counts, 2 * sizeof(int32_t), st), "pair_select(memset)");
     return MMG_OK;
   }
   MMG_CHECK_ARG(pi && deg && sel_low && sel_high, "pair_select: null buffer");

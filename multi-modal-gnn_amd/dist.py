@@ -118,8 +118,7 @@ class ShardComm:
           2. collect garbage, synchronise the device: no replay or collective of this process is in flight;
           3. barrier + synchronise: no OTHER rank is still inside a collective that needs this one;
           4. destroy the process group (destroy=False: the caller keeps the group for its next measurement).
-        An abort inside destroy_process_group was seen once (world_size 1, message lost: DESIGN.md section 6, cause not
-        established); every teardown of the repo goes through here so that a recurrence has one place to be read from."""
+        (The aborts round 3 saw around here were the watchdog meeting a capturing stream: eager_collective_stream.)"""
         for h in holders:
             rel = getattr(h, "release", None)
             if rel is not None:

@@ -1033,7 +1033,8 @@ def seed_advance(state: torch.Tensor):
 
 
 def zeros(*shape, device, dtype=torch.float32):
-    """torch.zeros through mmg_fill_zero (hipMemsetAsync on the current stream)."""
+    """torch.zeros through mmg_fill_zero: a zero-fill KERNEL on the current stream (not hipMemsetAsync -- its hipGraph node
+    does not reliably replay the recorded pattern on this ROCm: csrc/common.h, profiles/probes/hipgraph_memset_node.py)."""
     t = torch.empty(*shape, device=device, dtype=dtype)
     check(_lib.load().mmg_fill_zero(_p(t, dtype), t.numel() * t.element_size(), _stream()), "mmg_fill_zero")
     return t

@@ -30,10 +30,11 @@ import torch.optim as optim
 from .model import build_model, compute_regression_loss
 
 LAB_EDGE = ("patient", "has_lab", "lab")
-# Stream capture checks "unsafe" HIP calls of the capturing THREAD only.  With the default ("global") any thread counts:
+# Stream capture checks "unsafe" HIP calls of the capturing THREAD only.  With the default ("global") any thread counts, and
 # the watchdog thread of a torch.distributed NCCL / RCCL process group polls its work events (hipEventQuery) on its own
-# schedule, and one poll that lands inside a capture window invalidates the capture and aborts the process -- an
-# intermittent SIGABRT while a step is being recorded (seen once, bench.py with a world_size-1 RCCL group alive).
+# schedule.  (The abort this was introduced for turned out to be something else -- the watchdog querying an event whose
+# stream is capturing, which no error mode allows: mmgnn.dist.eager_collective_stream -- but a poll of an unrelated event
+# from that thread is still a call "global" mode counts.)
 CAPTURE_ERROR_MODE = "thread_local"
 
 
@@ -41,8 +42,7 @@ def capture_error_mode() -> str:
     """Mode of the next stream capture.  `thread_local` only while a torch.distributed process group is alive -- its
     watchdog thread is the one known source of HIP calls from another thread during a capture window; without a group
     the default ("global") stays, so that a capture-invalidating call from ANY thread is still reported instead of
-    silently corrupting the recording.  (The SIGABRT that led here left no log -- DESIGN.md section 6 -- so the mode is
-    confined to the situation it was seen in rather than applied everywhere.)"""
+    silently corrupting the recording."""
     try:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized():

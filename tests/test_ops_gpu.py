@@ -1352,3 +1352,32 @@ def test_next_bn_statistics_from_the_gather_epilogue(ops, dev, D, n_rows, p):
             _, sums = ops.gather_rows(rels, n_rows, D, o, accumulate=acc, next_bn=ops.NextBN(y, pro, fold))
             assert torch.equal(o, ref)
             _stats_close(ops, sums, o, y, pro, fold)
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 65, 5829, 100003])
+def test_zero_fill_recorded_into_a_hipgraph_zeroes_at_every_replay(ops, dev, n):
+    """ops.zeros inside a captured step: the buffer is zero at EVERY replay, whatever it held before.  (hipMemsetAsync recorded
+    into a hipGraph replays a stale fill pattern on this ROCm from the second replay on -- profiles/probes/hipgraph_memset_node.py;
+    the library fills with a kernel.)  Also unaligned views: a zero-fill of bytes 4 .. 4 + 4 n of a buffer touches nothing else."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = torch.empty(n, device=dev)
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin()
+        z = ops.zeros(n, device=dev)
+        out.copy_(z)
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    for rep in range(5):
+        z.fill_(float("inf") if rep % 2 else 7.0)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert int((out != 0).sum()) == 0, (rep, out[out != 0][:4].tolist())
+    del g
+    from mmgnn import _lib
+    buf = torch.full((n + 8,), 5.0, device=dev)
+    _lib.check(_lib.load().mmg_fill_zero(ops._p(buf[1:1 + n], torch.float32), n * 4, ops._stream()), "mmg_fill_zero")
+    torch.cuda.synchronize()
+    assert float(buf[0]) == 5.0 and bool((buf[1 + n:] == 5.0).all()) and int((buf[1:1 + n] != 0).sum()) == 0
