@@ -140,8 +140,6 @@ def parse():
                          "'none' = all of them as separate passes); default: the library's own")
     ap.add_argument("--overlap", choices=["auto", "off", "on"], default="auto",
                     help="vocab-side work of a layer on a side stream (mmgnn.model.set_overlap)")
-    ap.add_argument("--side-wgrad", choices=["on", "off"], default="on",
-                    help="the encoder's weight-gradient GEMMs on the side stream (mmgnn.model.SIDE_WGRAD)")
     return ap.parse_args()
 
 
@@ -665,7 +663,6 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     mmodel.set_overlap(args.overlap)
-    mmodel.SIDE_WGRAD = args.side_wgrad == "on"
     if args.next_bn is not None:
         mmodel.set_next_bn([] if args.next_bn == "none" else [t for t in args.next_bn.split(",") if t])
     world, rank, dev = setup_dist(args)

@@ -56,10 +56,6 @@ NEXT_BN_SITES = frozenset({"heads", "conv", "enc2"})
 # bits.  Used where the forward visits the supervision subset alone (a forward over ALL 4.3 M pairs would pay 68 us for the
 # 30 us the backward gains).
 SAVE_PAIR_STATE = True
-# The weight-gradient GEMMs of the encoder's backward (dW = dZ^T . X: nothing but the optimizer reads them) run on the side
-# stream underneath the data-gradient chain they hang off (BatchNorm-backward GEMM -> BatchNorm-backward GEMM -> ...), where
-# the model overlaps at all (OVERLAP_MODE) and is not sharded.
-SIDE_WGRAD = True
 
 
 def set_next_bn(sites):
@@ -233,13 +229,12 @@ class HeteroRGCN(nn.Module):
         run = _Run(self, data)
         return run.apply("predict", patient_indices, lab_indices)
 
-    def configure_execution(self, overlap: Optional[str] = None, next_bn=None, save_pair_state: Optional[bool] = None,
-                            side_wgrad: Optional[bool] = None):
+    def configure_execution(self, overlap: Optional[str] = None, next_bn=None, save_pair_state: Optional[bool] = None):
         """Per-model execution switches (None = keep / fall back to the module-level default): `overlap` 'auto' | 'off' |
         'on' (vocab-side work of a layer on a side stream), `next_bn` = the BatchNorm-backward statistics taken from
         producer epilogues (subset of {'heads', 'conv', 'enc2', 'enc1'}), `save_pair_state` = the heads' forward leaves its
-        layer states for the backward, `side_wgrad` = the encoder's weight-gradient GEMMs on the side stream (where the run
-        overlaps).  Results do not depend on any of them; a step captured earlier keeps what it was recorded with."""
+        layer states for the backward.  Results do not depend on any of them; a step captured earlier keeps what it was
+        recorded with."""
         ex = dict(getattr(self, "_exec", None) or {})
         if overlap is not None:
             if overlap not in ("auto", "off", "on"):
@@ -252,8 +247,6 @@ class HeteroRGCN(nn.Module):
             ex["next_bn"] = sites
         if save_pair_state is not None:
             ex["save_pair_state"] = bool(save_pair_state)
-        if side_wgrad is not None:
-            ex["side_wgrad"] = bool(side_wgrad)
         self._exec = ex
         return self
 
@@ -375,9 +368,6 @@ class _Run:
         self._nbt = {}               # BatchNorm step counters to advance: {id(module): [buffer, increment]}
         self.pending = {}            # parameter name -> further gradient contributions, summed at the end of the backward
         self.wgrad_jobs = []         # deferred slab sums of the big weight gradients: one launch at the end of the backward
-        self.wgrad_jobs_side = []    # ... of the weight gradients issued on the side stream (their own list: a flush forced by
-        #                              an accumulating launch must only meet slabs of its own stream)
-        self._side_keep = []         # operands of side-stream launches, alive until the streams are joined
         # (sel_low, sel_high, counts) of the pairs the backward must visit, when the caller knows them in advance (a
         # captured step with a per-epoch supervision mask: train.PiecewiseGraphedTrainStep); None: selected from dpred != 0
         self.static_select = None
@@ -403,8 +393,6 @@ class _Run:
             if getattr(model, "_side_stream", None) is None:
                 model._side_stream = torch.cuda.Stream(device=self.dev)
             self.side = model._side_stream
-        sw = ex["side_wgrad"] if ex.get("side_wgrad") is not None else SIDE_WGRAD
-        self.side_wgrad = bool(sw) and self.overlap and self.comm is None
         for t in self.plan.node_types:
             if t not in model.embeddings:
                 raise KeyError(f"no embedding table for node type '{t}': call model._init_embeddings(data) first")
@@ -431,10 +419,6 @@ class _Run:
         grads[name] may be shared (dWsum serves three lin_r names) or belong to the caller (an autograd grad_output in
         encode / forward mode).  More than three further contributions chain: each level reads the previous level's
         result, so levels are separate launches (jobs of one launch run concurrently)."""
-        if self._side_keep:                       # weight gradients still running on the side stream: join first
-            torch.cuda.current_stream().wait_stream(self.side)
-            self._side_keep.clear()
-        ops.wgrad_reduce_flush(self.wgrad_jobs_side)
         ops.wgrad_reduce_flush(self.wgrad_jobs)
         levels: List[list] = []
         for name, more in self.pending.items():
@@ -747,33 +731,19 @@ class _Run:
         return done(out)
 
     def lin_bwd(self, dy, x, pro, wname, bname, need_dx=True, partial=False, dx_into=None):
-        """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one.
-        The weight / bias gradient is nobody's input before the optimizer: where the run overlaps (side_wgrad) its GEMM goes
-        to the side stream behind an event on dy's producer, and the data-gradient chain carries on underneath it."""
-        def wgrad(jobs):
-            gw = self.grads.get(wname)       # a second contribution (the encoder runs twice) accumulates inside the kernel
-            if bname is not None:            # the bias gradient (column sums of dy) comes out of the same pass over dy
-                gb = self.grads.get(bname)
-                if gw is not None and gb is not None:
-                    ops.linear_wgrad(dy, x, pro, out=gw, accumulate=True, with_bias=True, bias_out=gb, defer=jobs)
-                    dW, db = gw, gb
-                else:
-                    dW, db = ops.linear_wgrad(dy, x, pro, with_bias=True, defer=jobs)
-                self.acc(wname, dW, partial)
-                self.acc(bname, db, partial)
+        """grads of  y = pro(x) W^T + b.  dx_into: accumulate dX into this tensor (inside the GEMM) instead of a new one."""
+        gw = self.grads.get(wname)       # a second contribution (the encoder runs twice) accumulates inside the kernel
+        if bname is not None:            # the bias gradient (column sums of dy) comes out of the same pass over dy
+            gb = self.grads.get(bname)
+            if gw is not None and gb is not None:
+                ops.linear_wgrad(dy, x, pro, out=gw, accumulate=True, with_bias=True, bias_out=gb, defer=self.wgrad_jobs)
+                dW, db = gw, gb
             else:
-                self.acc(wname, ops.linear_wgrad(dy, x, pro, out=gw, accumulate=gw is not None, defer=jobs), partial)
-
-        if self.side_wgrad:
-            main = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(ev)
-                wgrad(self.wgrad_jobs_side)
-            self._side_keep.append((dy, x, pro))     # (main-stream tensors: not handed back to the allocator under the launch)
+                dW, db = ops.linear_wgrad(dy, x, pro, with_bias=True, defer=self.wgrad_jobs)
+            self.acc(wname, dW, partial)
+            self.acc(bname, db, partial)
         else:
-            wgrad(self.wgrad_jobs)
+            self.acc(wname, ops.linear_wgrad(dy, x, pro, out=gw, accumulate=gw is not None, defer=self.wgrad_jobs), partial)
         if need_dx:
             if dx_into is not None:
                 return ops.linear_fwd(dy, self.W(wname), w_kn=True, out=dx_into, accumulate=True)

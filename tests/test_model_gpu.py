@@ -334,39 +334,6 @@ def test_two_models_of_one_process_run_with_their_own_execution_switches(dev):
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * float(g1[k].abs().max()) + 2e-6 * gmax, k
 
 
-def test_encoder_weight_gradients_on_the_side_stream_are_the_same_bits(dev):
-    """configure_execution(side_wgrad=...): the encoder's weight-gradient GEMMs issued on the side stream (behind an event on
-    their upstream gradient, joined before the deferred slab sums) against the single-stream order -- the same kernels on
-    the same operands: every prediction and every gradient bit for bit, over repeated backward passes (a missing
-    dependency would show as a changing bit pattern)."""
-    import mmgnn.model as mm
-    n, hidden = (1834, 50, 114, 100), 128
-    outs = []
-    for side in (True, False, True):
-        model, g, gd, gv, sd, ei, ea = make(dev, n, hidden, dropout=0.2)
-        model.configure_execution(overlap="on", side_wgrad=side)
-        run = mm._Run(model, gd)
-        assert run.side_wgrad == side
-        model.train()
-        pi, li = ei[0].to(dev), ei[1].to(dev)
-        grads = []
-        for rep in range(3):
-            model._seed_dev = None
-            model._dropout_seed = 99
-            model.zero_grad(set_to_none=True)
-            pred = model.predict_lab_values(gd, pi, li)
-            (pred * torch.linspace(-1, 1, pred.numel(), device=dev)).sum().backward()
-            grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
-        for k in grads[0]:
-            assert torch.equal(grads[0][k], grads[1][k]) and torch.equal(grads[0][k], grads[2][k]), (side, k)
-        outs.append((pred.detach().clone(), grads[0]))
-    for (p, gr) in outs[1:]:
-        assert torch.equal(outs[0][0], p)
-        for k in gr:
-            assert torch.equal(outs[0][1][k], gr[k]), k
-    assert any(k.startswith("patient_transform.0") for k in outs[0][1])
-
-
 @pytest.mark.parametrize("activation", ["elu", "leaky_relu"])
 def test_activation_variants_match_oracle(dev, activation):
     """model.py:145-152 accepts relu / elu / leaky_relu for the conv layers."""
