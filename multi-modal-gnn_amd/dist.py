@@ -84,13 +84,18 @@ class ShardComm:
         return self._capturable
 
     def _probe_capture(self) -> bool:
+        """Every rank runs the same probe and the verdicts are combined (MIN over the group): either ALL ranks record their
+        collectives or none does -- a rank that replays a graph with an all-reduce inside while another issues the chain's
+        eager one would wait for it forever."""
         env = os.environ.get("MMG_CAPTURE_COLLECTIVES")
         if env is not None and env.strip() in ("0", "1"):
             return env.strip() == "1"
         if self.backend() != "nccl" or not torch.cuda.is_available():
             return False
+        ok = 1.0
+        dev = torch.device("cuda", torch.cuda.current_device())
         try:
-            t = torch.zeros(64, device=torch.device("cuda", torch.cuda.current_device()))
+            t = torch.zeros(64, device=dev)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -103,12 +108,20 @@ class ShardComm:
                 torch.cuda.synchronize()
             torch.cuda.current_stream().wait_stream(side)
             del g
-            return True
         except Exception as e:                         # a backend that cannot record: the segment chain stays
             import sys
             print(f"[mmgnn.dist] collectives are not capturable here ({type(e).__name__}: {e}); using the segment chain",
                   file=sys.stderr)
-            return False
+            ok = 0.0
+        if self.world > 1:
+            verdict = torch.tensor([ok], device=dev)
+            work_stream = eager_collective_stream(dev.index)
+            work_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(work_stream):
+                dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=self.group)
+            torch.cuda.current_stream().wait_stream(work_stream)
+            ok = float(verdict.item())
+        return ok == 1.0
 
     # ---- teardown
     def close(self, *holders, destroy: bool = True):
