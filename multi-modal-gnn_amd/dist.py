@@ -152,10 +152,14 @@ class ShardComm:
 
     def raw_all_reduce(self, t: torch.Tensor) -> torch.Tensor:
         """SUM all-reduce in place.  RCCL on a HIP tensor: recorded on the current stream while that stream is capturing;
-        otherwise issued on the package's eager-collective stream, ordered after the current stream's work and before
-        what it does next (two event waits; see eager_collective_stream for why not on the current stream itself)."""
-        if t.is_cuda and self._nccl and not torch.cuda.is_current_stream_capturing():
-            cur = torch.cuda.current_stream(t.device)
+        issued on the package's eager-collective stream -- ordered after the current stream's work and before what it does
+        next, two event waits -- when the current stream is a side stream (see eager_collective_stream for why not there)."""
+        cur = torch.cuda.current_stream(t.device) if t.is_cuda else None
+        # (the default stream can never capture: a collective issued there -- the replays of a segment chain, a training
+        #  loop's own reductions -- stays where it is; only a side stream, which a step's construction records on right
+        #  after its warm-up, sends its eager collectives over)
+        if t.is_cuda and self._nccl and not torch.cuda.is_current_stream_capturing() and \
+                cur.cuda_stream != torch.cuda.default_stream(t.device).cuda_stream:
             es = eager_collective_stream(t.device.index)
             es.wait_stream(cur)
             with torch.cuda.stream(es):
