@@ -178,18 +178,28 @@ class ShardComm:
         self.n_bytes += t.numel() * t.element_size()
         return t
 
-    def all_reduce_list(self, ts: Sequence[torch.Tensor]):
-        """One bucket for many small tensors (the end-of-backward gradient exchange)."""
-        ts = [t for t in ts if t is not None]
+    def all_reduce_bucket(self, ts: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """One bucket for many small tensors (the end-of-backward gradient exchange): they are packed into ONE flat fp32
+        tensor (a single concatenation launch), all-reduced, and handed back as VIEWS of that bucket, in order -- no copy
+        back (63 separate device copies per step for this model: inside a captured step each is a graph node of its own,
+        ~0.2 ms together, most of what a sharded step cost over the unsharded one on one rank)."""
+        ts = list(ts)
         if not ts:
-            return
+            return []
         flat = torch.cat([t.reshape(-1).float() for t in ts])
         self.all_reduce(flat)
-        off = 0
+        out, off = [], 0
         for t in ts:
             n = t.numel()
-            t.copy_(flat[off:off + n].view_as(t))
+            out.append(flat[off:off + n].view(t.shape))
             off += n
+        return out
+
+    def all_reduce_list(self, ts: Sequence[torch.Tensor]):
+        """all_reduce_bucket with the sums copied back into the caller's tensors (in place; None entries skipped)."""
+        ts = [t for t in ts if t is not None]
+        for t, v in zip(ts, self.all_reduce_bucket(ts)):
+            t.copy_(v)
 
 
 def partition_rows(row_weights: torch.Tensor, world: int) -> List[int]:

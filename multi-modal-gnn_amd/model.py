@@ -571,7 +571,13 @@ class _Run:
                 self.acc("embeddings.lab.weight", g_init["lab"])
         self.flush_grad_sums()
         if self.comm is not None and self.partial:
-            self.comm.all_reduce_list([self.grads[n] for n in sorted(self.partial)])
+            names = sorted(self.partial)
+            bucket = getattr(self.comm, "all_reduce_bucket", None)
+            if bucket is not None:           # the summed gradients are views of the one bucket: nothing is copied back
+                for n, g in zip(names, bucket([self.grads[n] for n in names])):
+                    self.grads[n] = g
+            else:
+                self.comm.all_reduce_list([self.grads[n] for n in names])
         out = []
         for n in self.names:
             g = self.grads.pop(n, None)       # drop our reference: autograd can then adopt the tensor as .grad (no clone)
