@@ -79,8 +79,14 @@ def _worker(rank, world, port, q):
         names = [k for k, v in leaf.items() if torch.is_tensor(v) and v.requires_grad and k != "embeddings.patient.weight"]
         grads = [leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(leaf[k]) for k in names]
         calls0 = comm.n_calls
-        comm.all_reduce_list(grads)               # the product's end-of-backward bucket
+        views = comm.all_reduce_bucket([g_.clone() for g_ in grads])      # the product's end-of-backward bucket: views of ONE tensor
         assert comm.n_calls == calls0 + 1
+        assert [v.shape for v in views] == [g_.shape for g_ in grads]
+        assert len({v.untyped_storage().data_ptr() for v in views}) == 1 and all(v.is_contiguous() for v in views)
+        comm.all_reduce_list(grads)               # ... and the in-place form (the same sums copied back)
+        assert comm.n_calls == calls0 + 2
+        for v, g_ in zip(views, grads):
+            assert torch.equal(v, g_)
         loss = loss_part.detach().clone()
         dist.all_reduce(loss)
 
