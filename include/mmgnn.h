@@ -564,8 +564,9 @@ int mmg_small_bn_bwd_group(const mmg_small_bn_bwd_t* probs, int n_probs, int N, 
  * at offsets[0 .. n_tensors] (ascending, offsets[n_tensors] = end); grads[i] (HOST array of device pointers; NULL = the
  * tensor received no gradient and is left untouched, as torch skips a .grad of None) is read where the backward kernels
  * wrote it.  Arithmetic of torch.optim.Adam (amsgrad / maximize off, L2 weight decay added to the gradient).  `step`
- * (device float, the number of steps taken so far) is advanced by the kernel -- hipGraph replays keep counting --
- * through `ticket` (device uint32, zero-initialised by the caller once).
+ * (device float, the number of steps taken so far) is advanced by a one-thread launch behind the update -- hipGraph
+ * replays keep counting.  `ticket` (device uint32) is no longer used (the last-workgroup scheme it served cost a
+ * device-scope fence per workgroup) and stays in the signature for the ABI.
  * mmg_vec_sums: dst_j = src_j0 (+ src_j1 + src_j2 + src_j3), fixed order, <= MMG_SUM_MAX_JOBS jobs per launch (the
  * three lin_r weights / lin_l biases that share x_patient in a HeteroConv layer, src/model.py:125-131; the gradient
  * contributions of a parameter that is used twice).  A job is a [len / cols, cols] matrix with its own row stride on

@@ -7,7 +7,8 @@
 // per launch; longer lists take several launches that share the step counter).  Arithmetic = torch.optim.Adam
 // (amsgrad = False, maximize = False): g += wd * p;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The step counter t is a device-resident float (hipGraph
-// replays advance it): every workgroup reads it on entry, the LAST workgroup to finish writes t + 1.
+// replays advance it): every workgroup reads it on entry, a one-thread launch behind the update writes t + 1 (`ticket` is
+// unused since round 4 and stays in the signature for the ABI).
 #include "common.h"
 
 namespace {
@@ -20,39 +21,46 @@ struct AdamTable {
 
 __global__ __launch_bounds__(256) void k_adam(AdamTable tb, float* __restrict__ p, float* __restrict__ m,
                                               float* __restrict__ v, float lr, float b1, float b2, float eps, float wd,
-                                              const float* __restrict__ hyper, float* __restrict__ step,
-                                              unsigned* __restrict__ ticket, int bump) {
+                                              const float* __restrict__ hyper, const float* __restrict__ step) {
   // device-resident hyper-parameters (a captured step keeps its launch arguments; a scheduler changes lr between replays)
   if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; }
   // the bias corrections are two powf per step: one wave computes them, LDS hands them to the workgroup
   __shared__ float s_bc[3];
+  // The table travels as a kernel argument, and the kernarg segment is HOST memory: a lane-indexed read of it (the binary
+  // search below, then every advance of `lo`) is a round trip over the host link -- nine dependent ones per thread made this
+  // kernel 27 us for 484 k parameters.  ONE round brings the table into LDS (lane i reads entry i), the searches run there.
+  __shared__ int s_off[MMG_ADAM_MAX_TENSORS + 1];
+  __shared__ const float* s_grad[MMG_ADAM_MAX_TENSORS];
+  for (int i = threadIdx.x; i <= tb.n; i += 256) s_off[i] = tb.off[i];
+  for (int i = threadIdx.x; i < tb.n; i += 256) s_grad[i] = tb.grad[i];
   if (threadIdx.x == 0) {
     const float t0 = *step + 1.f;
     s_bc[0] = t0; s_bc[1] = 1.f - powf(b1, t0); s_bc[2] = sqrtf(1.f - powf(b2, t0));
   }
   __syncthreads();
-  const float t = s_bc[0], bc1 = s_bc[1], bc2s = s_bc[2];
+  const float bc1 = s_bc[1], bc2s = s_bc[2];
   const float step_size = lr / bc1;
-  const int total = tb.off[tb.n] - tb.off[0];
+  const int n_t = tb.n, off0 = s_off[0];
+  const int total = s_off[n_t] - off0;
   // every workgroup owns one contiguous chunk of the bucket, so a thread's elements (256 apart) cross a tensor boundary
   // rarely: one binary search for its first element, then a linear advance
   const int chunk = ((total + gridDim.x - 1) / gridDim.x + 255) & ~255;
   const int beg = blockIdx.x * chunk, end = min(total, beg + chunk);
   int lo = 0;
   {
-    const int e0 = tb.off[0] + beg + threadIdx.x;
-    int hi = tb.n;
+    const int e0 = off0 + beg + threadIdx.x;
+    int hi = n_t;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if (tb.off[mid] <= e0) lo = mid; else hi = mid;
+      if (s_off[mid] <= e0) lo = mid; else hi = mid;
     }
   }
   for (int i = beg + threadIdx.x; i < end; i += 256) {
-    const int e = tb.off[0] + i;
-    while (lo + 1 < tb.n && tb.off[lo + 1] <= e) ++lo;
-    const float* gp = tb.grad[lo];
+    const int e = off0 + i;
+    while (lo + 1 < n_t && s_off[lo + 1] <= e) ++lo;
+    const float* gp = s_grad[lo];
     if (!gp) continue;
-    float g = gp[e - tb.off[lo]];
+    float g = gp[e - s_off[lo]];
     const float pv = p[e];
     if (wd != 0.f) g = fmaf(wd, pv, g);
     const float mv = fmaf(b1, m[e], (1.f - b1) * g);
@@ -60,15 +68,12 @@ __global__ __launch_bounds__(256) void k_adam(AdamTable tb, float* __restrict__ 
     m[e] = mv; v[e] = vv;
     p[e] = pv - step_size * (mv / (sqrtf(vv) / bc2s + eps));
   }
-  if (bump) {                                    // the last workgroup to finish advances the step counter
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      const unsigned old = atomicAdd(ticket, 1u);
-      if (old == gridDim.x - 1) { *step = t; *ticket = 0u; }
-    }
-  }
 }
+
+// The step counter advances in a launch of its own behind the update (one thread).  It used to be the last workgroup to
+// finish -- __threadfence() + a ticket per workgroup: on this chip a device-scope fence writes the XCD's L2 back, and a
+// thousand of them made the kernel 33 us instead of 4 (measured with the tail compiled out).
+__global__ void k_adam_bump(float* __restrict__ step) { *step += 1.f; }
 
 struct SumJobs {
   float* dst[MMG_SUM_MAX_JOBS];
@@ -118,13 +123,13 @@ static int adam_launch(float* p, float* m, float* v, const float* const* grads, 
     tb.off[n] = offsets[t0 + n];
     MMG_CHECK_ARG(tb.off[n] >= tb.off[0], "adam_step: offsets must ascend");
     const int total = tb.off[n] - tb.off[0];
-    int nb = (total + 256 * 8 - 1) / (256 * 8);
+    // two elements per thread up to 2048 workgroups: the launch is all latency (a few loads per element), not bandwidth
+    int nb = (total + 256 * 2 - 1) / (256 * 2);
     if (nb < 1) nb = 1;
-    if (nb > 512) nb = 512;
-    const int last = t0 + MMG_ADAM_MAX_TENSORS >= n_tensors;
-    hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, st, tb, p, m, v, lr, beta1, beta2, eps, weight_decay, hyper, step, ticket,
-                       last);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, st, tb, p, m, v, lr, beta1, beta2, eps, weight_decay, hyper, step);
   }
+  hipLaunchKernelGGL(k_adam_bump, dim3(1), dim3(1), 0, st, step);       // every launch above read the same t
   MMG_CHECK_LAUNCH("adam_step");
   return MMG_OK;
 }
